@@ -1,0 +1,284 @@
+"""Model descriptors for the MI355X engine -- host side of the reference's chirpgp/models.py.
+
+The reference hands its filters Python closures (``cond_m_cov(u, dt)``, ``a(u)``, ``b(u)``, ``h(x)``) that JAX traces
+and differentiates (filters_smoothers.py:255, 382).  A HIP kernel cannot call a closure, so the same builder
+functions here return *descriptor objects*: they are still callable (NumPy, for simulating data or inspecting a
+model on the host) but what the filters consume is ``(model_id, d, n_harm, params)``, which is marshalled to the
+C-ABI (include/chirpgp_hip.h) where the model and its analytic Jacobian are evaluated on the device.
+
+Names, argument order and return tuples follow chirpgp/models.py.  Every ``params`` entry may carry a leading
+batch axis (one parameter vector per trial: parameter sweeps / MLE grids).
+"""
+import math
+import numpy as np
+
+__all__ = ['g', 'g_inv', 'DiscreteModel', 'DriftModel', 'Dispersion', 'MeasurementKPT',
+           'linear_cond_m_cov', 'linear_sde',
+           'model_chirp', 'model_harmonic_chirp', 'model_lascala',
+           'disc_chirp_lcd', 'disc_harmonic_chirp_lcd', 'disc_model_lascala_lcd', 'disc_m32',
+           'build_chirp_model', 'build_harmonic_chirp_model', 'build_lascala_model', 'build_kpt_chirp_model']
+
+# model ids of include/chirpgp_hip.h
+M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
+
+
+def g(x):
+    """Positive bijection log(exp(x) + 1) (models.py:50)."""
+    return np.log(np.exp(x) + 1.)
+
+
+def g_inv(x):
+    """models.py:53."""
+    return np.log(np.exp(x) - 1.)
+
+
+def _f64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def _m32(ell, sigma, dt):
+    """Closed-form Matern-3/2 discretisation (models.py:61-73), host evaluation."""
+    gamma = math.sqrt(3) / ell
+    eta = dt * gamma
+    beta = sigma ** 2 * math.exp(-2 * eta)
+    F = np.array([[1 + eta, dt], [-dt * gamma ** 2, 1 - eta]]) * math.exp(-eta)
+    off = 2 * dt ** 2 * gamma ** 3 * beta
+    S = np.array([[sigma ** 2 - beta * (2 * eta + 2 * eta ** 2 + 1), off],
+                  [off, gamma ** 2 * (sigma ** 2 + beta * (2 * eta - 2 * eta ** 2 - 1))]])
+    return F, S
+
+
+def _blkdiag(blocks):
+    blocks = [np.atleast_2d(b) for b in blocks]
+    n = sum(b.shape[0] for b in blocks)
+    out = np.zeros((n, n))
+    k = 0
+    for b in blocks:
+        out[k:k + b.shape[0], k:k + b.shape[0]] = b
+        k += b.shape[0]
+    return out
+
+
+class _Spec:
+    model_id = -1
+
+    def __init__(self, d, n_harm, params):
+        self.d = int(d)
+        self.n_harm = int(n_harm)
+        self.params = _f64(params)
+        self.gamma = None
+
+    @property
+    def batched(self):
+        return self.params.ndim == 2
+
+    def _single(self):
+        if self.batched:
+            raise ValueError('host evaluation of a batched model descriptor is not defined; index its params first')
+        return self.params
+
+    def __repr__(self):
+        return f'{type(self).__name__}(id={self.model_id}, d={self.d}, n_harm={self.n_harm}, params{self.params.shape})'
+
+
+class DiscreteModel(_Spec):
+    """Descriptor of a ``cond_m_cov(u, dt) -> (mean, cov)`` callable."""
+
+    def __init__(self, model_id, d, n_harm, params):
+        super().__init__(d, n_harm, params)
+        self.model_id = model_id
+
+    def __call__(self, u, dt):
+        p, d = self._single(), self.d
+        u = np.asarray(u)
+        if self.model_id == M_LINEAR:
+            return p[:d * d].reshape(d, d) @ u, p[d * d:].reshape(d, d)
+        if self.model_id == M_LASCALA_LCD:
+            lam, b, ell, sigma, fs = 0., 0., p[0], p[1], 1.
+        else:
+            lam, b, ell, sigma, fs = p
+        w = 2 * math.pi * g(u[-2]) * fs
+        rho = math.exp(-lam * dt)
+        blocks = []
+        for k in range(1, self.n_harm + 1):
+            c, s = np.cos(dt * k * w), np.sin(dt * k * w)
+            blocks.append(np.array([[c, -s], [s, c]]) * rho)
+        Fm, Sm = _m32(ell, sigma, dt)
+        q = b ** 2 * dt if lam == 0. else b ** 2 / (2 * lam) * (1 - math.exp(-2 * lam * dt))
+        return _blkdiag(blocks + [Fm]) @ u, _blkdiag([q] * (2 * self.n_harm) + [Sm])
+
+
+class DriftModel(_Spec):
+    """Descriptor of an SDE drift ``a(u)``."""
+
+    def __init__(self, model_id, d, n_harm, params):
+        super().__init__(d, n_harm, params)
+        self.model_id = model_id
+
+    def __call__(self, u):
+        p, d = self._single(), self.d
+        u = np.asarray(u)
+        if self.model_id == M_LINEAR_SDE:
+            return p.reshape(d, d) @ u
+        lam, ell, fs = p
+        gam = math.sqrt(3) / ell
+        w = 2 * math.pi * g(u[-2]) * fs
+        blocks = [np.array([[-lam, -w * k], [w * k, -lam]]) for k in range(1, self.n_harm + 1)]
+        return _blkdiag(blocks + [np.array([[0., 1.], [-(gam ** 2), -2 * gam]])]) @ u
+
+
+class Dispersion:
+    """Constant dispersion ``b(u) -> (d, dw)`` matrix (every model of the path has a state-independent one)."""
+
+    def __init__(self, matrix):
+        self.matrix = _f64(matrix)
+
+    def __call__(self, _=None):
+        return self.matrix
+
+    def outer(self):
+        """gamma = b b^T, with a leading batch axis if the matrix has one."""
+        return self.matrix @ np.swapaxes(self.matrix, -1, -2)
+
+
+class MeasurementKPT:
+    """h(x) = sum_k x[k] sin(k g(x[0] + x[-1])) of the KPT model (models.py:575-578)."""
+
+    def __init__(self, num_harmonics):
+        self.n_harm = int(num_harmonics)
+
+    def __call__(self, x):
+        x = np.asarray(x)
+        ks = np.arange(1, self.n_harm + 1)
+        return np.dot(x[1:-1], np.sin(g(x[0] + x[-1]) * ks))
+
+
+# --------------------------------------------------------------------------- generic linear descriptors
+def linear_cond_m_cov(F, Sigma):
+    """Descriptor of ``lambda u, dt: (F @ u, Sigma)`` (the linear test model of test_filters_smoothers.py:56-58)."""
+    F, Sigma = _f64(F), _f64(Sigma)
+    d = F.shape[-1]
+    lead = F.shape[:-2]
+    params = np.concatenate([F.reshape(lead + (d * d,)), np.broadcast_to(Sigma, lead + (d, d)).reshape(lead + (d * d,))], axis=-1)
+    return DiscreteModel(M_LINEAR, d, 0, params)
+
+
+def linear_sde(A, B):
+    """Descriptors of ``drift = lambda u: A @ u`` and ``dispersion = lambda _: B``."""
+    A = _f64(A)
+    d = A.shape[-1]
+    return DriftModel(M_LINEAR_SDE, d, 0, A.reshape(A.shape[:-2] + (d * d,))), Dispersion(B)
+
+
+# --------------------------------------------------------------------------- chirp models (models.py)
+def _stack(*cols):
+    cols = np.broadcast_arrays(*[np.asarray(c, dtype=np.float64) for c in cols])
+    return np.stack(cols, axis=-1)
+
+
+def _diag_rows(cols):
+    """Batched np.diag from a list of (possibly batched) diagonal entries."""
+    v = _stack(*cols)
+    out = np.zeros(v.shape + (v.shape[-1],))
+    idx = np.arange(v.shape[-1])
+    out[..., idx, idx] = v
+    return out
+
+
+def model_harmonic_chirp(lam, b, ell, sigma, delta, num_harmonics=1, freq_scale=1.):
+    """models.py:122-178 -> (drift, dispersion, m0, P0, H)."""
+    n = int(num_harmonics)
+    d = 2 * n + 2
+    lam, b, ell, sigma, delta = (np.asarray(x, dtype=np.float64) for x in (lam, b, ell, sigma, delta))
+    drift = DriftModel(M_HARMONIC_SDE, d, n, _stack(lam, ell, freq_scale))
+    dispersion = Dispersion(_diag_rows([b, b] * n + [0., 2 * sigma * (math.sqrt(3) / ell) ** 1.5]))
+    m0 = np.array([0., 1.] * n + [0., 0.])
+    P0 = _diag_rows([delta, delta] * n + [sigma ** 2, (math.sqrt(3) / ell) ** 2 * sigma ** 2])
+    H = np.array([0., 1.] * n + [0., 0.])
+    return drift, dispersion, m0, P0, H
+
+
+def model_chirp(lam, b, ell, sigma, delta):
+    """models.py:76-119."""
+    return model_harmonic_chirp(lam, b, ell, sigma, delta, 1, 1.)
+
+
+def model_lascala(ell, sigma, delta):
+    """models.py:181-261 (no damping, no chirp dispersion)."""
+    return model_harmonic_chirp(0., 0., ell, sigma, delta, 1, 1.)
+
+
+def disc_harmonic_chirp_lcd(lam, b, ell, sigma, num_harmonics=1, freq_scale=1.):
+    """models.py:332-386."""
+    n = int(num_harmonics)
+    return DiscreteModel(M_HARMONIC_LCD, 2 * n + 2, n, _stack(lam, b, ell, sigma, freq_scale))
+
+
+def disc_chirp_lcd(lam, b, ell, sigma):
+    """models.py:264-311."""
+    return disc_harmonic_chirp_lcd(lam, b, ell, sigma, 1, 1.)
+
+
+def disc_model_lascala_lcd(ell, sigma):
+    """models.py:419-434."""
+    return DiscreteModel(M_LASCALA_LCD, 4, 1, _stack(ell, sigma))
+
+
+def disc_m32(ell, sigma):
+    """models.py:408-416, as a linear descriptor factory: call the result with dt via ``.at(dt)``."""
+    class _M32:
+        def at(self, dt):
+            return linear_cond_m_cov(*_m32(ell, sigma, dt))
+
+        def __call__(self, u, dt):
+            F, S = _m32(ell, sigma, dt)
+            return F @ np.asarray(u), S
+    return _M32()
+
+
+def _split(params, n):
+    p = np.asarray(params, dtype=np.float64)
+    if p.shape[-1] != n:
+        raise ValueError(f'expected {n} parameters, got shape {p.shape}')
+    return [p[..., i] for i in range(n)]
+
+
+def build_harmonic_chirp_model(params, num_harmonics=1, freq_scale=1.):
+    """models.py:462-494.  params = lam, b, delta, ell, sigma, m0_1 (optionally with a leading batch axis)."""
+    lam, b, delta, ell, sigma, m0_v = _split(params, 6)
+    drift, dispersion, _, P0, H = model_harmonic_chirp(lam, b, ell, sigma, delta, num_harmonics, freq_scale)
+    m0 = _stack(*([0., 1.] * int(num_harmonics) + [m0_v, 0.]))
+    m_and_cov = disc_harmonic_chirp_lcd(lam, b, ell, sigma, num_harmonics, freq_scale)
+    return drift, dispersion, m_and_cov, m0, P0, H
+
+
+def build_chirp_model(params):
+    """models.py:437-459.  Note m0 = [0, 0, m0_v, 0] here (not the harmonic builder's [0, 1, ...])."""
+    lam, b, delta, ell, sigma, m0_v = _split(params, 6)
+    drift, dispersion, _, P0, H = model_chirp(lam, b, ell, sigma, delta)
+    m0 = _stack(0., 0., m0_v, 0.)
+    return drift, dispersion, disc_chirp_lcd(lam, b, ell, sigma), m0, P0, H
+
+
+def build_lascala_model(params):
+    """models.py:497-519.  params = delta, ell, sigma, m0_1."""
+    delta, ell, sigma, m0_v = _split(params, 4)
+    drift, dispersion, _, P0, H = model_lascala(ell, sigma, delta)
+    # model_lascala's dispersion has zeros on the chirp rows (models.py:254-255)
+    return drift, dispersion, disc_model_lascala_lcd(ell, sigma), _stack(0., 0., m0_v, 0.), P0, H
+
+
+def build_kpt_chirp_model(params, fs, num_harmonics=1):
+    """models.py:522-580 -> F, Sigma, m0, P0, h."""
+    q1, q2, p0, f0, a0 = [float(x) for x in params]
+    n = int(num_harmonics)
+    dim_x = n + 2
+    P0 = p0 * np.eye(dim_x)
+    m0 = np.array([2 * math.pi * f0 / fs] + [a0] * n + [0.])
+    F = np.eye(dim_x)
+    F[-1, 0] = 1.
+    Sigma = np.zeros((dim_x, dim_x))
+    Sigma[0, 0] = (2 * math.pi * q1 / fs) ** 2
+    for k in range(1, n + 1):
+        Sigma[k, k] = q2
+    return F, Sigma, m0, P0, MeasurementKPT(n)

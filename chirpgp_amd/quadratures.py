@@ -1,0 +1,77 @@
+"""Sigma-point sets for the MI355X engine -- host side of chirpgp/quadratures.py.
+
+The point sets are tiny host constants (81 x 4 doubles for Gauss-Hermite order 3 in d = 4) built once in NumPy
+and uploaded; everything that uses them per step -- chi = m + chol(P) xi, the model evaluations, the weighted
+sums, the RK4 stages -- runs inside the HIP kernels (csrc/cgp_sigma.hpp).  ``gaussian_expectation`` is the
+post-smoother step of every driver (demos/ekfs_mle.py:73-75) and runs on the device as well.
+"""
+import math
+from typing import NamedTuple, Optional
+import numpy as np
+
+__all__ = ['SigmaPoints', 'gaussian_expectation']
+
+
+def _hermite_physicists(order):
+    """Coefficient arrays (highest degree first) of H_0 .. H_order."""
+    hs = [np.array([1.]), np.array([2., 0.])]
+    while len(hs) <= order:
+        n = len(hs)
+        hs.append(2. * np.append(hs[-1], 0.) - 2. * (n - 1) * np.pad(hs[-2], (2, 0)))
+    return hs
+
+
+class SigmaPoints(NamedTuple):
+    """Same fields as the reference's SigmaPoints (quadratures.py:84-110): d, n_points, w (s,), wc, xi (s, d)."""
+    d: int
+    n_points: int
+    w: np.ndarray
+    wc: Optional[np.ndarray]
+    xi: np.ndarray
+
+    @classmethod
+    def cubature(cls, d: int):
+        """Spherical cubature rule: 2d points +-sqrt(d) e_i with equal weights (quadratures.py:138-150)."""
+        eye = np.eye(d)
+        return cls(d, 2 * d, np.full(2 * d, 1. / (2 * d)), None, math.sqrt(d) * np.vstack([eye, -eye]))
+
+    @classmethod
+    def unscented(cls, d: int, alpha: float, beta: float, lam: float):
+        """Not implemented in the reference either (quadratures.py:152-154)."""
+        raise NotImplementedError('Unscented transform is not implemented.')
+
+    @classmethod
+    def gauss_hermite(cls, d: int, order: int = 3):
+        """Tensor-product Gauss-Hermite rule with order**d points (quadratures.py:156-196).
+
+        Point n has 1-D node index (n // order**r) % order along dimension r, so dimension 0 varies fastest;
+        the 1-D nodes are the Hermite roots in the order np.flip(np.roots(.)) gives, as in the reference.
+        """
+        hs = _hermite_physicists(order)
+        nodes = np.real(np.flip(np.roots(hs[order])))
+        w1 = (2. ** (order - 1) * math.factorial(order) * math.sqrt(math.pi)
+              / (order ** 2 * np.polyval(hs[order - 1], nodes) ** 2))
+        idx = (np.arange(order ** d)[None, :] // (order ** np.arange(d))[:, None]) % order      # (d, s)
+        w = np.prod(w1[idx], axis=0) / math.sqrt(math.pi) ** d
+        return cls(d, order ** d, np.ascontiguousarray(w), None, np.ascontiguousarray(math.sqrt(2.) * nodes[idx].T))
+
+    def gen_sigma_points(self, m, chol_of_P):
+        """chi_i = m + chol(P) xi_i (host helper; the kernels do this per step on the device)."""
+        return np.asarray(m) + np.asarray(self.xi) @ np.asarray(chol_of_P).T
+
+    def expectation(self, evals_of_integrand):
+        return np.tensordot(self.w, np.asarray(evals_of_integrand), axes=(0, 0))
+
+
+def gaussian_expectation(ms, chol_Ps, func=None, d: int = 1, order: int = 10, force_shape: bool = False):
+    """E[g(V_t)] for scalar Gaussian marginals by 1-D Gauss-Hermite, on the device (quadratures.py:234-274).
+
+    Only the reference's own use is supported: d = 1 and func = g (softplus), which is what every driver calls
+    (demos/ekfs_mle.py:73-75).  Returns an array of shape (T, 1) like the reference.
+    """
+    from chirpgp_amd import models as _models
+    from chirpgp_amd import _engine
+    if d != 1 or (func is not None and func is not _models.g):
+        raise NotImplementedError('the device kernel implements d = 1, func = g (the reference drivers\' only use)')
+    sg = SigmaPoints.gauss_hermite(1, order)
+    return _engine.gaussian_expectation(ms, chol_Ps, sg.xi[:, 0], sg.w)

@@ -1,0 +1,149 @@
+/*
+ * chirpgp_hip.h -- C-ABI of libchirpgp_hip.so, the MI355X (gfx950) batched Kalman / RTS engine.
+ *
+ * Drop-in boundary for the hot path of spdes/chirpgp, chirpgp/filters_smoothers.py.  The reference is a
+ * pure-Python/JAX module with no FFI of its own, so these entry points are what a binding
+ * for that module would bind; each one names the reference functions it replaces:
+ *
+ *   cgp_filter   (method = CGP_F_EKF,     model = CGP_M_LINEAR)        kf          filters_smoothers.py:145-184
+ *   cgp_filter   (method = CGP_F_EKF,     model = *_LCD)               ekf         filters_smoothers.py:222-264
+ *   cgp_filter   (method = CGP_F_EKF_KPT, model = CGP_M_KPT)           ekf_for_kpt filters_smoothers.py:267-314
+ *   cgp_filter   (method = CGP_F_SGP)                                  sgp_filter  filters_smoothers.py:446-490
+ *   cgp_filter   (method = CGP_F_CD_EKF,  model = *_SDE)               cd_ekf      filters_smoothers.py:352-397
+ *   cgp_filter   (method = CGP_F_CD_SGP,  model = *_SDE)               cd_sgp_filter   filters_smoothers.py:534-582
+ *   cgp_smoother (method = CGP_S_EKS,     model = CGP_M_LINEAR)        rts         filters_smoothers.py:187-219
+ *   cgp_smoother (method = CGP_S_EKS,     model = *_LCD)               eks         filters_smoothers.py:317-349
+ *   cgp_smoother (method = CGP_S_SGP)                                  sgp_smoother    filters_smoothers.py:493-531
+ *   cgp_smoother (method = CGP_S_CD_EKS)                               cd_eks      filters_smoothers.py:400-443
+ *   cgp_smoother (method = CGP_S_CD_SGP)                               cd_sgp_smoother filters_smoothers.py:585-632
+ *   cgp_gaussian_expectation                                           gaussian_expectation quadratures.py:234-274
+ *
+ * The leading batch axis B is the reference's jax.vmap(..., in_axes=0) over ys (tetralith/jobs/crlb_ekf.py:68-72).
+ *
+ * Conventions
+ *   - every array pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()); float64,
+ *     C-contiguous, batch-major: ys [B][T], mfs [B][T][d], Pfs [B][T][d][d], nll [B][T];
+ *   - the library allocates nothing the caller sees and never frees caller memory; outputs are fully overwritten;
+ *   - calls enqueue work on `stream` (a hipStream_t, NULL = default stream) and return without synchronising;
+ *   - return value 0 = success, negative = CGP_E_* (message via cgp_last_error);
+ *   - numerical breakdown (non-PD covariance in a Cholesky) is NOT an error: NaN is written where the
+ *     reference (JAX) would produce NaN and the run continues;
+ *   - model callables of the reference (cond_m_cov, a, b, h) are replaced by an enumerated model set with
+ *     analytic Jacobians (cgp_model); "stride" fields are in doubles, 0 = shared by all trials.
+ */
+#ifndef CHIRPGP_HIP_H
+#define CHIRPGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGP_VERSION 100          /* 0.1.0 */
+#define CGP_MAX_D   8            /* largest state dimension compiled in */
+
+typedef struct cgp_ctx cgp_ctx;
+
+/* ---- filter methods ------------------------------------------------------------------------------------- */
+enum {
+    CGP_F_EKF     = 0,   /* discrete model: (J, mean, Sigma) per step; with CGP_M_LINEAR this is kf             */
+    CGP_F_SGP     = 1,   /* discrete model through sigma points                                                 */
+    CGP_F_CD_EKF  = 2,   /* SDE model, RK4 on the EKF moment ODEs                                               */
+    CGP_F_CD_SGP  = 3,   /* SDE model, RK4 on the sigma-point moment ODEs                                       */
+    CGP_F_EKF_KPT = 4    /* linear dynamics, nonlinear harmonic measurement h (CGP_M_KPT)                       */
+};
+/* ---- smoother methods ----------------------------------------------------------------------------------- */
+enum {
+    CGP_S_EKS    = 0,    /* with CGP_M_LINEAR this is rts */
+    CGP_S_SGP    = 1,
+    CGP_S_CD_EKS = 2,
+    CGP_S_CD_SGP = 3
+};
+
+/* ---- models ---------------------------------------------------------------------------------------------
+ * Discrete (cond_m_cov) models:
+ *   CGP_M_LINEAR        params = [F (d*d, row-major), Sigma (d*d)]                        mean = F u
+ *   CGP_M_HARMONIC_LCD  params = [lam, b, ell, sigma, freq_scale], n_harm >= 1, d = 2 n_harm + 2
+ *                       models.py:332-386 (disc_harmonic_chirp_lcd); n_harm = 1, freq_scale = 1 is
+ *                       disc_chirp_lcd (models.py:264-311)
+ *   CGP_M_LASCALA_LCD   params = [ell, sigma], d = 4                                      models.py:419-434
+ * SDE (drift a, constant dispersion b) models -- gamma = b b^T is passed densely in cgp_model.gamma:
+ *   CGP_M_LINEAR_SDE    params = [A (d*d)]                                                a(u) = A u
+ *   CGP_M_HARMONIC_SDE  params = [lam, ell, freq_scale], n_harm >= 1                       models.py:122-178
+ *                       (n_harm = 1: model_chirp models.py:76-119; lam = 0: model_lascala models.py:181-261)
+ * Measurement model for ekf_for_kpt:
+ *   CGP_M_KPT           params = [F (d*d), Sigma (d*d)], d = n_harm + 2                   models.py:522-580
+ */
+enum {
+    CGP_M_LINEAR       = 0,
+    CGP_M_HARMONIC_LCD = 1,
+    CGP_M_LASCALA_LCD  = 2,
+    CGP_M_LINEAR_SDE   = 3,
+    CGP_M_HARMONIC_SDE = 4,
+    CGP_M_KPT          = 5
+};
+
+typedef struct cgp_model {
+    int32_t       model_id;
+    int32_t       d;             /* state dimension                                  */
+    int32_t       n_harm;        /* harmonic / KPT models, else 0                     */
+    int32_t       n_params;      /* doubles per parameter vector                      */
+    const double* params;        /* [n_params] or [B][param_stride]                   */
+    int64_t       param_stride;  /* 0 = one parameter vector shared by all trials     */
+    const double* gamma;         /* SDE methods: b b^T, [d][d]; else NULL             */
+    int64_t       gamma_stride;  /* 0 = shared                                        */
+} cgp_model;
+
+/* Sigma points (quadratures.py:84-231): chi_i = m + chol(P) xi_i, E[z] ~ sum_i w_i z(chi_i). */
+typedef struct cgp_sigma {
+    int32_t       s;             /* number of points         */
+    int32_t       d;
+    const double* xi;            /* [s][d]                    */
+    const double* w;             /* [s]                       */
+} cgp_sigma;
+
+/* Measurement model and initial condition of a filter. */
+typedef struct cgp_init {
+    const double* H;   int64_t H_stride;     /* [d]    (ignored by CGP_F_EKF_KPT)  */
+    const double* Xi;  int64_t Xi_stride;    /* [1]                                 */
+    const double* m0;  int64_t m0_stride;    /* [d]                                 */
+    const double* P0;  int64_t P0_stride;    /* [d][d]                              */
+} cgp_init;
+
+/* ---- flags ---------------------------------------------------------------------------------------------- */
+#define CGP_NLL_FINAL_ONLY    0x1u   /* nll is [B]: only the last cumulative value (the MLE objective ekf(...)[-1][-1]) */
+#define CGP_WAVE_PER_TRIAL    0x2u   /* force one 64-lane wavefront per trial (small batches; default below a threshold)  */
+#define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
+#define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
+
+/* ---- error codes ---------------------------------------------------------------------------------------- */
+#define CGP_OK              0
+#define CGP_E_ARG          -1
+#define CGP_E_UNSUPPORTED  -2
+#define CGP_E_HIP          -3
+
+int         cgp_version(void);
+int         cgp_create(cgp_ctx** out, int device);
+void        cgp_destroy(cgp_ctx* ctx);
+const char* cgp_last_error(const cgp_ctx* ctx);
+
+/* Filters: reads ys, writes mfs / Pfs / nll (any of the three may be NULL = not wanted). */
+int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+               double dt, const double* ys, int64_t B, int64_t T,
+               double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
+
+/* Smoothers: reads mfs / Pfs, writes mss / Pss (row T-1 is the filtering row T-1). */
+int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
+                 double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
+                 double* mss, double* Pss, uint32_t flags, void* stream);
+
+/* E[softplus(V)] for n scalar Gaussian marginals N(ms[i], sd[i]^2) by 1-D Gauss-Hermite of the given order
+ * (nodes xi[order], weights w[order] already in the reference's scaling): quadratures.py:234-274 with func = g. */
+int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
+                             const double* xi, const double* w, int32_t order, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHIRPGP_HIP_H */
