@@ -1,0 +1,287 @@
+"""ctypes binding of libchirpgp_hip.so (include/chirpgp_hip.h) and the marshalling shared by the public functions.
+
+PyTorch-ROCm is used for device memory, streams and torch.distributed only: every array handed to the library is a
+``torch.Tensor.data_ptr()`` of a float64 CUDA(HIP) tensor; no torch op takes part in the arithmetic.  There is no
+CPU path: a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+import threading
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libchirpgp_hip.so')
+
+# enumerations of include/chirpgp_hip.h
+F_EKF, F_SGP, F_CD_EKF, F_CD_SGP, F_EKF_KPT = range(5)
+S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
+M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
+NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN = 0x1, 0x2, 0x4, 0x8
+MAX_D = 8
+
+_vp = C.c_void_p
+
+
+class CgpModel(C.Structure):
+    _fields_ = [('model_id', C.c_int32), ('d', C.c_int32), ('n_harm', C.c_int32), ('n_params', C.c_int32),
+                ('params', _vp), ('param_stride', C.c_int64), ('gamma', _vp), ('gamma_stride', C.c_int64)]
+
+
+class CgpSigma(C.Structure):
+    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _vp), ('w', _vp)]
+
+
+class CgpInit(C.Structure):
+    _fields_ = [('H', _vp), ('H_stride', C.c_int64), ('Xi', _vp), ('Xi_stride', C.c_int64),
+                ('m0', _vp), ('m0_stride', C.c_int64), ('P0', _vp), ('P0_stride', C.c_int64)]
+
+
+EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
+           'cgp_gaussian_expectation')
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libchirpgp_hip.so and declare the prototypes.  Raises if the library has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               f'or `make -C chirpgp_amd/csrc` (there is no CPU fallback)')
+        lib = C.CDLL(LIB_PATH)
+        lib.cgp_version.restype = C.c_int
+        lib.cgp_create.restype = C.c_int
+        lib.cgp_create.argtypes = [C.POINTER(_vp), C.c_int]
+        lib.cgp_destroy.restype = None
+        lib.cgp_destroy.argtypes = [_vp]
+        lib.cgp_last_error.restype = C.c_char_p
+        lib.cgp_last_error.argtypes = [_vp]
+        lib.cgp_filter.restype = C.c_int
+        lib.cgp_filter.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.POINTER(CgpInit), C.c_double,
+                                   _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_smoother.restype = C.c_int
+        lib.cgp_smoother.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
+                                     _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_gaussian_expectation.restype = C.c_int
+        lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
+        _lib = lib
+        return lib
+
+
+_contexts = {}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def context(device_index=None):
+    """One cgp_ctx per (process, device)."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError('chirpgp_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback')
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    with _lock:
+        ctx = _contexts.get(device_index)
+    if ctx is None:
+        lib = load_library()
+        h = _vp()
+        rc = lib.cgp_create(C.byref(h), int(device_index))
+        if rc != 0:
+            raise RuntimeError(f'cgp_create(device={device_index}) failed with {rc}')
+        with _lock:
+            ctx = _contexts.setdefault(device_index, h)
+    return ctx
+
+
+def _check(ctx, rc, what):
+    if rc != 0:
+        msg = load_library().cgp_last_error(ctx)
+        raise RuntimeError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith('torch')
+
+
+def dev(x, device=None):
+    """-> contiguous float64 tensor on the GPU (uploading NumPy input)."""
+    torch = _torch()
+    if _is_torch(x):
+        t = x
+        if not t.is_cuda:
+            t = t.cuda(device) if device is not None else t.cuda()
+        return t.to(torch.float64).contiguous()
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    t = torch.from_numpy(a)
+    return t.cuda(device) if device is not None else t.cuda()
+
+
+_const_cache = {}
+
+
+def dev_const(x):
+    """Device copy of a small host constant (model parameters, H, m0, P0, sigma points), cached by value so that
+    repeated calls with the same model do not pay a pageable host-to-device copy (which would also serialise the
+    host behind the previous kernel)."""
+    if _is_torch(x):
+        return dev(x)
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    if a.size > 8192:
+        return dev(a)
+    key = (_torch().cuda.current_device(), a.shape, a.tobytes())
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) >= 512:
+            _const_cache.clear()
+        t = _const_cache[key] = dev(a)
+    return t
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return _vp(_torch().cuda.current_stream().cuda_stream)
+
+
+def _batched_operand(x, base_ndim, B, name):
+    """Device tensor of an operand that is shared (base_ndim dims) or per-trial (leading B); returns (tensor, stride)."""
+    t = dev_const(x)
+    if t.ndim == base_ndim:
+        return t, 0
+    if t.ndim == base_ndim + 1 and t.shape[0] == B:
+        per = 1
+        for s in t.shape[1:]:
+            per *= int(s)
+        return t, per
+    raise ValueError(f'{name}: expected {base_ndim} dims (shared) or a leading batch axis of {B}, got shape {tuple(t.shape)}')
+
+
+def _model_struct(spec, gamma, B, keep):
+    params = dev_const(spec.params)
+    if params.ndim == 2 and params.shape[0] != B:
+        raise ValueError(f'model parameters have batch {params.shape[0]} but the data has batch {B}')
+    keep.append(params)
+    m = CgpModel()
+    m.model_id, m.d, m.n_harm, m.n_params = int(spec.model_id), int(spec.d), int(spec.n_harm), int(params.shape[-1])
+    m.params, m.param_stride = _ptr(params), (int(params.shape[-1]) if params.ndim == 2 else 0)
+    if gamma is not None:
+        g, gs = _batched_operand(gamma, 2, B, 'dispersion')
+        if tuple(g.shape[-2:]) != (spec.d, spec.d):
+            raise ValueError(f'b b^T must be {spec.d} x {spec.d}, got {tuple(g.shape)}')
+        keep.append(g)
+        m.gamma, m.gamma_stride = _ptr(g), gs
+    return m
+
+
+def _sigma_struct(sgps, d, keep):
+    if sgps is None:
+        return None
+    xi, w = dev_const(sgps.xi), dev_const(sgps.w)
+    if xi.ndim != 2 or xi.shape[1] != d or w.shape != (xi.shape[0],):
+        raise ValueError(f'sigma points must be (s, {d}) with (s,) weights; got {tuple(xi.shape)}, {tuple(w.shape)}')
+    keep += [xi, w]
+    return CgpSigma(int(xi.shape[0]), int(d), _ptr(xi), _ptr(w))
+
+
+def _out(t, like_numpy, squeeze):
+    if squeeze:
+        t = t[0]
+    return t.cpu().numpy() if like_numpy else t
+
+
+def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, flags=0, want=(True, True, True)):
+    """cgp_filter with NumPy / torch marshalling.  ys (T,) or (B, T) -> (mfs, Pfs, nll) with matching leading axes."""
+    torch = _torch()
+    like_numpy = not _is_torch(ys)
+    ys_d = dev(ys)
+    squeeze = ys_d.ndim == 1
+    if squeeze:
+        ys_d = ys_d[None, :]
+    if ys_d.ndim != 2:
+        raise ValueError(f'ys must be (T,) or (B, T), got {tuple(ys_d.shape)}')
+    B, T = int(ys_d.shape[0]), int(ys_d.shape[1])
+    d = int(spec.d)
+    if d > MAX_D:
+        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    ctx = context(ys_d.device.index)
+    keep = [ys_d]
+    model = _model_struct(spec, gamma, B, keep)
+    sig = _sigma_struct(sgps, d, keep)
+    init = CgpInit()
+    if H is not None:
+        Ht, init.H_stride = _batched_operand(H, 1, B, 'H')
+        if Ht.shape[-1] != d:
+            raise ValueError(f'H must have {d} entries')
+        init.H = _ptr(Ht)
+        keep.append(Ht)
+    Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
+    if Xit.numel() not in (1, B):
+        raise ValueError('Xi must be a scalar or have one entry per trial')
+    init.Xi, init.Xi_stride = _ptr(Xit), (1 if Xit.numel() > 1 else 0)
+    m0t, init.m0_stride = _batched_operand(m0, 1, B, 'm0')
+    P0t, init.P0_stride = _batched_operand(P0, 2, B, 'P0')
+    if m0t.shape[-1] != d or tuple(P0t.shape[-2:]) != (d, d):
+        raise ValueError(f'm0 / P0 must be ({d},) / ({d}, {d})')
+    init.m0, init.P0 = _ptr(m0t), _ptr(P0t)
+    keep += [Xit, m0t, P0t]
+    opts = dict(dtype=torch.float64, device=ys_d.device)
+    mfs = torch.empty((B, T, d), **opts) if want[0] else None
+    Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
+    nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
+    fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
+    rc = load_library().cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                   C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, _stream())
+    _check(ctx, rc, 'cgp_filter')
+    return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
+
+
+def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
+    """cgp_smoother with NumPy / torch marshalling.  (T, d) / (T, d, d) or with a leading batch axis."""
+    torch = _torch()
+    like_numpy = not _is_torch(mfs)
+    m, P = dev(mfs), dev(Pfs)
+    squeeze = m.ndim == 2
+    if squeeze:
+        m, P = m[None], P[None]
+    if m.ndim != 3 or P.ndim != 4 or P.shape[:2] != m.shape[:2] or P.shape[2] != m.shape[2] or P.shape[3] != m.shape[2]:
+        raise ValueError(f'mfs / Pfs must be (B, T, d) / (B, T, d, d); got {tuple(m.shape)} / {tuple(P.shape)}')
+    B, T, d = (int(s) for s in m.shape)
+    if d != int(spec.d):
+        raise ValueError(f'model dimension {spec.d} != data dimension {d}')
+    if d > MAX_D:
+        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    ctx = context(m.device.index)
+    keep = [m, P]
+    model = _model_struct(spec, gamma, B, keep)
+    sig = _sigma_struct(sgps, d, keep)
+    mss, Pss = torch.empty_like(m), torch.empty_like(P)
+    rc = load_library().cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None, float(dt),
+                                     _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), _stream())
+    _check(ctx, rc, 'cgp_smoother')
+    return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
+
+
+def gaussian_expectation(ms, chol_Ps, xi, w):
+    """E[softplus(V)] for scalar marginals on the device -> (n, 1) like the reference's force_shape=True call."""
+    torch = _torch()
+    like_numpy = not _is_torch(ms)
+    m, s = dev(ms).reshape(-1), dev(chol_Ps).reshape(-1)
+    if m.shape != s.shape:
+        raise ValueError('ms and chol_Ps must have the same number of entries')
+    ctx = context(m.device.index)
+    xi_d, w_d = dev(xi).reshape(-1), dev(w).reshape(-1)
+    out = torch.empty_like(m)
+    rc = load_library().cgp_gaussian_expectation(ctx, _ptr(m), _ptr(s), m.numel(), 1, _ptr(xi_d), _ptr(w_d), xi_d.numel(),
+                                                 _ptr(out), _stream())
+    _check(ctx, rc, 'cgp_gaussian_expectation')
+    out = out.reshape(-1, 1)
+    return out.cpu().numpy() if like_numpy else out

@@ -1,0 +1,187 @@
+// cgp_api.hip -- the C-ABI of include/chirpgp_hip.h: argument checks, launch-shape choice, dispatch.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "cgp_kernels.hpp"
+
+struct cgp_ctx {
+    int device;
+    int num_cus;
+    std::string err;
+};
+
+namespace cgp {
+
+static int fail(cgp_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// One wavefront per trial until the batch alone fills every SIMD several times over; beyond that one lane per trial
+// keeps all 64 lanes busy (the per-step work of a trial is far too small to split across lanes).
+static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags) {
+    if (flags & CGP_WAVE_PER_TRIAL) return true;
+    if (flags & CGP_THREAD_PER_TRIAL) return false;
+    const int64_t simds = (int64_t)(ctx ? ctx->num_cus : 256) * 4;
+    return B < simds * 8;
+}
+
+static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sigma, const cgp_sigma* sg) {
+    if (!m || !m->params) return fail(ctx, CGP_E_ARG, "model or model.params is NULL");
+    if (m->d < 1 || m->d > CGP_MAX_D) return fail(ctx, CGP_E_UNSUPPORTED, "state dimension outside 1.." + std::to_string(CGP_MAX_D));
+    int want_params = -1, want_d = m->d;
+    switch (m->model_id) {
+    case CGP_M_LINEAR: case CGP_M_KPT: want_params = 2 * m->d * m->d; if (m->model_id == CGP_M_KPT) want_d = m->n_harm + 2; break;
+    case CGP_M_HARMONIC_LCD: want_params = 5; want_d = 2 * m->n_harm + 2; break;
+    case CGP_M_LASCALA_LCD: want_params = 2; want_d = 4; break;
+    case CGP_M_LINEAR_SDE: want_params = m->d * m->d; break;
+    case CGP_M_HARMONIC_SDE: want_params = 3; want_d = 2 * m->n_harm + 2; break;
+    default: return fail(ctx, CGP_E_ARG, "unknown model_id");
+    }
+    if (m->n_params != want_params) return fail(ctx, CGP_E_ARG, "model.n_params does not match model_id / d");
+    if (m->d != want_d) return fail(ctx, CGP_E_ARG, "model.d does not match model_id / n_harm");
+    if (m->param_stride != 0 && m->param_stride < m->n_params) return fail(ctx, CGP_E_ARG, "model.param_stride < n_params");
+    const bool is_sde = m->model_id == CGP_M_LINEAR_SDE || m->model_id == CGP_M_HARMONIC_SDE;
+    if (sde != is_sde) return fail(ctx, CGP_E_ARG, sde ? "continuous-discrete methods need an SDE model" : "discrete methods need a discrete (cond_m_cov) model");
+    if (sde && !m->gamma) return fail(ctx, CGP_E_ARG, "SDE methods need model.gamma = b b^T");
+    if (need_sigma) {
+        if (!sg || !sg->xi || !sg->w || sg->s < 1) return fail(ctx, CGP_E_ARG, "sigma-point methods need a cgp_sigma");
+        if (sg->d != m->d) return fail(ctx, CGP_E_ARG, "cgp_sigma.d != model.d");
+    }
+    return CGP_OK;
+}
+
+static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt) {
+    ModelArgs a;
+    a.params = m->params; a.param_stride = m->param_stride;
+    a.gamma = m->gamma; a.gamma_stride = m->gamma_stride;
+    a.model_id = m->model_id;
+    a.sg.xi = sg ? sg->xi : nullptr; a.sg.w = sg ? sg->w : nullptr; a.sg.s = sg ? sg->s : 0;
+    a.dt = dt;
+    return a;
+}
+
+__global__ void __launch_bounds__(256) gaussian_expectation_kernel(const double* __restrict__ ms, const double* __restrict__ sd,
+                                                                   int64_t n, int64_t stride, const double* __restrict__ xi,
+                                                                   const double* __restrict__ w, int order, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double m = ms[i * stride], s = sd[i * stride];
+        double acc = 0.0;
+        for (int p = 0; p < order; p++) acc = fma(w[p], log(exp(fma(s, xi[p], m)) + 1.0), acc);
+        out[i] = acc;
+    }
+}
+
+}  // namespace cgp
+
+using namespace cgp;
+
+extern "C" {
+
+int cgp_version(void) { return CGP_VERSION; }
+
+int cgp_create(cgp_ctx** out, int device) {
+    if (!out) return CGP_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CGP_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CGP_E_HIP;
+    cgp_ctx* c = new cgp_ctx;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return CGP_OK;
+}
+
+void cgp_destroy(cgp_ctx* ctx) { delete ctx; }
+
+const char* cgp_last_error(const cgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+               double dt, const double* ys, int64_t B, int64_t T, double* mfs, double* Pfs, double* nll,
+               uint32_t flags, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
+    if (B == 0 || T == 0) return CGP_OK;
+    if (!ys) return fail(ctx, CGP_E_ARG, "ys is NULL");
+    if (!init || !init->Xi || !init->m0 || !init->P0) return fail(ctx, CGP_E_ARG, "init.Xi / m0 / P0 must be set");
+    if (method != CGP_F_EKF_KPT && !init->H) return fail(ctx, CGP_E_ARG, "init.H must be set");
+    const bool sde = method == CGP_F_CD_EKF || method == CGP_F_CD_SGP;
+    const bool sig = method == CGP_F_SGP || method == CGP_F_CD_SGP;
+    if (method < CGP_F_EKF || method > CGP_F_EKF_KPT) return fail(ctx, CGP_E_ARG, "unknown filter method");
+    int rc = check_model(ctx, model, sde, sig, sigma);
+    if (rc != CGP_OK) return rc;
+    if ((method == CGP_F_EKF_KPT) != (model->model_id == CGP_M_KPT)) return fail(ctx, CGP_E_ARG, "CGP_F_EKF_KPT goes with CGP_M_KPT only");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+
+    FilterIO io;
+    io.H = init->H; io.H_stride = init->H_stride;
+    io.Xi = init->Xi; io.Xi_stride = init->Xi_stride;
+    io.m0 = init->m0; io.m0_stride = init->m0_stride;
+    io.P0 = init->P0; io.P0_stride = init->P0_stride;
+    io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
+    const ModelArgs ma = model_args(model, sigma, dt);
+    const bool wave = choose_wave(ctx, B, flags);
+    hipStream_t st = (hipStream_t)stream;
+    switch (model->model_id) {
+    case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_HARMONIC_LCD:
+    case CGP_M_LASCALA_LCD:  rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st); break;
+    case CGP_M_LINEAR_SDE:   rc = dispatch_filter_sde_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_HARMONIC_SDE: rc = dispatch_filter_sde_harm(method, model->n_harm, wave, io, ma, st); break;
+    case CGP_M_KPT:          rc = dispatch_filter_kpt(model->n_harm, wave, io, ma, st); break;
+    default: rc = CGP_E_ARG;
+    }
+    if (rc == CGP_E_UNSUPPORTED) return fail(ctx, rc, "this (method, model, dimension) combination is not compiled in");
+    if (rc == CGP_E_HIP) return fail(ctx, rc, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
+                 const double* mfs, const double* Pfs, int64_t B, int64_t T, double* mss, double* Pss,
+                 uint32_t flags, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
+    if (B == 0 || T == 0) return CGP_OK;
+    if (!mfs || !Pfs || !mss || !Pss) return fail(ctx, CGP_E_ARG, "mfs / Pfs / mss / Pss must be set");
+    if (method < CGP_S_EKS || method > CGP_S_CD_SGP) return fail(ctx, CGP_E_ARG, "unknown smoother method");
+    const bool sde = method == CGP_S_CD_EKS || method == CGP_S_CD_SGP;
+    const bool sig = method == CGP_S_SGP || method == CGP_S_CD_SGP;
+    int rc = check_model(ctx, model, sde, sig, sigma);
+    if (rc != CGP_OK) return rc;
+    if (model->model_id == CGP_M_KPT) return fail(ctx, CGP_E_ARG, "the KPT model has no smoother in the reference");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+
+    SmootherIO io;
+    io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
+    const ModelArgs ma = model_args(model, sigma, dt);
+    const bool wave = choose_wave(ctx, B, flags);
+    hipStream_t st = (hipStream_t)stream;
+    switch (model->model_id) {
+    case CGP_M_LINEAR:       rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_HARMONIC_LCD:
+    case CGP_M_LASCALA_LCD:  rc = dispatch_smoother_disc_harm(method, model->n_harm, wave, io, ma, st); break;
+    case CGP_M_LINEAR_SDE:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_HARMONIC_SDE: rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st); break;
+    default: rc = CGP_E_ARG;
+    }
+    if (rc == CGP_E_UNSUPPORTED) return fail(ctx, rc, "this (method, model, dimension) combination is not compiled in");
+    if (rc == CGP_E_HIP) return fail(ctx, rc, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
+                             const double* xi, const double* w, int32_t order, double* out, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (n < 0 || order < 1) return fail(ctx, CGP_E_ARG, "bad n or order");
+    if (n == 0) return CGP_OK;
+    if (!ms || !sd || !xi || !w || !out) return fail(ctx, CGP_E_ARG, "NULL pointer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    const int64_t blocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL(gaussian_expectation_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ms, sd, n, in_stride, xi, w, order, out);
+    return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
+}
+
+}  // extern "C"

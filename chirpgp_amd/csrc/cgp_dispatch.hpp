@@ -1,0 +1,50 @@
+// cgp_dispatch.hpp -- per-model-family dispatch helpers shared by the cgp_inst_*.hip translation units.
+#pragma once
+#include "cgp_kernels.hpp"
+
+namespace cgp {
+
+template <class DM>
+static int filter_disc(int method, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    using Meas = LinearMeasurement<DM::D>;
+    switch (method) {
+    case CGP_F_EKF:
+        return hip_rc(wave ? launch_filter<EkfPredict<DM, true>, Meas>(io, ma, st) : launch_filter<EkfPredict<DM, false>, Meas>(io, ma, st));
+    case CGP_F_SGP:
+        return hip_rc(wave ? launch_filter<SgpPredict<DM, true>, Meas>(io, ma, st) : launch_filter<SgpPredict<DM, false>, Meas>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+template <class DM>
+static int smoother_disc(int method, bool wave, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (method) {
+    case CGP_S_EKS:
+        return hip_rc(wave ? launch_smoother<EksStep<DM, true>>(io, ma, st) : launch_smoother<EksStep<DM, false>>(io, ma, st));
+    case CGP_S_SGP:
+        return hip_rc(wave ? launch_smoother<SgpsStep<DM, true>>(io, ma, st) : launch_smoother<SgpsStep<DM, false>>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+template <class SM>
+static int filter_sde(int method, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    using Meas = LinearMeasurement<SM::D>;
+    switch (method) {
+    case CGP_F_CD_EKF:
+        return hip_rc(wave ? launch_filter<CdEkfPredict<SM, true>, Meas>(io, ma, st) : launch_filter<CdEkfPredict<SM, false>, Meas>(io, ma, st));
+    case CGP_F_CD_SGP:
+        return hip_rc(wave ? launch_filter<CdSgpPredict<SM, true>, Meas>(io, ma, st) : launch_filter<CdSgpPredict<SM, false>, Meas>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+template <class SM>
+static int smoother_sde(int method, bool wave, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (method) {
+    case CGP_S_CD_EKS:
+        return hip_rc(wave ? launch_smoother<CdEksStep<SM, true>>(io, ma, st) : launch_smoother<CdEksStep<SM, false>>(io, ma, st));
+    case CGP_S_CD_SGP:
+        return hip_rc(wave ? launch_smoother<CdSgpsStep<SM, true>>(io, ma, st) : launch_smoother<CdSgpsStep<SM, false>>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace cgp

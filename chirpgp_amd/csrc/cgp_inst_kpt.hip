@@ -1,0 +1,18 @@
+// ekf_for_kpt: linear dynamics of dimension n_harm + 2 with the harmonic measurement h, n_harm = 1..3.
+#include "cgp_dispatch.hpp"
+namespace cgp {
+template <int NH>
+static int kpt(bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    using DM = LinearDisc<NH + 2>;
+    return hip_rc(wave ? launch_filter<EkfPredict<DM, true>, KptUpdate<NH>>(io, ma, st)
+                       : launch_filter<EkfPredict<DM, false>, KptUpdate<NH>>(io, ma, st));
+}
+int dispatch_filter_kpt(int key, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (key) {
+    case 1: return kpt<1>(wave, io, ma, st);
+    case 2: return kpt<2>(wave, io, ma, st);
+    case 3: return kpt<3>(wave, io, ma, st);
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+}  // namespace cgp

@@ -1,0 +1,22 @@
+// Linear SDE (drift A u, constant dispersion): cd_ekf / cd_eks / cd_sgp_* on the linear test models, d = 1..4.
+#include "cgp_dispatch.hpp"
+namespace cgp {
+int dispatch_filter_sde_linear(int method, int key, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (key) {
+    case 1: return filter_sde<LinearSDE<1>>(method, wave, io, ma, st);
+    case 2: return filter_sde<LinearSDE<2>>(method, wave, io, ma, st);
+    case 3: return filter_sde<LinearSDE<3>>(method, wave, io, ma, st);
+    case 4: return filter_sde<LinearSDE<4>>(method, wave, io, ma, st);
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+int dispatch_smoother_sde_linear(int method, int key, bool wave, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (key) {
+    case 1: return smoother_sde<LinearSDE<1>>(method, wave, io, ma, st);
+    case 2: return smoother_sde<LinearSDE<2>>(method, wave, io, ma, st);
+    case 3: return smoother_sde<LinearSDE<3>>(method, wave, io, ma, st);
+    case 4: return smoother_sde<LinearSDE<4>>(method, wave, io, ma, st);
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+}  // namespace cgp

@@ -1,0 +1,169 @@
+// cgp_kernels.hpp -- the scan kernels: a forward pass over T measurements (filters) and a reverse pass over the
+// filtering results (smoothers), batched over independent trials.  Layouts are the reference's batch-major
+// (B, T, ...) arrays (jax.vmap over ys: tetralith/jobs/crlb_ekf.py:68-72).
+//
+// Launch shapes (block = one 64-lane wavefront in both):
+//   WAVE  = true  : grid = B.   One wavefront per trial; ys is fetched 64 steps at a time with one coalesced 512-B
+//                   load and handed out by v_readlane; lane 0 streams the 8(d + d^2 + 1) output bytes of each step
+//                   (consecutive steps of a trial are contiguous in HBM, so L2 write-combines them into full lines).
+//   WAVE  = false : grid = ceil(B / 64).  One lane per trial (large batches).
+#pragma once
+#include "cgp_steps.hpp"
+#include "../../include/chirpgp_hip.h"
+
+namespace cgp {
+
+struct FilterIO {
+    const double* __restrict__ H;  int64_t H_stride;
+    const double* __restrict__ Xi; int64_t Xi_stride;
+    const double* __restrict__ m0; int64_t m0_stride;
+    const double* __restrict__ P0; int64_t P0_stride;
+    const double* __restrict__ ys;
+    int64_t B, T;
+    double* __restrict__ mfs;
+    double* __restrict__ Pfs;
+    double* __restrict__ nll;
+    uint32_t flags;
+};
+
+struct SmootherIO {
+    const double* __restrict__ mfs;
+    const double* __restrict__ Pfs;
+    int64_t B, T;
+    double* __restrict__ mss;
+    double* __restrict__ Pss;
+    uint32_t flags;
+};
+
+// Linear scalar measurement y = H x + noise (every filter but ekf_for_kpt).
+template <int D> struct LinearMeasurement {
+    CGP_DEV static double update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y, Vec<D>& mf, Sym<D>& Pf) {
+        return scalar_update<D>(mp, Pp, H, Xi, y, false, 0.0, mf, Pf);
+    }
+};
+// ekf_for_kpt (filters_smoothers.py:298-311): H = grad h(mp), pred = h(mp).
+template <int NH> struct KptUpdate {
+    static constexpr int D = NH + 2;
+    CGP_DEV static double update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>&, double Xi, double y, Vec<D>& mf, Sym<D>& Pf) {
+        Vec<D> H;
+        const double pred = KptMeasurement<NH>::eval(mp, H);
+        return scalar_update<D>(mp, Pp, H, Xi, y, true, pred, mf, Pf);
+    }
+};
+
+template <class Pred, class Meas>
+__global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
+    constexpr int D = Pred::D;
+    constexpr bool WAVE = Pred::WAVE;
+    __shared__ double lds[Pred::USES_LDS ? kFanLdsDoubles : 1];
+    const int lane = threadIdx.x;
+    const int64_t trial = WAVE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 64 + lane;
+    if (trial >= io.B) return;
+
+    Pred pred;
+    pred.setup(ma, trial);
+    Vec<D> H, mf;
+    Sym<D> Pf;
+    if (io.H) load_vec<D>(io.H + trial * io.H_stride, H);
+    else { CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0; }
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    load_vec<D>(io.m0 + trial * io.m0_stride, mf);
+    load_sym<D>(io.P0 + trial * io.P0_stride, Pf);
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
+    double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool writer = !WAVE || lane == 0;
+
+    double cum = 0.0, ychunk = 0.0;
+    for (int64_t t = 0; t < T; t++) {
+        double y;
+        if (WAVE) {
+            if ((t & 63) == 0) ychunk = (t + lane < T) ? ys[t + lane] : 0.0;
+            y = readlane_f64(ychunk, (int)(t & 63));
+        } else {
+            y = ys[t];
+        }
+        Vec<D> mp; Sym<D> Pp;
+        pred.predict(lane, lds, mf, Pf, mp, Pp);
+        cum += Meas::update(mp, Pp, H, Xi, y, mf, Pf);
+        if (writer) {
+            if (mfs) store_vec<D>(mfs + t * D, mf);
+            if (Pfs) store_sym_full<D>(Pfs + t * D * D, Pf);
+            if (nll) nll[t] = cum;
+        }
+    }
+    if (writer && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+template <class Step>
+__global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs ma) {
+    constexpr int D = Step::D;
+    constexpr bool WAVE = Step::WAVE;
+    __shared__ double lds[Step::USES_LDS ? kFanLdsDoubles : 1];
+    const int lane = threadIdx.x;
+    const int64_t trial = WAVE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 64 + lane;
+    if (trial >= io.B) return;
+
+    Step step;
+    step.setup(ma, trial);
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * D;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
+    double* __restrict__ mss = io.mss + trial * T * D;
+    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+    const bool writer = !WAVE || lane == 0;
+
+    Vec<D> ms, mf;
+    Sym<D> Ps, Pf;
+    load_vec<D>(mfs + (T - 1) * D, ms);
+    load_sym<D>(Pfs + (T - 1) * D * D, Ps);
+    if (writer) {   // filters_smoothers.py:140-142: the last smoothing row is the last filtering row (copied verbatim)
+        CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+        CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i];
+    }
+    for (int64_t t = T - 2; t >= 0; t--) {
+        load_vec<D>(mfs + t * D, mf);
+        load_sym<D>(Pfs + t * D * D, Pf);
+        step.step(lane, lds, mf, Pf, ms, Ps);
+        if (writer) {
+            store_vec<D>(mss + t * D, ms);
+            store_sym_full<D>(Pss + t * D * D, Ps);
+        }
+    }
+}
+
+template <class Pred, class Meas>
+inline hipError_t launch_filter(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    const unsigned grid = Pred::WAVE ? (unsigned)io.B : (unsigned)((io.B + 63) / 64);
+    hipLaunchKernelGGL((filter_kernel<Pred, Meas>), dim3(grid), dim3(64), 0, stream, io, ma);
+    return hipGetLastError();
+}
+template <class Step>
+inline hipError_t launch_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    const unsigned grid = Step::WAVE ? (unsigned)io.B : (unsigned)((io.B + 63) / 64);
+    hipLaunchKernelGGL((smoother_kernel<Step>), dim3(grid), dim3(64), 0, stream, io, ma);
+    return hipGetLastError();
+}
+
+// Dispatch tables implemented one per translation unit (cgp_inst_*.hip) so that they compile in parallel.
+// `key` is d for the linear models and n_harm for the harmonic / KPT ones.  Return CGP_E_UNSUPPORTED if the
+// combination is not compiled in, CGP_E_HIP on a launch error.
+int dispatch_filter_disc_linear(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_disc_harm(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_sde_linear(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_sde_harm(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_kpt(int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_disc_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_disc_harm(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_sde_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_sde_harm(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? CGP_OK : CGP_E_HIP; }
+
+}  // namespace cgp

@@ -1,0 +1,195 @@
+// cgp_math.hpp -- fixed-size float64 linear algebra held entirely in VGPRs (gfx950).
+//
+// Every container is a plain array indexed only by compile-time constants after full unrolling, so the
+// compiler keeps it in registers (runtime-indexed arrays go to scratch: cdna_hip_programming.md rule 20).
+// Symmetric matrices are stored packed (lower triangle, D(D+1)/2 doubles): d = 4 -> 10, d = 8 -> 36 doubles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#define CGP_DEV __device__ __forceinline__
+#define CGP_UNROLL _Pragma("unroll")
+
+namespace cgp {
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+
+template <int D> struct Vec { double v[D]; };
+template <int D> struct Mat { double a[D][D]; };
+
+template <int D> struct Sym {
+    static constexpr int N = D * (D + 1) / 2;
+    double a[N];
+    static constexpr int idx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+    CGP_DEV double  operator()(int i, int j) const { return a[idx(i, j)]; }
+    CGP_DEV double& operator()(int i, int j) { return a[idx(i, j)]; }
+};
+
+// ---------------------------------------------------------------------------------------------- products
+// T = A P   (A dense, P symmetric)
+template <int D> CGP_DEV void mul_dense_sym(const Mat<D>& A, const Sym<D>& P, Mat<D>& T) {
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            double s = A.a[i][0] * P(0, j);
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(A.a[i][k], P(k, j), s);
+            T.a[i][j] = s;
+        }
+}
+// out = T A^T + C  (lower triangle only; result symmetric by construction of the callers)
+template <int D> CGP_DEV void mul_nt_sym_add(const Mat<D>& T, const Mat<D>& A, const Sym<D>& C, Sym<D>& out) {
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) {
+            double s = T.a[i][0] * A.a[j][0];
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(T.a[i][k], A.a[j][k], s);
+            out(i, j) = s + C(i, j);
+        }
+}
+// out = T + T^T + sign * C   (symmetric)
+template <int D> CGP_DEV void sym_from_sum(const Mat<D>& T, const Sym<D>& C, double sign, Sym<D>& out) {
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) out(i, j) = (T.a[i][j] + T.a[j][i]) + sign * C(i, j);
+}
+template <int D> CGP_DEV void matvec(const Mat<D>& A, const Vec<D>& x, Vec<D>& y) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = A.a[i][0] * x.v[0];
+        CGP_UNROLL for (int k = 1; k < D; k++) s = fma(A.a[i][k], x.v[k], s);
+        y.v[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Cholesky
+// Lower Cholesky factor of a packed symmetric matrix.  Like LAPACK potrf under JAX, a pivot that is <= 0
+// or NaN makes the whole factor NaN (no trap, no exception): SURVEY.md section 5 "silent NaN propagation".
+// Also returns 1/L_ii in inv_diag for the triangular solves.
+template <int D> CGP_DEV void cholesky(const Sym<D>& P, Sym<D>& L, Vec<D>& inv_diag) {
+    bool bad = false;
+    CGP_UNROLL for (int j = 0; j < D; j++) {
+        double s = P(j, j);
+        CGP_UNROLL for (int k = 0; k < j; k++) s = fma(-L(j, k), L(j, k), s);
+        bad = bad || !(s > 0.0);
+        const double ljj = sqrt(s);
+        const double inv = 1.0 / ljj;
+        L(j, j) = ljj;
+        inv_diag.v[j] = inv;
+        CGP_UNROLL for (int i = j + 1; i < D; i++) {
+            double t = P(i, j);
+            CGP_UNROLL for (int k = 0; k < j; k++) t = fma(-L(i, k), L(j, k), t);
+            L(i, j) = t * inv;
+        }
+    }
+    const double poison = bad ? __builtin_nan("") : 0.0;
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) L.a[i] += poison;
+    CGP_UNROLL for (int i = 0; i < D; i++) inv_diag.v[i] += poison;
+}
+
+// Solve (L L^T) x = b for one right-hand side given as D scalars (in place).
+template <int D> CGP_DEV void cho_solve_vec(const Sym<D>& L, const Vec<D>& inv_diag, Vec<D>& x) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = x.v[i];
+        CGP_UNROLL for (int k = 0; k < i; k++) s = fma(-L(i, k), x.v[k], s);
+        x.v[i] = s * inv_diag.v[i];
+    }
+    CGP_UNROLL for (int i = D - 1; i >= 0; i--) {
+        double s = x.v[i];
+        CGP_UNROLL for (int k = i + 1; k < D; k++) s = fma(-L(k, i), x.v[k], s);
+        x.v[i] = s * inv_diag.v[i];
+    }
+}
+// X = (L L^T)^{-1} R, column by column (R and X dense D x D, may alias).
+template <int D> CGP_DEV void cho_solve_mat(const Sym<D>& L, const Vec<D>& inv_diag, const Mat<D>& R, Mat<D>& X) {
+    CGP_UNROLL for (int c = 0; c < D; c++) {
+        Vec<D> col;
+        CGP_UNROLL for (int i = 0; i < D; i++) col.v[i] = R.a[i][c];
+        cho_solve_vec<D>(L, inv_diag, col);
+        CGP_UNROLL for (int i = 0; i < D; i++) X.a[i][c] = col.v[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Kalman pieces
+// Scalar-measurement update, filters_smoothers.py:55-68: S = H^T Pp H + Xi, K = Pp H / S, mf = mp + K (y - pred),
+// Pf = Pp - (K K^T) S (the reference's form, not Joseph), and the increment of the negative log-likelihood in the
+// arithmetic of jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)).
+template <int D>
+CGP_DEV double scalar_update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y,
+                             bool override_pred, double pred_in, Vec<D>& mf, Sym<D>& Pf) {
+    Vec<D> PH;
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = Pp(i, 0) * H.v[0];
+        CGP_UNROLL for (int k = 1; k < D; k++) s = fma(Pp(i, k), H.v[k], s);
+        PH.v[i] = s;
+    }
+    double S = H.v[0] * PH.v[0], pred = H.v[0] * mp.v[0];
+    CGP_UNROLL for (int k = 1; k < D; k++) { S = fma(H.v[k], PH.v[k], S); pred = fma(H.v[k], mp.v[k], pred); }
+    S += Xi;
+    if (override_pred) pred = pred_in;
+    const double innov = y - pred;
+    Vec<D> K;
+    CGP_UNROLL for (int i = 0; i < D; i++) K.v[i] = PH.v[i] / S;
+    CGP_UNROLL for (int i = 0; i < D; i++) mf.v[i] = fma(K.v[i], innov, mp.v[i]);
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) Pf(i, j) = Pp(i, j) - (K.v[i] * K.v[j]) * S;
+    const double sc = sqrt(S), s2 = sc * sc;
+    return 0.5 * (log(kTwoPi * s2) + innov * innov / s2);
+}
+
+// Gaussian smoother step, filters_smoothers.py:71-85: G = (Pp^{-1} DT)^T, ms = mf + G (ms - mp), Ps = Pf + G (Ps - Pp) G^T.
+// DT is dense D x D (the transposed cross-covariance).  ms / Ps are updated in place.
+template <int D>
+CGP_DEV void smoother_gain(const Mat<D>& DT, const Sym<D>& Pp, Mat<D>& G) {
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pp, L, inv);
+    Mat<D> X;
+    cho_solve_mat<D>(L, inv, DT, X);
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) G.a[i][j] = X.a[j][i];
+}
+template <int D>
+CGP_DEV void smoother_apply(const Mat<D>& G, const Vec<D>& mf, const Sym<D>& Pf, const Vec<D>& mp, const Sym<D>& Pp,
+                            Vec<D>& ms, Sym<D>& Ps) {
+    Vec<D> dm; Sym<D> dP;
+    CGP_UNROLL for (int i = 0; i < D; i++) dm.v[i] = ms.v[i] - mp.v[i];
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) dP.a[i] = Ps.a[i] - Pp.a[i];
+    Mat<D> T;
+    mul_dense_sym<D>(G, dP, T);
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = mf.v[i];
+        CGP_UNROLL for (int k = 0; k < D; k++) s = fma(G.a[i][k], dm.v[k], s);
+        ms.v[i] = s;
+    }
+    mul_nt_sym_add<D>(T, G, Pf, Ps);
+}
+
+// ---------------------------------------------------------------------------------------------- memory helpers
+template <int D> CGP_DEV void load_vec(const double* __restrict__ p, Vec<D>& v) {
+    CGP_UNROLL for (int i = 0; i < D; i++) v.v[i] = p[i];
+}
+// Reads the lower triangle of a row-major D x D matrix (what LAPACK potrf / the reference's symmetric maths use).
+template <int D> CGP_DEV void load_sym(const double* __restrict__ p, Sym<D>& P) {
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j <= i; j++) P(i, j) = p[i * D + j];
+}
+template <int D> CGP_DEV void load_mat(const double* __restrict__ p, Mat<D>& A) {
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) A.a[i][j] = p[i * D + j];
+}
+template <int D> CGP_DEV void store_vec(double* __restrict__ p, const Vec<D>& v) {
+    if constexpr (D % 2 == 0) {
+        CGP_UNROLL for (int i = 0; i < D; i += 2) *reinterpret_cast<double2*>(p + i) = make_double2(v.v[i], v.v[i + 1]);
+    } else {
+        CGP_UNROLL for (int i = 0; i < D; i++) p[i] = v.v[i];
+    }
+}
+template <int D> CGP_DEV void store_sym_full(double* __restrict__ p, const Sym<D>& P) {
+    if constexpr (D % 2 == 0) {
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j < D; j += 2) *reinterpret_cast<double2*>(p + i * D + j) = make_double2(P(i, j), P(i, j + 1));
+    } else {
+        CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) p[i * D + j] = P(i, j);
+    }
+}
+
+// Wave-uniform broadcast of a double held in lane `src` (src may be a runtime, wave-uniform value).
+CGP_DEV double readlane_f64(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace cgp

@@ -1,0 +1,243 @@
+// cgp_models.hpp -- device-side models of the path with hand-derived Jacobians (SURVEY.md notes N1, N2).
+//
+// Discrete models  (the reference's cond_m_cov(u, dt) closures, chirpgp/models.py:264-311, 332-386, 419-434):
+//     mean(u)                          conditional mean f(u)
+//     propagate(u, P, f, T, Pp)        f(u), T = J(u) P, Pp = T J(u)^T + Sigma   (EKF predict; T is the smoother's DT)
+//     add_sigma(S, w)                  S += w * Sigma
+// SDE models       (drift a(u), models.py:104-110, 164-168; constant dispersion passed as gamma = b b^T):
+//     drift(u, a), drift_jp(u, P, a, T)   a(u), T = J_a(u) P,  jac_dense(u, J)
+//
+// The harmonic family has J = blockdiag(rho Rot(k theta), M32) + one dense column (d/d u_v), which the products below
+// exploit: ~4.5 d^2 FMAs instead of 4 d^3.
+#pragma once
+#include "cgp_math.hpp"
+
+namespace cgp {
+
+// softplus in the reference's naive form log(exp(x) + 1) (models.py:50) and its derivative as jax.jacfwd forms it,
+// exp(x) / (exp(x) + 1): both overflow (inf, NaN) exactly where the reference does.
+CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
+    const double e = exp(x);
+    const double z = e + 1.0;
+    sp = log(z);
+    dsp = e / z;
+}
+
+// Closed-form Matern-3/2 discretisation, models.py:61-73.
+CGP_DEV void m32_solution(double ell, double sigma, double dt, double (&M)[4], double (&S)[3]) {
+    const double gamma = sqrt(3.0) / ell, eta = dt * gamma;
+    const double beta = sigma * sigma * exp(-2.0 * eta), e = exp(-eta);
+    M[0] = (1.0 + eta) * e; M[1] = dt * e; M[2] = -dt * gamma * gamma * e; M[3] = (1.0 - eta) * e;
+    S[0] = sigma * sigma - beta * (2.0 * eta + 2.0 * eta * eta + 1.0);
+    S[1] = 2.0 * dt * dt * gamma * gamma * gamma * beta;
+    S[2] = gamma * gamma * (sigma * sigma + beta * (2.0 * eta - 2.0 * eta * eta - 1.0));
+}
+
+// ------------------------------------------------------------------------------------------------ linear discrete
+template <int D_> struct LinearDisc {
+    static constexpr int D = D_;
+    Mat<D> F;
+    Sym<D> Sigma;
+    CGP_DEV void setup(const double* __restrict__ p, double /*dt*/, int /*model_id*/) {
+        load_mat<D>(p, F);
+        load_sym<D>(p + D * D, Sigma);
+    }
+    CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const { matvec<D>(F, u, f); }
+    CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
+        matvec<D>(F, u, f);
+        mul_dense_sym<D>(F, P, T);
+        mul_nt_sym_add<D>(T, F, Sigma, Pp);
+    }
+    CGP_DEV void add_sigma(Sym<D>& S, double w) const {
+        CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) S.a[i] = fma(w, Sigma.a[i], S.a[i]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ harmonic chirp, LCD
+// disc_harmonic_chirp_lcd (models.py:332-386); NH = 1, freq_scale = 1 is disc_chirp_lcd (models.py:264-311);
+// model_id CGP_M_LASCALA_LCD (params = ell, sigma) is disc_model_lascala_lcd (models.py:419-434): rho = 1, q = 0.
+template <int NH> struct HarmonicLCD {
+    static constexpr int D = 2 * NH + 2;
+    static constexpr int IV = D - 2;
+    double rho, q, fs, dt;
+    double M[4], MS[3];
+    CGP_DEV void setup(const double* __restrict__ p, double dt_, int model_id) {
+        dt = dt_;
+        if (model_id == 2 /* CGP_M_LASCALA_LCD */) {
+            rho = 1.0; q = 0.0; fs = 1.0;
+            m32_solution(p[0], p[1], dt, M, MS);
+        } else {
+            const double lam = p[0], b = p[1];
+            fs = p[4];
+            rho = exp(-lam * dt);
+            q = (lam == 0.0) ? b * b * dt : b * b / (2.0 * lam) * (1.0 - exp(-2.0 * lam * dt));   // models.py:302-308
+            m32_solution(p[2], p[3], dt, M, MS);
+        }
+    }
+    // cos/sin of dt*k*w scaled by rho, for every harmonic
+    CGP_DEV void rotations(double w, double (&c)[NH], double (&s)[NH]) const {
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            double sn, cs;
+            sincos((dt * (double)(k + 1)) * w, &sn, &cs);
+            c[k] = cs * rho; s[k] = sn * rho;
+        }
+    }
+    CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const {
+        const double w = (kTwoPi * log(exp(u.v[IV]) + 1.0)) * fs;
+        double c[NH], s[NH];
+        rotations(w, c, s);
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            f.v[2 * k] = c[k] * u.v[2 * k] - s[k] * u.v[2 * k + 1];
+            f.v[2 * k + 1] = s[k] * u.v[2 * k] + c[k] * u.v[2 * k + 1];
+        }
+        f.v[IV] = M[0] * u.v[IV] + M[1] * u.v[IV + 1];
+        f.v[IV + 1] = M[2] * u.v[IV] + M[3] * u.v[IV + 1];
+    }
+    CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
+        double sp, dsp;
+        softplus_pair(u.v[IV], sp, dsp);
+        const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
+        double c[NH], s[NH], jv[2 * NH];
+        rotations(w, c, s);
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            const double u0 = u.v[2 * k], u1 = u.v[2 * k + 1];
+            f.v[2 * k] = c[k] * u0 - s[k] * u1;
+            f.v[2 * k + 1] = s[k] * u0 + c[k] * u1;
+            const double dth = (dt * (double)(k + 1)) * dw;
+            jv[2 * k] = dth * (-s[k] * u0 - c[k] * u1);       // d f_{2k} / d u_v     (N1)
+            jv[2 * k + 1] = dth * (c[k] * u0 - s[k] * u1);    // d f_{2k+1} / d u_v
+        }
+        f.v[IV] = M[0] * u.v[IV] + M[1] * u.v[IV + 1];
+        f.v[IV + 1] = M[2] * u.v[IV] + M[3] * u.v[IV + 1];
+        // T = J P
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            CGP_UNROLL for (int k = 0; k < NH; k++) {
+                const double p0 = P(2 * k, j), p1 = P(2 * k + 1, j), pv = P(IV, j);
+                T.a[2 * k][j] = fma(jv[2 * k], pv, fma(c[k], p0, -s[k] * p1));
+                T.a[2 * k + 1][j] = fma(jv[2 * k + 1], pv, fma(s[k], p0, c[k] * p1));
+            }
+            T.a[IV][j] = fma(M[0], P(IV, j), M[1] * P(IV + 1, j));
+            T.a[IV + 1][j] = fma(M[2], P(IV, j), M[3] * P(IV + 1, j));
+        }
+        // Pp = T J^T + Sigma, lower triangle: (T J^T)(i, j) = sum_l T(i, l) J(j, l)
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j <= i; j++) {
+                double v;
+                if (j < IV) {
+                    const int k = j / 2;
+                    if (j % 2 == 0) v = fma(jv[j], T.a[i][IV], fma(c[k], T.a[i][2 * k], -s[k] * T.a[i][2 * k + 1]));
+                    else            v = fma(jv[j], T.a[i][IV], fma(s[k], T.a[i][2 * k], c[k] * T.a[i][2 * k + 1]));
+                    if (i == j) v += q;
+                } else if (j == IV) {
+                    v = fma(M[0], T.a[i][IV], M[1] * T.a[i][IV + 1]) + (i == IV ? MS[0] : MS[1]);
+                } else {
+                    v = fma(M[2], T.a[i][IV], M[3] * T.a[i][IV + 1]) + MS[2];
+                }
+                Pp(i, j) = v;
+            }
+    }
+    CGP_DEV void add_sigma(Sym<D>& S, double w) const {
+        CGP_UNROLL for (int i = 0; i < IV; i++) S(i, i) = fma(w, q, S(i, i));
+        S(IV, IV) = fma(w, MS[0], S(IV, IV));
+        S(IV + 1, IV) = fma(w, MS[1], S(IV + 1, IV));
+        S(IV + 1, IV + 1) = fma(w, MS[2], S(IV + 1, IV + 1));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ linear SDE
+template <int D_> struct LinearSDE {
+    static constexpr int D = D_;
+    Mat<D> A;
+    CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { load_mat<D>(p, A); }
+    CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const { matvec<D>(A, u, a); }
+    CGP_DEV void drift_jp(const Vec<D>& u, const Sym<D>& P, Vec<D>& a, Mat<D>& T) const {
+        matvec<D>(A, u, a);
+        mul_dense_sym<D>(A, P, T);
+    }
+    CGP_DEV void drift_jac(const Vec<D>& u, Vec<D>& a, Mat<D>& J) const { matvec<D>(A, u, a); J = A; }
+};
+
+// ------------------------------------------------------------------------------------------------ harmonic chirp SDE
+// model_harmonic_chirp drift (models.py:164-168); NH = 1 is model_chirp (models.py:104-110); lam = 0 is model_lascala.
+template <int NH> struct HarmonicSDE {
+    static constexpr int D = 2 * NH + 2;
+    static constexpr int IV = D - 2;
+    double lam, gam, fs;
+    CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { lam = p[0]; gam = sqrt(3.0) / p[1]; fs = p[2]; }
+    CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
+        const double w = (kTwoPi * log(exp(u.v[IV]) + 1.0)) * fs;
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            const double wk = w * (double)(k + 1);
+            a.v[2 * k] = -lam * u.v[2 * k] - wk * u.v[2 * k + 1];
+            a.v[2 * k + 1] = wk * u.v[2 * k] - lam * u.v[2 * k + 1];
+        }
+        a.v[IV] = u.v[IV + 1];
+        a.v[IV + 1] = -(gam * gam) * u.v[IV] - 2.0 * gam * u.v[IV + 1];
+    }
+    // a(u) and the non-trivial Jacobian pieces: wk[k] and the d/du_v column jv (N2)
+    CGP_DEV void pieces(const Vec<D>& u, Vec<D>& a, double (&wk)[NH], double (&jv)[2 * NH]) const {
+        double sp, dsp;
+        softplus_pair(u.v[IV], sp, dsp);
+        const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            wk[k] = w * (double)(k + 1);
+            const double dwk = dw * (double)(k + 1);
+            a.v[2 * k] = -lam * u.v[2 * k] - wk[k] * u.v[2 * k + 1];
+            a.v[2 * k + 1] = wk[k] * u.v[2 * k] - lam * u.v[2 * k + 1];
+            jv[2 * k] = -dwk * u.v[2 * k + 1];
+            jv[2 * k + 1] = dwk * u.v[2 * k];
+        }
+        a.v[IV] = u.v[IV + 1];
+        a.v[IV + 1] = -(gam * gam) * u.v[IV] - 2.0 * gam * u.v[IV + 1];
+    }
+    CGP_DEV void drift_jp(const Vec<D>& u, const Sym<D>& P, Vec<D>& a, Mat<D>& T) const {
+        double wk[NH], jv[2 * NH];
+        pieces(u, a, wk, jv);
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            CGP_UNROLL for (int k = 0; k < NH; k++) {
+                const double p0 = P(2 * k, j), p1 = P(2 * k + 1, j), pv = P(IV, j);
+                T.a[2 * k][j] = fma(jv[2 * k], pv, fma(-lam, p0, -wk[k] * p1));
+                T.a[2 * k + 1][j] = fma(jv[2 * k + 1], pv, fma(wk[k], p0, -lam * p1));
+            }
+            T.a[IV][j] = P(IV + 1, j);
+            T.a[IV + 1][j] = fma(-(gam * gam), P(IV, j), -2.0 * gam * P(IV + 1, j));
+        }
+    }
+    CGP_DEV void drift_jac(const Vec<D>& u, Vec<D>& a, Mat<D>& J) const {
+        double wk[NH], jv[2 * NH];
+        pieces(u, a, wk, jv);
+        CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) J.a[i][j] = 0.0;
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            J.a[2 * k][2 * k] = -lam; J.a[2 * k][2 * k + 1] = -wk[k];
+            J.a[2 * k + 1][2 * k] = wk[k]; J.a[2 * k + 1][2 * k + 1] = -lam;
+            J.a[2 * k][IV] = jv[2 * k]; J.a[2 * k + 1][IV] = jv[2 * k + 1];
+        }
+        J.a[IV][IV + 1] = 1.0;
+        J.a[IV + 1][IV] = -(gam * gam);
+        J.a[IV + 1][IV + 1] = -2.0 * gam;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ KPT measurement
+// h(x) = sum_k x[k] sin(k g(x[0] + x[d-1])) and its gradient (models.py:575-578).
+template <int NH> struct KptMeasurement {
+    static constexpr int D = NH + 2;
+    CGP_DEV static double eval(const Vec<D>& x, Vec<D>& H) {
+        double gs, dgs;
+        softplus_pair(x.v[0] + x.v[D - 1], gs, dgs);
+        double h = 0.0, dsum = 0.0;
+        CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0;
+        CGP_UNROLL for (int k = 1; k <= NH; k++) {
+            double sn, cs;
+            sincos(gs * (double)k, &sn, &cs);
+            h = fma(x.v[k], sn, h);
+            H.v[k] = sn;
+            dsum = fma(x.v[k] * cs, (double)k * dgs, dsum);
+        }
+        H.v[0] += dsum;
+        H.v[D - 1] += dsum;
+        return h;
+    }
+};
+
+}  // namespace cgp

@@ -1,0 +1,314 @@
+// cgp_steps.hpp -- one time step of every filter / smoother of chirpgp/filters_smoothers.py, as device code.
+//
+// Two execution shapes share this code (template parameter WAVE):
+//   WAVE = true   one 64-lane wavefront per trial.  Sigma-point fans are spread over the lanes (lane p evaluates
+//                 points p, p + 64, ...), the weighted sums are reduced through LDS, everything else is computed
+//                 redundantly (identically) by all lanes so no broadcast is ever needed.
+//   WAVE = false  one lane per trial (large batches): the fan is a serial loop, no LDS.
+#pragma once
+#include "cgp_math.hpp"
+#include "cgp_models.hpp"
+
+namespace cgp {
+
+// ---------------------------------------------------------------------------------------------- sigma-point fan
+constexpr int kRedChunk = 32;          // values reduced per LDS pass
+constexpr int kRedLd = 66;             // row pitch in doubles: 64 lanes + 16 B pad (conflict-free ds_read_b128 across rows)
+constexpr int kFanLdsDoubles = kRedChunk * kRedLd + kRedChunk;
+
+struct SigmaSet {
+    const double* __restrict__ xi;     // [s][d]
+    const double* __restrict__ w;      // [s]
+    int s;
+};
+
+// All-lane sum of R per-lane partials through LDS: every lane ends with bitwise-identical totals
+// (rows are summed in lane order by one lane each, then re-read by all).
+template <int R>
+CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int nl) {
+    double* tot = lds + kRedChunk * kRedLd;
+    CGP_UNROLL for (int base = 0; base < R; base += kRedChunk) {
+        constexpr int dummy = 0; (void)dummy;
+        const int n = (R - base < kRedChunk) ? (R - base) : kRedChunk;
+        CGP_UNROLL for (int r = 0; r < kRedChunk; r++)
+            if (base + r < R) lds[r * kRedLd + lane] = acc[base + r];
+        __syncthreads();
+        if (lane < n) {
+            const double* row = lds + lane * kRedLd;
+            double s = row[0];
+            for (int j = 1; j < nl; j++) s += row[j];
+            tot[lane] = s;
+        }
+        __syncthreads();
+        CGP_UNROLL for (int r = 0; r < kRedChunk; r++)
+            if (base + r < R) acc[base + r] = tot[r];
+        __syncthreads();
+    }
+}
+
+// chi = m + L xi_p   (quadratures.py:198-201), L lower-triangular packed.
+template <int D> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, const double* __restrict__ xi, Vec<D>& chi) {
+    double x[D];
+    CGP_UNROLL for (int j = 0; j < D; j++) x[j] = xi[j];
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double t = L(i, 0) * x[0];
+        CGP_UNROLL for (int j = 1; j <= i; j++) t = fma(L(i, j), x[j], t);
+        chi.v[i] = m.v[i] + t;
+    }
+}
+
+// Sigma-point prediction of a discrete model, filters_smoothers.py:88-121, plus (CROSS) the smoother's
+// D^T = (sum_i w_i chi_i f_i^T - mf mp^T)^T, filters_smoothers.py:525.
+template <class DM, bool WAVE, bool CROSS>
+CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, double* lds,
+                            const Vec<DM::D>& mf, const Sym<DM::D>& Pf, Vec<DM::D>& mp, Sym<DM::D>& Pp, Mat<DM::D>& DT) {
+    constexpr int D = DM::D;
+    constexpr int NS = Sym<D>::N;
+    constexpr int R = 1 + D + NS + (CROSS ? D * D : 0);
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pf, L, inv);
+    double acc[R];
+    CGP_UNROLL for (int r = 0; r < R; r++) acc[r] = 0.0;
+    const int step = WAVE ? 64 : 1;
+    for (int p = WAVE ? lane : 0; p < sg.s; p += step) {
+        Vec<D> chi, f;
+        sigma_point<D>(mf, L, sg.xi + (size_t)p * D, chi);
+        model.mean(chi, f);
+        const double w = sg.w[p];
+        acc[0] += w;
+        CGP_UNROLL for (int i = 0; i < D; i++) acc[1 + i] = fma(w, f.v[i], acc[1 + i]);
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j <= i; j++)
+                acc[1 + D + Sym<D>::idx(i, j)] = fma(w, f.v[i] * f.v[j], acc[1 + D + Sym<D>::idx(i, j)]);
+        if (CROSS) {
+            CGP_UNROLL for (int i = 0; i < D; i++)
+                CGP_UNROLL for (int j = 0; j < D; j++)
+                    acc[1 + D + NS + i * D + j] = fma(w, chi.v[i] * f.v[j], acc[1 + D + NS + i * D + j]);
+        }
+    }
+    if (WAVE) wave_allreduce<R>(acc, lds, lane, sg.s < 64 ? sg.s : 64);
+    CGP_UNROLL for (int i = 0; i < D; i++) mp.v[i] = acc[1 + i];
+    // Pp = E[f f^T + Sigma] - mp mp^T ; E[Sigma] = (sum_i w_i) Sigma since Sigma does not depend on the point (N3)
+    CGP_UNROLL for (int i = 0; i < NS; i++) Pp.a[i] = acc[1 + D + i];
+    model.add_sigma(Pp, acc[0]);
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) Pp(i, j) -= mp.v[i] * mp.v[j];
+    if (CROSS) {
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j < D; j++) DT.a[j][i] = acc[1 + D + NS + i * D + j] - mf.v[i] * mp.v[j];
+    }
+}
+
+// Sigma-point moment ODE of an SDE model, filters_smoothers.py:124-137: dm = E[a], dP = C + C^T + gamma,
+// C = E[(chi - m) a^T].
+template <class SM, bool WAVE>
+CGP_DEV void cd_sgp_common(const SM& model, const SigmaSet& sg, int lane, double* lds, const Sym<SM::D>& gamma,
+                           const Vec<SM::D>& m, const Sym<SM::D>& P, Vec<SM::D>& dm, Sym<SM::D>& dP) {
+    constexpr int D = SM::D;
+    constexpr int R = D + D * D;
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(P, L, inv);
+    double acc[R];
+    CGP_UNROLL for (int r = 0; r < R; r++) acc[r] = 0.0;
+    const int step = WAVE ? 64 : 1;
+    for (int p = WAVE ? lane : 0; p < sg.s; p += step) {
+        Vec<D> chi, a;
+        sigma_point<D>(m, L, sg.xi + (size_t)p * D, chi);
+        model.drift(chi, a);
+        const double w = sg.w[p];
+        CGP_UNROLL for (int i = 0; i < D; i++) acc[i] = fma(w, a.v[i], acc[i]);
+        CGP_UNROLL for (int i = 0; i < D; i++) {
+            const double ci = chi.v[i] - m.v[i];
+            CGP_UNROLL for (int j = 0; j < D; j++) acc[D + i * D + j] = fma(w, ci * a.v[j], acc[D + i * D + j]);
+        }
+    }
+    if (WAVE) wave_allreduce<R>(acc, lds, lane, sg.s < 64 ? sg.s : 64);
+    CGP_UNROLL for (int i = 0; i < D; i++) dm.v[i] = acc[i];
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) dP(i, j) = (acc[D + i * D + j] + acc[D + j * D + i]) + gamma(i, j);
+}
+
+// ---------------------------------------------------------------------------------------------- RK4 on the (m, P) pair
+// quadratures.py:34-54 / 57-81: k1..k4, x + dt (k1 + 2 k2 + 2 k3 + k4) / 6; the stage loop is kept rolled (code size).
+template <int D, class Rhs>
+CGP_DEV void rk4_m_cov(Rhs&& rhs, Vec<D>& m, Sym<D>& P, double dt) {
+    Vec<D> km, tm = m, am;
+    Sym<D> kP, tP = P, aP;
+    CGP_UNROLL for (int i = 0; i < D; i++) am.v[i] = 0.0;
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) aP.a[i] = 0.0;
+#pragma unroll 1
+    for (int stage = 0; stage < 4; stage++) {
+        rhs(tm, tP, km, kP);
+        const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+        const double half = (stage == 2) ? 1.0 : 0.5;      // (dt * k) / 2 == (dt * k) * 0.5 exactly
+        CGP_UNROLL for (int i = 0; i < D; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = m.v[i] + (dt * km.v[i]) * half; }
+        CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) { aP.a[i] = fma(wgt, kP.a[i], aP.a[i]); tP.a[i] = P.a[i] + (dt * kP.a[i]) * half; }
+    }
+    CGP_UNROLL for (int i = 0; i < D; i++) m.v[i] = m.v[i] + (dt * am.v[i]) / 6.0;
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) P.a[i] = P.a[i] + (dt * aP.a[i]) / 6.0;
+}
+
+// ---------------------------------------------------------------------------------------------- per-trial arguments
+struct ModelArgs {
+    const double* __restrict__ params; int64_t param_stride;
+    const double* __restrict__ gamma;  int64_t gamma_stride;
+    int model_id;
+    SigmaSet sg;
+    double dt;
+};
+
+// ============================================================================================== FILTER PREDICTORS
+// predict(lane, lds, mf, Pf) -> (mp, Pp)
+
+// ekf (filters_smoothers.py:251-261) and, with a linear model, kf (:174-181)
+template <class DM, bool WAVE_> struct EkfPredict {
+    static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
+    DM model;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> T;
+        model.propagate(mf, Pf, mp, T, Pp);
+    }
+};
+
+// sgp_filter (filters_smoothers.py:480-487)
+template <class DM, bool WAVE_> struct SgpPredict {
+    static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> unused;
+        sgp_prediction<DM, WAVE, false>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
+    }
+};
+
+// cd_ekf (filters_smoothers.py:384-394): dm = a(m), dP = P J^T + J P + gamma
+template <class SM, bool WAVE_> struct CdEkfPredict {
+    static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
+    SM model; Sym<D> gamma; double dt;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
+        model.setup(a.params + trial * a.param_stride, a.model_id);
+        load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
+        dt = a.dt;
+    }
+    CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        mp = mf; Pp = Pf;
+        rk4_m_cov<D>([&](const Vec<D>& m, const Sym<D>& P, Vec<D>& dm, Sym<D>& dP) {
+            Mat<D> T;
+            model.drift_jp(m, P, dm, T);
+            sym_from_sum<D>(T, gamma, 1.0, dP);
+        }, mp, Pp, dt);
+    }
+};
+
+// cd_sgp_filter (filters_smoothers.py:569-579)
+template <class SM, bool WAVE_> struct CdSgpPredict {
+    static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
+    SM model; Sym<D> gamma; SigmaSet sg; double dt;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
+        model.setup(a.params + trial * a.param_stride, a.model_id);
+        load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
+        sg = a.sg; dt = a.dt;
+    }
+    CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        mp = mf; Pp = Pf;
+        rk4_m_cov<D>([&](const Vec<D>& m, const Sym<D>& P, Vec<D>& dm, Sym<D>& dP) {
+            cd_sgp_common<SM, WAVE>(model, sg, lane, lds, gamma, m, P, dm, dP);
+        }, mp, Pp, dt);
+    }
+};
+
+// ============================================================================================== SMOOTHER STEPS
+// step(lane, lds, mf, Pf, ms, Ps): (ms, Ps) at k+1 -> (ms, Ps) at k, given the filtering result (mf, Pf) at k.
+
+// eks (filters_smoothers.py:338-346) and, with a linear model, rts (:208-216)
+template <class DM, bool WAVE_> struct EksStep {
+    static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
+    DM model;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void step(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
+        Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
+        model.propagate(mf, Pf, mp, DT, Pp);          // DT = J Pf
+        smoother_gain<D>(DT, Pp, G);
+        smoother_apply<D>(G, mf, Pf, mp, Pp, ms, Ps);
+    }
+};
+
+// sgp_smoother (filters_smoothers.py:520-528)
+template <class DM, bool WAVE_> struct SgpsStep {
+    static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void step(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
+        Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
+        sgp_prediction<DM, WAVE, true>(model, sg, lane, lds, mf, Pf, mp, Pp, DT);
+        smoother_gain<D>(DT, Pp, G);
+        smoother_apply<D>(G, mf, Pf, mp, Pp, ms, Ps);
+    }
+};
+
+// Pf^{-1} gamma, constant over the four RK4 stages of a backward step (the reference recomputes it per stage:
+// filters_smoothers.py:429, 617-618 -- same values, hoisted).
+template <int D> CGP_DEV void pinv_gamma(const Sym<D>& Pf, const Sym<D>& gamma, Mat<D>& PG) {
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pf, L, inv);
+    Mat<D> R;
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) R.a[i][j] = gamma(i, j);
+    cho_solve_mat<D>(L, inv, R, PG);
+}
+
+// cd_eks (filters_smoothers.py:423-438), dt negated
+template <class SM, bool WAVE_> struct CdEksStep {
+    static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
+    SM model; Sym<D> gamma; double dt;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
+        model.setup(a.params + trial * a.param_stride, a.model_id);
+        load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
+        dt = -a.dt;
+    }
+    CGP_DEV void step(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
+        Mat<D> PG;
+        pinv_gamma<D>(Pf, gamma, PG);
+        rk4_m_cov<D>([&](const Vec<D>& m, const Sym<D>& P, Vec<D>& dm, Sym<D>& dP) {
+            Mat<D> A, T;
+            model.drift_jac(m, dm, A);
+            // A = J_a + gamma Pf^{-1} = J_a + (Pf^{-1} gamma)^T ; dm = a + gamma Pf^{-1} (m - mf)
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                double s = dm.v[i];
+                CGP_UNROLL for (int k = 0; k < D; k++) { A.a[i][k] += PG.a[k][i]; s = fma(PG.a[k][i], m.v[k] - mf.v[k], s); }
+                dm.v[i] = s;
+            }
+            mul_dense_sym<D>(A, P, T);
+            sym_from_sum<D>(T, gamma, -1.0, dP);          // A P + P A^T - gamma
+        }, ms, Ps, dt);
+    }
+};
+
+// cd_sgp_smoother (filters_smoothers.py:611-629)
+template <class SM, bool WAVE_> struct CdSgpsStep {
+    static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
+    SM model; Sym<D> gamma; SigmaSet sg; double dt;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
+        model.setup(a.params + trial * a.param_stride, a.model_id);
+        load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
+        sg = a.sg; dt = -a.dt;
+    }
+    CGP_DEV void step(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
+        Mat<D> PG;
+        pinv_gamma<D>(Pf, gamma, PG);
+        rk4_m_cov<D>([&](const Vec<D>& m, const Sym<D>& P, Vec<D>& dm, Sym<D>& dP) {
+            cd_sgp_common<SM, WAVE>(model, sg, lane, lds, gamma, m, P, dm, dP);       // (_m, _P), _P includes + gamma
+            Mat<D> GT, T;
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                double s = dm.v[i];
+                CGP_UNROLL for (int k = 0; k < D; k++) { GT.a[i][k] = PG.a[k][i]; s = fma(PG.a[k][i], m.v[k] - mf.v[k], s); }
+                dm.v[i] = s;                                                           // _m + G^T (m - mf)
+            }
+            mul_dense_sym<D>(GT, P, T);                                                // G^T P
+            CGP_UNROLL for (int i = 0; i < D; i++)
+                CGP_UNROLL for (int j = 0; j <= i; j++) dP(i, j) = (dP(i, j) + (T.a[i][j] + T.a[j][i])) - 2.0 * gamma(i, j);
+        }, ms, Ps, dt);
+    }
+};
+
+}  // namespace cgp

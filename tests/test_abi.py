@@ -1,0 +1,64 @@
+"""The C-ABI library loads and exports exactly what include/chirpgp_hip.h declares (no compute: no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'chirpgp_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(cgp_[a-z_]+)\s*\(', src)))
+
+
+def _lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from chirpgp_amd import _engine
+    return _engine.load_library(), _engine
+
+
+def test_header_symbols_are_exported():
+    lib, eng = _lib()
+    names = _declared()
+    assert set(names) == set(eng.EXPORTS), (names, eng.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in chirpgp_hip.h but not exported'
+    assert lib.cgp_version() == 100
+
+
+def test_struct_layouts_match_header():
+    _, eng = _lib()
+    assert ctypes.sizeof(eng.CgpModel) == 48
+    assert ctypes.sizeof(eng.CgpSigma) == 24
+    assert ctypes.sizeof(eng.CgpInit) == 64
+
+
+def test_null_context_is_rejected_without_gpu():
+    lib, _ = _lib()
+    assert lib.cgp_filter(None, 0, None, None, None, 0.0, None, 1, 1, None, None, None, 0, None) == -1
+    assert lib.cgp_smoother(None, 0, None, None, 0.0, None, None, 1, 1, None, None, 0, None) == -1
+
+
+def test_python_callables_are_refused():
+    """No CPU fallback: a plain closure is a TypeError, never a silent host evaluation."""
+    import numpy as np
+    from chirpgp_amd import filters_smoothers as fs
+    with pytest.raises(TypeError):
+        fs.ekf(lambda u, dt: (u, np.eye(2)), np.ones(2), 0.1, np.zeros(2), np.eye(2), 0.1, np.zeros(5))
+    with pytest.raises(TypeError):
+        fs.cd_ekf(lambda u: u, lambda u: np.eye(2), np.ones(2), 0.1, np.zeros(2), np.eye(2), 0.1, np.zeros(5))
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, 'chirpgp_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in txt, f'{f} mentions oracle'

@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path, called through the public functions (-> ctypes -> C-ABI), against the oracle.
+
+Tolerance: the north star states 1e-5 relative on filtered / smoothed means and covariances (BASELINE.json); the gate
+below is RTOL = 1e-5 everywhere (element-wise, with a 1e-3 * array-scale floor for structurally-zero covariance
+entries; NaN positions must be identical), and a tighter 1e-9 where the arithmetic is benign (linear models).
+Both launch shapes are exercised: one wavefront per trial and one lane per trial.
+"""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from tests import backends as bk
+from tests import cases as cs
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+WAVE = dict(flags=0x2)
+THREAD = dict(flags=0x4)
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(THREAD, id='lane_per_trial')]
+
+
+def _fs():
+    from chirpgp_amd import filters_smoothers as fs
+    return fs
+
+
+# ------------------------------------------------------------------ the reference's own test, on the HIP path
+@pytest.mark.parametrize('idx', [0, 1])
+def test_equivalence_on_linear_models(idx):
+    """test/test_filters_smoothers.py:19-85 with the engine's functions (same data, same tolerances)."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    fs = _fs()
+    c = cs.linear_case(idx)
+    F, Sigma, H, Xi, m0, P0, dt, ys = c.F, c.Sigma, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys
+    drift, dispersion = c.drift, c.disp
+    m_and_cov = pm.linear_cond_m_cov(F, Sigma)
+    B = dispersion(None)
+
+    kf_results = fs.kf(F, Sigma, H, Xi, m0, P0, ys)
+    ekf_results = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
+    cd_ekf_results = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
+    sgps = SigmaPoints.gauss_hermite(d=3, order=4)
+    ghkf_results = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
+    cd_ghkf_results = fs.cd_sgp_filter(drift, B, sgps, H, Xi, m0, P0, dt, ys)
+    for i in range(3):
+        npt.assert_allclose(kf_results[i], ekf_results[i])
+        npt.assert_allclose(kf_results[i], ghkf_results[i])
+        npt.assert_allclose(kf_results[i], cd_ekf_results[i], rtol=1e-5)
+        npt.assert_allclose(kf_results[i], cd_ghkf_results[i], rtol=1e-5)
+
+    rts_results = fs.rts(F, Sigma, kf_results[0], kf_results[1])
+    eks_results = fs.eks(m_and_cov, ekf_results[0], ekf_results[1], dt)
+    cd_eks_results = fs.cd_eks(drift, dispersion, cd_ekf_results[0], cd_ekf_results[1], dt)
+    ghks_results = fs.sgp_smoother(m_and_cov, sgps, ghkf_results[0], ghkf_results[1], dt)
+    cd_ghks_results = fs.cd_sgp_smoother(drift, B, sgps, cd_ghkf_results[0], cd_ghkf_results[1], dt)
+    for i in range(2):
+        npt.assert_allclose(rts_results[i], eks_results[i])
+        npt.assert_allclose(rts_results[i], ghks_results[i])
+        npt.assert_allclose(rts_results[i], cd_eks_results[i], atol=1e-1)
+        npt.assert_allclose(cd_eks_results[i], cd_ghks_results[i], rtol=1e-6)
+    npt.assert_array_equal(rts_results[0][-1], kf_results[0][-1])
+    npt.assert_array_equal(rts_results[1][-1], kf_results[1][-1])
+
+
+# ------------------------------------------------------------------ golden vectors (NumPy-oracle outputs)
+GOLDEN = {
+    'linear_ou': (lambda: cs.linear_case(0, T=200), 200),
+    'chirp_gh3': (lambda: cs.chirp_case(T=200, seed=21), 100),
+    'harmonic3_cubature': (lambda: cs.harmonic_case(T=120, seed=22, nh=3), 60),
+    'lascala_gh3': (lambda: cs.lascala_case(T=120, seed=23), 60),
+}
+
+
+@pytest.mark.parametrize('kw', SHAPES)
+@pytest.mark.parametrize('name', sorted(GOLDEN))
+def test_golden_vectors(name, kw):
+    make, cd_T = GOLDEN[name]
+    c = make()
+    _, want = bk.load_golden(name)
+    got = bk.run_pairs('hip', c, cd_T, hip_kw=kw)
+    worst = bk.compare(got, want, RTOL, f'{name}')
+    print(name, {k: f'{v:.1e}' for k, v in worst.items()})
+
+
+def test_golden_kf_rts_and_kpt():
+    fs = _fs()
+    z, want = bk.load_golden('linear_ou')
+    kf = fs.kf(z['F'], z['Sigma'], z['H'], float(z['Xi']), z['m0'], z['P0'], z['ys'])
+    bk.compare({'kf': kf, 'rts': fs.rts(z['F'], z['Sigma'], kf[0], kf[1])}, want, 1e-9, 'linear_ou')
+    c = cs.kpt_case(T=200, seed=24)
+    _, want = bk.load_golden('kpt2')
+    for kw in (WAVE, THREAD):
+        got = {'ekf_for_kpt': fs.ekf_for_kpt(c.F, c.Sigma, c.h, c.Xi, c.m0, c.P0, c.dt, c.ys, **kw)}
+        bk.compare(got, want, RTOL, 'kpt2')
+
+
+# ------------------------------------------------------------------ longer runs against the C port
+def _batch_case(make, B, **kw):
+    cs_ = [make(seed=100 + i, **kw) for i in range(B)]
+    c = cs_[0]
+    c.ys = np.stack([x.ys for x in cs_])
+    return c
+
+
+@pytest.mark.parametrize('kw', SHAPES)
+def test_chirp_gh3_long_batched(kw):
+    """Config C2 / C3 shape at a size the C port finishes in seconds: d = 4, T = 3000, B = 6."""
+    c = _batch_case(cs.chirp_case, 6, T=3000)
+    want = bk.run_pairs('port', c, cd_T=600)
+    got = bk.run_pairs('hip', c, cd_T=600, hip_kw=kw)
+    worst = bk.compare(got, want, RTOL, 'chirp_long')
+    print({k: f'{v:.1e}' for k, v in worst.items()})
+    # smoothers on identical inputs (the oracle's filtering results)
+    sm = bk.smoothers_on('hip', c, want, hip_kw=kw)
+    bk.compare(sm, want, RTOL, 'chirp_long/smoothers_on_oracle_inputs')
+
+
+@pytest.mark.parametrize('kw', SHAPES)
+def test_harmonics_long_batched(kw):
+    """Config C5 shape: 3 harmonics (d = 8) with cubature, and 2 harmonics (d = 6) with freq_scale != 1."""
+    c = _batch_case(cs.harmonic_case, 3, T=1500, nh=3)
+    bk.compare(bk.run_pairs('hip', c, cd_T=300, hip_kw=kw), bk.run_pairs('port', c, cd_T=300), RTOL, 'harmonic3')
+    c = _batch_case(cs.harmonic_case, 3, T=800, nh=2, freq_scale=1.7)
+    bk.compare(bk.run_pairs('hip', c, cd_T=200, hip_kw=kw), bk.run_pairs('port', c, cd_T=200), RTOL, 'harmonic2')
+
+
+def test_chirp_lam0_and_cubature():
+    c = cs.chirp_case(T=800, sg='cub', params=(0., 0.3, 0.2, 0.5, 2., 6.))
+    bk.compare(bk.run_pairs('hip', c, cd_T=300), bk.run_pairs('port', c, cd_T=300), RTOL, 'lam0')
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize('T', [1, 2, 63, 64, 65, 129])
+def test_ragged_lengths(T):
+    """T = 1 (the smoother returns the filter row), and the 64-step measurement-chunk boundaries."""
+    c = cs.chirp_case(T=T, seed=31)
+    for kw in (WAVE, THREAD):
+        bk.compare(bk.run_pairs('hip', c, hip_kw=kw, only=('ekf', 'sgp_filter')),
+                   bk.run_pairs('port', c, only=('ekf', 'sgp_filter')), RTOL, f'T={T}')
+
+
+@pytest.mark.parametrize('B', [1, 63, 65, 130])
+def test_ragged_batches(B):
+    """Partial last wavefront in the one-lane-per-trial shape."""
+    c = _batch_case(cs.chirp_case, B, T=40)
+    bk.compare(bk.run_pairs('hip', c, hip_kw=THREAD, only=('ekf', 'cd_ekf')),
+               bk.run_pairs('port', c, only=('ekf', 'cd_ekf')), RTOL, f'B={B}')
+
+
+def test_empty_inputs():
+    fs = _fs()
+    c = cs.chirp_case(T=8)
+    mfs, Pfs, nll = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, np.zeros((0,)))
+    assert mfs.shape == (0, 4) and Pfs.shape == (0, 4, 4) and nll.shape == (0,)
+    mfs, Pfs, nll = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, np.zeros((0, 5)))
+    assert mfs.shape == (0, 5, 4)
+
+
+def test_per_trial_parameters_and_nll_only():
+    """Parameter sweep (config C5 / MLE objective): per-trial model parameters, m0, P0; nll-only output."""
+    from chirpgp_amd import models as pm
+    from oracle import port
+    fs = _fs()
+    B, T = 9, 500
+    rng = np.random.default_rng(3)
+    params = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * rng.uniform(0.7, 1.3, size=(B, 6))
+    drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+    ys = np.stack([cs.chirp_measurements(T, 200 + i)[2] for i in range(B)])
+    want = port.filter(port.F_EKF, disc, None, H, 0.1, m0, P0, 1e-3, ys)
+    for kw in (WAVE, THREAD):
+        got = fs.ekf(disc, H, 0.1, m0, P0, 1e-3, ys, **kw)
+        for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+            cs.assert_close(g, w, RTOL, f'sweep.{n}')
+        last = fs.ekf(disc, H, 0.1, m0, P0, 1e-3, ys, nll_final_only=True, want=(False, False, True), **kw)
+        assert last[0] is None and last[1] is None
+        npt.assert_array_equal(last[2], got[2][:, -1])
+
+
+def test_nan_semantics():
+    """Indefinite P0: NaN exactly where the oracle has NaN (everywhere), no exception, run continues."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    sg = SigmaPoints.cubature(2)
+    spec = pm.linear_cond_m_cov(0.9 * np.eye(2), 0.01 * np.eye(2))
+    P0 = np.array([[1., 2.], [2., 1.]])
+    args = (np.array([1., 0.]), 0.1, np.zeros(2), P0, 0.1, np.ones(5))
+    want = port.filter(port.F_SGP, spec, sg, *args)
+    for kw in (WAVE, THREAD):
+        got = fs.sgp_filter(spec, sg, *args, **kw)
+        for g, w in zip(got, want):
+            assert np.array_equal(np.isnan(g), np.isnan(w)) and np.all(np.isnan(g))
+    # a batch where only one trial breaks down: the others are untouched
+    P0b = np.stack([np.eye(2), P0, 2 * np.eye(2)])
+    ysb = np.ones((3, 5))
+    got = fs.sgp_filter(spec, sg, args[0], 0.1, np.zeros(2), P0b, 0.1, ysb)
+    assert np.all(np.isnan(got[0][1])) and not np.any(np.isnan(got[0][0])) and not np.any(np.isnan(got[0][2]))
+
+
+def test_torch_tensors_stay_on_device():
+    import torch
+    fs = _fs()
+    c = cs.chirp_case(T=100)
+    ys = torch.from_numpy(c.ys).cuda()
+    mfs, Pfs, nll = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    assert mfs.is_cuda and Pfs.is_cuda and nll.is_cuda and mfs.dtype == torch.float64
+    mss, Pss = fs.eks(c.disc, mfs, Pfs, c.dt)
+    assert mss.is_cuda and tuple(Pss.shape) == (100, 4, 4)
+
+
+def test_gaussian_expectation_on_device():
+    from chirpgp_amd.quadratures import gaussian_expectation, SigmaPoints
+    from chirpgp_amd.models import g
+    from oracle import np_quadratures as oq
+    rng = np.random.default_rng(5)
+    ms, sd = rng.standard_normal(1000) * 3 + 5, rng.uniform(0.05, 1.5, 1000)
+    got = gaussian_expectation(ms, sd, func=g, force_shape=True)
+    want = oq.gaussian_expectation(ms[:50], sd[:50], force_shape=True)
+    npt.assert_allclose(got[:50], want, rtol=1e-12)
+    sg = SigmaPoints.gauss_hermite(1, 10)
+    npt.assert_allclose(got[:, 0], (np.log1p(np.exp(ms[:, None] + sd[:, None] * sg.xi[:, 0][None, :])) * sg.w).sum(1), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ full benchmark size: size-independent properties
+def test_full_size_properties_and_parity():
+    """BASELINE config C2 at full size (d = 4, T = 10 000, B = 1000) on device-resident data:
+    the whole EKF + EKS result against the C port (which finishes this in seconds on the host cores)."""
+    import torch
+    from chirpgp_amd import models as pm
+    from oracle import port
+    import bench
+    fs = _fs()
+    B, T = 1000, 10000
+    wl = bench.make_workload(B, T, seed=0)
+    ys = torch.from_numpy(wl['ys']).cuda()
+    mfs, Pfs, nll = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys)
+    mss, Pss = fs.eks(wl['disc'], mfs, Pfs, wl['dt'])
+    assert bool(torch.isfinite(mfs).all()) and bool(torch.isfinite(Pss).all())
+    # N5: last smoothing row == last filtering row, bit for bit
+    assert torch.equal(mss[:, -1], mfs[:, -1]) and torch.equal(Pss[:, -1], Pfs[:, -1])
+    # cumulative nll is non-decreasing only in expectation; but it must equal the running sum of its own increments
+    # symmetric covariances
+    assert torch.equal(Pfs, Pfs.transpose(-1, -2)) and torch.equal(Pss, Pss.transpose(-1, -2))
+    # smoothing never increases the marginal variance (up to rounding)
+    dvar = torch.diagonal(Pfs - Pss, dim1=-2, dim2=-1)
+    assert float(dvar.min()) > -1e-9 * float(torch.diagonal(Pfs, dim1=-2, dim2=-1).abs().max())
+    sel = np.arange(0, B, 8)
+    w_f = port.filter(port.F_EKF, wl['disc'], None, wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], wl['ys'][sel])
+    w_s = port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], w_f[0], w_f[1])
+    idx = torch.from_numpy(sel).cuda()
+    for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
+        cs.assert_close(g.cpu().numpy(), w, RTOL, f'full.{n}')
+        print(n, f'{cs.max_rel_err(g.cpu().numpy(), w):.2e}')
