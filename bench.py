@@ -129,10 +129,9 @@ def main():
     ys_dev = torch.from_numpy(wl['ys']).cuda()
     kw = dict(flags=args.flags) if args.flags else {}
 
+    from chirpgp_amd import _engine
+
     def step(record=None):
-        if record is not None:
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record()
         k = wl['kind']
         if k == 'ekf':
             f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
@@ -142,8 +141,6 @@ def main():
             f = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
         else:
             f = fs.cd_ekf(wl['drift'], wl['disp'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
-        if record is not None:
-            e1.record()
         if k == 'ekf':
             s = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
         elif k in ('sgp', 'harmonic'):
@@ -152,9 +149,6 @@ def main():
             s = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], f[0], f[1], wl['dt'], **kw)
         else:
             s = fs.cd_eks(wl['drift'], wl['disp'], f[0], f[1], wl['dt'], **kw)
-        if record is not None:
-            e2.record()
-            record.append((e0, e1, e2))
         return f, s
 
     def sync():
@@ -165,12 +159,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    events = []
+    # HIP events on the launch stream, recorded immediately around each C-ABI call (kernel duration, not host time)
+    events = _engine.kernel_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         f, s = step(events)
     sync()
     elapsed = time.perf_counter() - t0
+    _engine.kernel_events = None
     tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -188,8 +184,8 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     if rank == 0:
-        filt_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))
-        smooth_ms = float(np.mean([b.elapsed_time(c) for _, b, c in events]))
+        filt_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
+        smooth_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'smoother']))
         bf, bs = bytes_per_trial_step(d)
         units = B * T
         dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)

@@ -125,6 +125,22 @@ def dev(x, device=None):
 
 _const_cache = {}
 
+# Optional timing hook used by bench.py: when set to a list, every kernel launch appends
+# (name, start_event, end_event), the events recorded on the launch stream immediately around the C-ABI call.
+kernel_events = None
+
+
+def _timed(name, call):
+    if kernel_events is None:
+        return call()
+    torch = _torch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = call()
+    e1.record()
+    kernel_events.append((name, e0, e1))
+    return rc
+
 
 def dev_const(x):
     """Device copy of a small host constant (model parameters, H, m0, P0, sigma points), cached by value so that
@@ -238,8 +254,9 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
     nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
     fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
-    rc = load_library().cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                   C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, _stream())
+    lib, st = load_library(), _stream()
+    rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                 C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
     _check(ctx, rc, 'cgp_filter')
     return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
 
@@ -264,8 +281,9 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
     model = _model_struct(spec, gamma, B, keep)
     sig = _sigma_struct(sgps, d, keep)
     mss, Pss = torch.empty_like(m), torch.empty_like(P)
-    rc = load_library().cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None, float(dt),
-                                     _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), _stream())
+    lib, st = load_library(), _stream()
+    rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                     float(dt), _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), st))
     _check(ctx, rc, 'cgp_smoother')
     return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
 

@@ -4,6 +4,12 @@
 
 namespace cgp {
 
+// Largest state dimension for which the time-parallel smoother (30 / 108 doubles of affine map per lane at d = 4 / 8)
+// is instantiated.
+#ifndef CGP_TP_MAX_D
+#define CGP_TP_MAX_D 8
+#endif
+
 template <class DM>
 static int filter_disc(int method, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     using Meas = LinearMeasurement<DM::D>;
@@ -17,10 +23,14 @@ static int filter_disc(int method, bool wave, const FilterIO& io, const ModelArg
 }
 template <class DM>
 static int smoother_disc(int method, bool wave, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    // One wavefront per trial: time-parallel affine scan unless the caller asks for the step-by-step scan.
+    const bool tp = wave && !(io.flags & CGP_SEQUENTIAL_SCAN) && DM::D <= CGP_TP_MAX_D;
     switch (method) {
     case CGP_S_EKS:
+        if constexpr (DM::D <= CGP_TP_MAX_D) { if (tp) return hip_rc(launch_tp_smoother<EksElement<DM>>(io, ma, st)); }
         return hip_rc(wave ? launch_smoother<EksStep<DM, true>>(io, ma, st) : launch_smoother<EksStep<DM, false>>(io, ma, st));
     case CGP_S_SGP:
+        if constexpr (DM::D <= CGP_TP_MAX_D) { if (tp) return hip_rc(launch_tp_smoother<SgpsElement<DM>>(io, ma, st)); }
         return hip_rc(wave ? launch_smoother<SgpsStep<DM, true>>(io, ma, st) : launch_smoother<SgpsStep<DM, false>>(io, ma, st));
     default: return CGP_E_UNSUPPORTED;
     }

@@ -136,6 +136,69 @@ __global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs m
     }
 }
 
+// Time-parallel discrete smoother (rts / eks / sgp_smoother): one wavefront per trial, one lane per time step,
+// 64 steps per tile, tiles walked from the end of the record to its start.  See "TIME-PARALLEL SMOOTHER" in
+// cgp_steps.hpp.  Loads and stores are per-lane rows of consecutive time steps, i.e. contiguous 64 * 8(d + d^2) bytes
+// per tile.
+template <class Elem>
+__global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArgs ma) {
+    constexpr int D = Elem::D;
+    const int lane = threadIdx.x;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    Elem elem;
+    elem.setup(ma, trial);
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * D;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
+    double* __restrict__ mss = io.mss + trial * T * D;
+    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+
+    Vec<D> ms;
+    Sym<D> Ps;
+    load_vec<D>(mfs + (T - 1) * D, ms);
+    load_sym<D>(Pfs + (T - 1) * D * D, Ps);
+    if (lane == 0) {   // filters_smoothers.py:140-142: last smoothing row = last filtering row, copied verbatim
+        CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+        CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i];
+    }
+    for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+        const int64_t k = hi - 63 + lane;
+        const bool valid = k >= 0;
+        Affine<D> e;
+        affine_identity<D>(e);
+        if (valid) {
+            Vec<D> mf; Sym<D> Pf;
+            load_vec<D>(mfs + k * D, mf);
+            load_sym<D>(Pfs + k * D * D, Pf);
+            elem.element(mf, Pf, e);
+        }
+        // suffix scan: e_l <- e_l o e_{l+1} o ... o e_63
+        CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+            Affine<D> o;
+            affine_shfl_down<D>(e, delta, o);
+            if (lane + delta < 64) affine_compose<D>(e, o);
+        }
+        Vec<D> xm; Sym<D> xP;
+        affine_apply<D>(e, ms, Ps, xm, xP);
+        if (valid) {
+            store_vec<D>(mss + k * D, xm);
+            store_sym_full<D>(Pss + k * D * D, xP);
+        }
+        // carry for the next (earlier) tile: the state at the tile's first step, held by lane 0
+        CGP_UNROLL for (int i = 0; i < D; i++) ms.v[i] = readlane_f64(xm.v[i], 0);
+        CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) Ps.a[i] = readlane_f64(xP.a[i], 0);
+    }
+}
+
+template <class Elem>
+inline hipError_t launch_tp_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    hipLaunchKernelGGL((tp_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hipGetLastError();
+}
+
 template <class Pred, class Meas>
 inline hipError_t launch_filter(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;

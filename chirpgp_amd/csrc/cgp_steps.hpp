@@ -311,4 +311,107 @@ template <class SM, bool WAVE_> struct CdSgpsStep {
     }
 };
 
+// ============================================================================================== TIME-PARALLEL SMOOTHER
+// The discrete smoothers (rts / eks / sgp_smoother) are affine in the carry once the filtering results are known:
+//     ms_k = G_k ms_{k+1} + c_k,            c_k = mf_k - G_k mp_k
+//     Ps_k = G_k Ps_{k+1} G_k^T + C_k,      C_k = Pf_k - G_k Pp_k G_k^T = Pf_k - (G_k DT_k)^T     (G_k Pp_k = DT_k^T)
+// with G_k, mp_k, Pp_k, DT_k functions of (mf_k, Pf_k) only (filters_smoothers.py:71-85, 212-215, 342-345, 524-527).
+// So a wavefront takes 64 consecutive time steps of ONE trial, one per lane: every lane computes its own element
+// (G, c, C) -- the expensive part: model, Jacobian / sigma fan, Cholesky, solves -- then a 6-round suffix scan over
+// the lanes composes the affine maps, and each lane applies its composed map to the carry coming from later times.
+template <int D> struct Affine {
+    Mat<D> G; Vec<D> c; Sym<D> C;
+};
+
+template <int D> CGP_DEV void affine_identity(Affine<D>& e) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        e.c.v[i] = 0.0;
+        CGP_UNROLL for (int j = 0; j < D; j++) e.G.a[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) e.C.a[i] = 0.0;
+}
+
+// a <- a o b : first b (the later time steps), then a.
+template <int D> CGP_DEV void affine_compose(Affine<D>& a, const Affine<D>& b) {
+    Vec<D> c; Mat<D> T, G;
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = a.c.v[i];
+        CGP_UNROLL for (int k = 0; k < D; k++) s = fma(a.G.a[i][k], b.c.v[k], s);
+        c.v[i] = s;
+    }
+    mul_dense_sym<D>(a.G, b.C, T);                      // T = G_a C_b
+    Sym<D> Cn;
+    mul_nt_sym_add<D>(T, a.G, a.C, Cn);                 // G_a C_b G_a^T + C_a
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            double s = a.G.a[i][0] * b.G.a[0][j];
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(a.G.a[i][k], b.G.a[k][j], s);
+            G.a[i][j] = s;
+        }
+    a.G = G; a.c = c; a.C = Cn;
+}
+
+CGP_DEV double shfl_down_f64(double x, int delta) { return __shfl_down(x, delta, 64); }
+
+template <int D> CGP_DEV void affine_shfl_down(const Affine<D>& e, int delta, Affine<D>& o) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        o.c.v[i] = shfl_down_f64(e.c.v[i], delta);
+        CGP_UNROLL for (int j = 0; j < D; j++) o.G.a[i][j] = shfl_down_f64(e.G.a[i][j], delta);
+    }
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) o.C.a[i] = shfl_down_f64(e.C.a[i], delta);
+}
+
+// The element of one time step from its (mp, Pp, DT).
+template <int D>
+CGP_DEV void affine_from_prediction(const Vec<D>& mf, const Sym<D>& Pf, const Vec<D>& mp, const Sym<D>& Pp, const Mat<D>& DT,
+                                    Affine<D>& e) {
+    smoother_gain<D>(DT, Pp, e.G);
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = mf.v[i];
+        CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-e.G.a[i][k], mp.v[k], s);
+        e.c.v[i] = s;
+    }
+    CGP_UNROLL for (int i = 0; i < D; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) {
+            double s = Pf(i, j);
+            CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-e.G.a[j][k], DT.a[k][i], s);      // (G DT)(j, i)
+            e.C(i, j) = s;
+        }
+}
+
+// Applies a composed map to the carry.
+template <int D>
+CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps, Vec<D>& xm, Sym<D>& xP) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = e.c.v[i];
+        CGP_UNROLL for (int k = 0; k < D; k++) s = fma(e.G.a[i][k], ms.v[k], s);
+        xm.v[i] = s;
+    }
+    Mat<D> T;
+    mul_dense_sym<D>(e.G, Ps, T);
+    mul_nt_sym_add<D>(T, e.G, e.C, xP);
+}
+
+// Per-lane element producers (one lane = one time step, so the fan of the sigma-point variant is a serial loop).
+template <class DM> struct EksElement {
+    static constexpr int D = DM::D;
+    DM model;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
+        Vec<D> mp; Sym<D> Pp; Mat<D> DT;
+        model.propagate(mf, Pf, mp, DT, Pp);
+        affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
+    }
+};
+template <class DM> struct SgpsElement {
+    static constexpr int D = DM::D;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
+        Vec<D> mp; Sym<D> Pp; Mat<D> DT;
+        sgp_prediction<DM, false, true>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
+        affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
+    }
+};
+
 }  // namespace cgp

@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 WAVE = dict(flags=0x2)
 THREAD = dict(flags=0x4)
-SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(THREAD, id='lane_per_trial')]
+WAVE_SEQ = dict(flags=0x2 | 0x8)     # wave per trial, smoothers forced to the step-by-step scan
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
+          pytest.param(THREAD, id='lane_per_trial')]
 
 
 def _fs():
