@@ -37,7 +37,7 @@ class CgpInit(C.Structure):
 
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
-           'cgp_gaussian_expectation')
+           'cgp_gaussian_expectation', 'cgp_debug_math')
 
 _lib = None
 _lock = threading.Lock()
@@ -68,6 +68,8 @@ def load_library():
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
+        lib.cgp_debug_math.restype = C.c_int
+        lib.cgp_debug_math.argtypes = [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp]
         _lib = lib
         return lib
 
@@ -303,3 +305,14 @@ def gaussian_expectation(ms, chol_Ps, xi, w):
     _check(ctx, rc, 'cgp_gaussian_expectation')
     out = out.reshape(-1, 1)
     return out.cpu().numpy() if like_numpy else out
+
+
+def debug_math(op, x):
+    """In-kernel elementary functions on the device (test hook): returns (out0, out1) as NumPy arrays."""
+    torch = _torch()
+    xd = dev(x).reshape(-1)
+    ctx = context(xd.device.index)
+    o0, o1 = torch.empty_like(xd), torch.empty_like(xd)
+    rc = load_library().cgp_debug_math(ctx, int(op), _ptr(xd), xd.numel(), _ptr(o0), _ptr(o1), _stream())
+    _check(ctx, rc, 'cgp_debug_math')
+    return o0.cpu().numpy(), o1.cpu().numpy()

@@ -72,6 +72,23 @@ __global__ void __launch_bounds__(256) gaussian_expectation_kernel(const double*
     }
 }
 
+__global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* __restrict__ x, int64_t n,
+                                                         double* __restrict__ o0, double* __restrict__ o1) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        double a = 0.0, b = 0.0;
+        switch (op) {
+        case 0: a = fast_exp(v); break;
+        case 1: a = fast_log_ge1(v); break;
+        case 2: fast_sincos(v, a, b); break;
+        case 3: a = rcp_nr(v); break;
+        default: softplus_pair(v, a, b); break;
+        }
+        o0[i] = a;
+        if (o1) o1[i] = b;
+    }
+}
+
 }  // namespace cgp
 
 using namespace cgp;
@@ -181,6 +198,17 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
     const int64_t blocks = (n + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
     hipLaunchKernelGGL(gaussian_expectation_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ms, sd, n, in_stride, xi, w, order, out);
+    return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
+}
+
+int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (n < 0 || op < 0 || op > 4) return fail(ctx, CGP_E_ARG, "bad op or n");
+    if (n == 0) return CGP_OK;
+    if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, op, x, n, out0, out1);
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
 }
 

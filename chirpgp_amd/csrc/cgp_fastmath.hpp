@@ -1,0 +1,141 @@
+// cgp_fastmath.hpp -- lean float64 elementary functions for the serial part of the filters.
+//
+// A filter step is a strict dependency chain through exp -> log -> sincos (softplus frequency, rotation angle) and a
+// reciprocal (Kalman gain).  Measured on MI355X (tools/ubench/f64_issue.hip), one wave per SIMD, dependent chain:
+//     v_fma_f64 7 cycles | ocml exp 123 | ocml log 412 | ocml sincos 364 | f64 divide 74 | sqrt 107
+// so the library calls alone cost ~1000 of the ~3700 cycles of a v1 EKF step.  The versions below are branch-free
+// (one rarely taken fallback in sincos), have no denormal / errno / special-case paths beyond what the reference's
+// arithmetic can produce (+inf from exp overflow, NaN), and are accurate to a few ulp -- far inside the 1e-5 gate
+// and checked against a 200-bit reference in tests/test_gpu_fastmath.py.
+//
+// Constants were generated with mpmath at 200 bits (tools/gen_math_constants.py).
+#pragma once
+#include "cgp_math.hpp"
+
+namespace cgp {
+
+constexpr double kLog2e = 1.4426950408889634;
+constexpr double kLn2Hi = 0.6931471806019545;        // 32 significant bits: k * kLn2Hi is exact for |k| < 2^21
+constexpr double kLn2Lo = -4.2009150726810846e-11;
+constexpr double kTwoOverPi = 0.6366197723675814;
+constexpr double kPio2_1 = 1.5707963267341256;       // 33 bits
+constexpr double kPio2_2 = 6.077100506303966e-11;    // 33 bits
+constexpr double kPio2_3 = 2.0222662487959506e-21;
+constexpr double kSqrtHalf = 0.70710678118654752440;
+
+// 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
+CGP_DEV double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// n / d with one residual correction (<= 1 ulp).
+CGP_DEV double div_nr(double n, double d) {
+    const double r = rcp_nr(d);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// exp(x): x = k ln2 + r, Taylor of degree 13 on |r| <= ln2 / 2 (truncation 4e-18), v_ldexp_f64.
+// Overflows to +inf above 709.78 like libm; NaN in -> NaN out.
+CGP_DEV double fast_exp(double x) {
+    const double k = __builtin_rint(x * kLog2e);
+    double r = fma(-k, kLn2Hi, x);
+    r = fma(-k, kLn2Lo, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    double y = __builtin_amdgcn_ldexp(p, (int)k);
+    y = (x > 709.782712893384) ? __builtin_inf() : y;
+    y = (x < -745.2) ? 0.0 : y;
+    return y;
+}
+
+// log(z) for z in [1, +inf] (the softplus argument exp(x) + 1): z = 2^k m, m in [sqrt(1/2), sqrt(2)),
+// s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^20/21)   (|s| <= 0.1716, truncation 2e-17).
+CGP_DEV double fast_log_ge1(double z) {
+    double m = __builtin_amdgcn_frexp_mant(z);            // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(z);
+    const bool small = m < kSqrtHalf;
+    m = small ? m + m : m;
+    e = small ? e - 1 : e;
+    const double k = (double)e;
+    const double f = m - 1.0;
+    const double s = div_nr(f, m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, s2, 1.0 / 19.0);
+    p = fma(p, s2, 1.0 / 17.0);
+    p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0);
+    p = fma(p, s2, 1.0 / 11.0);
+    p = fma(p, s2, 1.0 / 9.0);
+    p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0);
+    p = fma(p, s2, 1.0 / 3.0);
+    const double two_s = s + s;
+    double lm = fma(two_s, p * s2, two_s);
+    lm = fma(k, kLn2Lo, lm);
+    double y = fma(k, kLn2Hi, lm);
+    return (z == __builtin_inf()) ? z : y;
+}
+
+// sin(x), cos(x): 3-term Cody-Waite reduction by pi/2 for |x| < 1e5 (n < 2^16: n * kPio2_1, n * kPio2_2 exact),
+// Taylor to r^17 / r^16 on |r| <= pi/4 (truncation 5e-17).  Larger |x|, inf and NaN take the library path.
+CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
+    if (!(fabs(x) < 1.0e5)) {
+        sincos(x, &sn, &cs);
+        return;
+    }
+    const double n = __builtin_rint(x * kTwoOverPi);
+    double r = fma(-n, kPio2_1, x);
+    r = fma(-n, kPio2_2, r);
+    r = fma(-n, kPio2_3, r);
+    const double r2 = r * r;
+    double ps = -1.0 / 355687428096000.0;          // -1/17!
+    ps = fma(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
+    ps = fma(ps, r2, -1.0 / 6227020800.0);         // -1/13!
+    ps = fma(ps, r2, 1.0 / 39916800.0);            //  1/11!
+    ps = fma(ps, r2, -1.0 / 362880.0);             // -1/9!
+    ps = fma(ps, r2, 1.0 / 5040.0);                //  1/7!
+    ps = fma(ps, r2, -1.0 / 120.0);                // -1/5!
+    ps = fma(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
+    double pc = 1.0 / 20922789888000.0;            //  1/16!
+    pc = fma(pc, r2, -1.0 / 87178291200.0);        // -1/14!
+    pc = fma(pc, r2, 1.0 / 479001600.0);           //  1/12!
+    pc = fma(pc, r2, -1.0 / 3628800.0);            // -1/10!
+    pc = fma(pc, r2, 1.0 / 40320.0);               //  1/8!
+    pc = fma(pc, r2, -1.0 / 720.0);                // -1/6!
+    pc = fma(pc, r2, 1.0 / 24.0);                  //  1/4!
+    const double s0 = fma(-(r * r2), ps, r);                // r - r^3 (1/3! - r^2/5! + ...)
+    const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0)); // 1 - r^2/2 + r^4 (1/4! - ...)
+    const int q = (int)n;
+    const bool swap = (q & 1) != 0;
+    double a = swap ? c0 : s0;
+    double b = swap ? s0 : c0;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
+// Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of
+// jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)) (filters_smoothers.py:44-45, 68).
+CGP_DEV double nll_increment(double S, double innov) {
+    const double sc = sqrt(S), s2 = sc * sc;
+    return 0.5 * (log(kTwoPi * s2) + innov * innov / s2);
+}
+
+}  // namespace cgp

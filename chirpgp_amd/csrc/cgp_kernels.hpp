@@ -37,17 +37,19 @@ struct SmootherIO {
 
 // Linear scalar measurement y = H x + noise (every filter but ekf_for_kpt).
 template <int D> struct LinearMeasurement {
-    CGP_DEV static double update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y, Vec<D>& mf, Sym<D>& Pf) {
-        return scalar_update<D>(mp, Pp, H, Xi, y, false, 0.0, mf, Pf);
+    CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
+                               double& S, double& innov) {
+        scalar_update<D>(mp, Pp, H, Xi, y, false, 0.0, mf, Pf, S, innov);
     }
 };
 // ekf_for_kpt (filters_smoothers.py:298-311): H = grad h(mp), pred = h(mp).
 template <int NH> struct KptUpdate {
     static constexpr int D = NH + 2;
-    CGP_DEV static double update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>&, double Xi, double y, Vec<D>& mf, Sym<D>& Pf) {
+    CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>&, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
+                               double& S, double& innov) {
         Vec<D> H;
         const double pred = KptMeasurement<NH>::eval(mp, H);
-        return scalar_update<D>(mp, Pp, H, Xi, y, true, pred, mf, Pf);
+        scalar_update<D>(mp, Pp, H, Xi, y, true, pred, mf, Pf, S, innov);
     }
 };
 
@@ -78,7 +80,12 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool writer = !WAVE || lane == 0;
 
-    double cum = 0.0, ychunk = 0.0;
+    // The negative log-likelihood needs sqrt, log and a divide per step but nothing downstream depends on it, so the
+    // wave-per-trial shape keeps it off the serial chain: lane (t mod 64) latches (S, innovation) of step t, and every
+    // 64 steps all lanes evaluate their increment at once, prefix-sum it across the wave and store 64 cumulative
+    // values with one coalesced 512-B store.
+    const bool want_nll = io.nll != nullptr;
+    double cum = 0.0, ychunk = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t = 0; t < T; t++) {
         double y;
         if (WAVE) {
@@ -88,12 +95,31 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
             y = ys[t];
         }
         Vec<D> mp; Sym<D> Pp;
+        double S, innov;
         pred.predict(lane, lds, mf, Pf, mp, Pp);
-        cum += Meas::update(mp, Pp, H, Xi, y, mf, Pf);
+        Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+        if (WAVE) {
+            if (want_nll) {
+                const int slot = (int)(t & 63);
+                if (lane == slot) { S_l = S; innov_l = innov; }
+                if (slot == 63 || t == T - 1) {
+                    double v = (lane <= slot) ? nll_increment(S_l, innov_l) : 0.0;
+                    CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+                        const double up = __shfl_up(v, delta, 64);
+                        if (lane >= delta) v += up;
+                    }
+                    v += cum;
+                    if (nll && lane <= slot) nll[t - slot + lane] = v;
+                    cum = readlane_f64(v, slot);
+                }
+            }
+        } else if (want_nll) {
+            cum += nll_increment(S, innov);
+            if (nll) nll[t] = cum;
+        }
         if (writer) {
             if (mfs) store_vec<D>(mfs + t * D, mf);
             if (Pfs) store_sym_full<D>(Pfs + t * D * D, Pf);
-            if (nll) nll[t] = cum;
         }
     }
     if (writer && io.nll && nll_final) io.nll[trial] = cum;

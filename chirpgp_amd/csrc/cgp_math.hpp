@@ -107,11 +107,12 @@ template <int D> CGP_DEV void cho_solve_mat(const Sym<D>& L, const Vec<D>& inv_d
 
 // ---------------------------------------------------------------------------------------------- Kalman pieces
 // Scalar-measurement update, filters_smoothers.py:55-68: S = H^T Pp H + Xi, K = Pp H / S, mf = mp + K (y - pred),
-// Pf = Pp - (K K^T) S (the reference's form, not Joseph), and the increment of the negative log-likelihood in the
-// arithmetic of jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)).
+// Pf = Pp - (K K^T) S (the reference's form, not Joseph).  Here K = (Pp H) * (1 / S) with a Newton-refined reciprocal
+// and (K K^T) S is formed as K (Pp H)^T -- the same matrix, one rounding fewer.  Returns S and the innovation; the
+// negative log-likelihood increment is nll_increment(S, innov) (cgp_fastmath.hpp).
 template <int D>
-CGP_DEV double scalar_update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y,
-                             bool override_pred, double pred_in, Vec<D>& mf, Sym<D>& Pf) {
+CGP_DEV void scalar_update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y,
+                           bool override_pred, double pred_in, Vec<D>& mf, Sym<D>& Pf, double& S_out, double& innov_out) {
     Vec<D> PH;
     CGP_UNROLL for (int i = 0; i < D; i++) {
         double s = Pp(i, 0) * H.v[0];
@@ -123,13 +124,18 @@ CGP_DEV double scalar_update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H
     S += Xi;
     if (override_pred) pred = pred_in;
     const double innov = y - pred;
+    double rS = __builtin_amdgcn_rcp(S);
+    double e = fma(-S, rS, 1.0);
+    rS = fma(rS, e, rS);
+    e = fma(-S, rS, 1.0);
+    rS = fma(rS, e, rS);
     Vec<D> K;
-    CGP_UNROLL for (int i = 0; i < D; i++) K.v[i] = PH.v[i] / S;
+    CGP_UNROLL for (int i = 0; i < D; i++) K.v[i] = PH.v[i] * rS;
     CGP_UNROLL for (int i = 0; i < D; i++) mf.v[i] = fma(K.v[i], innov, mp.v[i]);
     CGP_UNROLL for (int i = 0; i < D; i++)
-        CGP_UNROLL for (int j = 0; j <= i; j++) Pf(i, j) = Pp(i, j) - (K.v[i] * K.v[j]) * S;
-    const double sc = sqrt(S), s2 = sc * sc;
-    return 0.5 * (log(kTwoPi * s2) + innov * innov / s2);
+        CGP_UNROLL for (int j = 0; j <= i; j++) Pf(i, j) = fma(-K.v[i], PH.v[j], Pp(i, j));
+    S_out = S;
+    innov_out = innov;
 }
 
 // Gaussian smoother step, filters_smoothers.py:71-85: G = (Pp^{-1} DT)^T, ms = mf + G (ms - mp), Ps = Pf + G (Ps - Pp) G^T.

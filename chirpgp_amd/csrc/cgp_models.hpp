@@ -11,17 +11,19 @@
 // exploit: ~4.5 d^2 FMAs instead of 4 d^3.
 #pragma once
 #include "cgp_math.hpp"
+#include "cgp_fastmath.hpp"
 
 namespace cgp {
 
 // softplus in the reference's naive form log(exp(x) + 1) (models.py:50) and its derivative as jax.jacfwd forms it,
 // exp(x) / (exp(x) + 1): both overflow (inf, NaN) exactly where the reference does.
 CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
-    const double e = exp(x);
+    const double e = fast_exp(x);
     const double z = e + 1.0;
-    sp = log(z);
-    dsp = e / z;
+    sp = fast_log_ge1(z);
+    dsp = e * rcp_nr(z);            // inf * NaN = NaN where the reference has inf / inf = NaN
 }
+CGP_DEV double softplus(double x) { return fast_log_ge1(fast_exp(x) + 1.0); }
 
 // Closed-form Matern-3/2 discretisation, models.py:61-73.
 CGP_DEV void m32_solution(double ell, double sigma, double dt, double (&M)[4], double (&S)[3]) {
@@ -74,16 +76,21 @@ template <int NH> struct HarmonicLCD {
             m32_solution(p[2], p[3], dt, M, MS);
         }
     }
-    // cos/sin of dt*k*w scaled by rho, for every harmonic
+    // cos/sin of dt*k*w scaled by rho, for every harmonic: one sincos for the fundamental, the angle-addition
+    // recurrence for the overtones (same values as cos(dt k w), sin(dt k w) up to rounding).
     CGP_DEV void rotations(double w, double (&c)[NH], double (&s)[NH]) const {
-        CGP_UNROLL for (int k = 0; k < NH; k++) {
-            double sn, cs;
-            sincos((dt * (double)(k + 1)) * w, &sn, &cs);
-            c[k] = cs * rho; s[k] = sn * rho;
+        double s1, c1;
+        fast_sincos(dt * w, s1, c1);
+        double ck = c1, sk = s1;
+        c[0] = c1 * rho; s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            c[k] = ck * rho; s[k] = sk * rho;
         }
     }
     CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const {
-        const double w = (kTwoPi * log(exp(u.v[IV]) + 1.0)) * fs;
+        const double w = (kTwoPi * softplus(u.v[IV])) * fs;
         double c[NH], s[NH];
         rotations(w, c, s);
         CGP_UNROLL for (int k = 0; k < NH; k++) {
@@ -165,7 +172,7 @@ template <int NH> struct HarmonicSDE {
     double lam, gam, fs;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { lam = p[0]; gam = sqrt(3.0) / p[1]; fs = p[2]; }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
-        const double w = (kTwoPi * log(exp(u.v[IV]) + 1.0)) * fs;
+        const double w = (kTwoPi * softplus(u.v[IV])) * fs;
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             const double wk = w * (double)(k + 1);
             a.v[2 * k] = -lam * u.v[2 * k] - wk * u.v[2 * k + 1];
@@ -229,7 +236,7 @@ template <int NH> struct KptMeasurement {
         CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0;
         CGP_UNROLL for (int k = 1; k <= NH; k++) {
             double sn, cs;
-            sincos(gs * (double)k, &sn, &cs);
+            fast_sincos(gs * (double)k, sn, cs);
             h = fma(x.v[k], sn, h);
             H.v[k] = sn;
             dsum = fma(x.v[k] * cs, (double)k * dgs, dsum);

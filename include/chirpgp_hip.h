@@ -143,6 +143,11 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
                              const double* xi, const double* w, int32_t order, double* out, void* stream);
 
+/* Test hook: evaluates one of the engine's in-kernel float64 elementary functions (csrc/cgp_fastmath.hpp) on n inputs.
+ * op: 0 exp, 1 log on [1, inf] (softplus argument), 2 sincos (out0 = sin, out1 = cos), 3 reciprocal,
+ *     4 softplus pair (out0 = log(exp(x) + 1), out1 = its derivative).  out1 may be NULL for one-output ops. */
+int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,81 @@
+"""Accuracy of the engine's in-kernel float64 elementary functions (csrc/cgp_fastmath.hpp) against a 200-bit
+reference (mpmath), through the C-ABI test hook cgp_debug_math.  Bar: a few ulp -- 1e-14 relative here, nine orders
+inside the path's 1e-5 gate."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_err(got, want_mp):
+    import mpmath as mp
+    errs = []
+    for g, w in zip(got, want_mp):
+        if w == 0:
+            errs.append(abs(g))
+        else:
+            errs.append(float(abs((mp.mpf(float(g)) - w) / w)))
+    return max(errs)
+
+
+def test_exp():
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-40, 40, 3000), rng.uniform(-700, 700, 500), [0., 1., -1., 709.7, -708., 1e-300]])
+    got, _ = E.debug_math(0, x)
+    assert _ulp_err(got, [mp.exp(mp.mpf(float(v))) for v in x]) < 1e-14
+    sp, _ = E.debug_math(0, np.array([710., 1e4, np.inf, -746., -np.inf, np.nan]))
+    assert sp[0] == np.inf and sp[1] == np.inf and sp[2] == np.inf and sp[3] == 0. and sp[4] == 0. and np.isnan(sp[5])
+    np.testing.assert_array_equal(sp[:5], np.exp(np.array([710., 1e4, np.inf, -746., -np.inf])))
+
+
+def test_log_ge1_and_softplus():
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(1)
+    z = np.concatenate([1 + np.exp(rng.uniform(-36, 40, 3000)), rng.uniform(1, 4, 500), 10 ** rng.uniform(0, 300, 500),
+                        [1., 1. + 2 ** -52, 2., np.sqrt(2.), 1.7976931348623157e308]])
+    got, _ = E.debug_math(1, z)
+    assert _ulp_err(got, [mp.log(mp.mpf(float(v))) for v in z]) < 1e-14
+    inf, _ = E.debug_math(1, np.array([np.inf, np.nan]))
+    assert inf[0] == np.inf and np.isnan(inf[1])
+    # softplus pair in the reference's naive form, incl. its overflow behaviour (models.py:50)
+    x = np.concatenate([rng.uniform(-30, 60, 2000), [7., 0., 708., 710., 800., -800.]])
+    sp, dsp = E.debug_math(4, x)
+    with np.errstate(over='ignore', invalid='ignore'):
+        e = np.exp(x)
+        want_sp, want_d = np.log(e + 1.), e / (e + 1.)
+    assert np.array_equal(np.isnan(dsp), np.isnan(want_d)) and np.array_equal(np.isinf(sp), np.isinf(want_sp))
+    ok = np.isfinite(want_sp) & (want_sp > 0)
+    assert np.max(np.abs(sp[ok] - want_sp[ok]) / want_sp[ok]) < 1e-14
+    okd = np.isfinite(want_d)
+    assert np.max(np.abs(dsp[okd] - want_d[okd]) / np.maximum(want_d[okd], 1e-300)) < 1e-14
+
+
+def test_sincos():
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 300
+    rng = np.random.default_rng(2)
+    k = rng.integers(-60000, 60000, 400)
+    x = np.concatenate([rng.uniform(-10, 10, 3000), rng.uniform(-9e4, 9e4, 1500), k * (np.pi / 2) + rng.uniform(-1e-6, 1e-6, 400),
+                        [0., 0.044, np.pi / 4, -np.pi / 4, 99999.9, 1.0e5, 3.3e7, 1e15]])
+    sn, cs = E.debug_math(2, x)
+    want_s = [mp.sin(mp.mpf(float(v))) for v in x]
+    want_c = [mp.cos(mp.mpf(float(v))) for v in x]
+    # absolute error (the values feed rotations: what matters is |error| vs 1), plus relative where not tiny
+    assert max(abs(float(mp.mpf(float(g)) - w)) for g, w in zip(sn, want_s)) < 3e-16
+    assert max(abs(float(mp.mpf(float(g)) - w)) for g, w in zip(cs, want_c)) < 3e-16
+    sp, cp = E.debug_math(2, np.array([np.inf, np.nan]))
+    assert np.all(np.isnan(sp)) and np.all(np.isnan(cp))
+
+
+def test_rcp():
+    from chirpgp_amd import _engine as E
+    rng = np.random.default_rng(3)
+    x = np.concatenate([10 ** rng.uniform(-200, 200, 3000) * rng.choice([-1, 1], 3000), [1., 0.1, 3.]])
+    got, _ = E.debug_math(3, x)
+    assert np.max(np.abs(got * x - 1.0)) < 4e-16
