@@ -23,6 +23,15 @@ constexpr double kPio2_2 = 6.077100506303966e-11;    // 33 bits
 constexpr double kPio2_3 = 2.0222662487959506e-21;
 constexpr double kSqrtHalf = 0.70710678118654752440;
 
+// p * x + c as a three-address v_fma_f64.  hipcc selects the two-address v_fmac_f64 for fma(p, x, CONSTANT) and then has to
+// copy the loop-invariant constant into the destination first (v_mov_b64 + v_fmac_f64 per Horner step, seen in the
+// ISA of the v2 kernels); the explicit form keeps every coefficient in its own VGPR pair and issues one instruction.
+CGP_DEV double horner(double p, double x, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "v"(c));
+    return d;
+}
+
 // 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
 CGP_DEV double rcp_nr(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -46,19 +55,19 @@ CGP_DEV double fast_exp(double x) {
     double r = fma(-k, kLn2Hi, x);
     r = fma(-k, kLn2Lo, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    p = horner(p, r, 1.0 / 479001600.0);
+    p = horner(p, r, 1.0 / 39916800.0);
+    p = horner(p, r, 1.0 / 3628800.0);
+    p = horner(p, r, 1.0 / 362880.0);
+    p = horner(p, r, 1.0 / 40320.0);
+    p = horner(p, r, 1.0 / 5040.0);
+    p = horner(p, r, 1.0 / 720.0);
+    p = horner(p, r, 1.0 / 120.0);
+    p = horner(p, r, 1.0 / 24.0);
+    p = horner(p, r, 1.0 / 6.0);
+    p = horner(p, r, 0.5);
+    p = horner(p, r, 1.0);
+    p = horner(p, r, 1.0);
     double y = __builtin_amdgcn_ldexp(p, (int)k);
     y = (x > 709.782712893384) ? __builtin_inf() : y;
     y = (x < -745.2) ? 0.0 : y;
@@ -78,15 +87,15 @@ CGP_DEV double fast_log_ge1(double z) {
     const double s = div_nr(f, m + 1.0);
     const double s2 = s * s;
     double p = 1.0 / 21.0;
-    p = fma(p, s2, 1.0 / 19.0);
-    p = fma(p, s2, 1.0 / 17.0);
-    p = fma(p, s2, 1.0 / 15.0);
-    p = fma(p, s2, 1.0 / 13.0);
-    p = fma(p, s2, 1.0 / 11.0);
-    p = fma(p, s2, 1.0 / 9.0);
-    p = fma(p, s2, 1.0 / 7.0);
-    p = fma(p, s2, 1.0 / 5.0);
-    p = fma(p, s2, 1.0 / 3.0);
+    p = horner(p, s2, 1.0 / 19.0);
+    p = horner(p, s2, 1.0 / 17.0);
+    p = horner(p, s2, 1.0 / 15.0);
+    p = horner(p, s2, 1.0 / 13.0);
+    p = horner(p, s2, 1.0 / 11.0);
+    p = horner(p, s2, 1.0 / 9.0);
+    p = horner(p, s2, 1.0 / 7.0);
+    p = horner(p, s2, 1.0 / 5.0);
+    p = horner(p, s2, 1.0 / 3.0);
     const double two_s = s + s;
     double lm = fma(two_s, p * s2, two_s);
     lm = fma(k, kLn2Lo, lm);
@@ -107,20 +116,20 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     r = fma(-n, kPio2_3, r);
     const double r2 = r * r;
     double ps = -1.0 / 355687428096000.0;          // -1/17!
-    ps = fma(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
-    ps = fma(ps, r2, -1.0 / 6227020800.0);         // -1/13!
-    ps = fma(ps, r2, 1.0 / 39916800.0);            //  1/11!
-    ps = fma(ps, r2, -1.0 / 362880.0);             // -1/9!
-    ps = fma(ps, r2, 1.0 / 5040.0);                //  1/7!
-    ps = fma(ps, r2, -1.0 / 120.0);                // -1/5!
-    ps = fma(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
+    ps = horner(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
+    ps = horner(ps, r2, -1.0 / 6227020800.0);         // -1/13!
+    ps = horner(ps, r2, 1.0 / 39916800.0);            //  1/11!
+    ps = horner(ps, r2, -1.0 / 362880.0);             // -1/9!
+    ps = horner(ps, r2, 1.0 / 5040.0);                //  1/7!
+    ps = horner(ps, r2, -1.0 / 120.0);                // -1/5!
+    ps = horner(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
     double pc = 1.0 / 20922789888000.0;            //  1/16!
-    pc = fma(pc, r2, -1.0 / 87178291200.0);        // -1/14!
-    pc = fma(pc, r2, 1.0 / 479001600.0);           //  1/12!
-    pc = fma(pc, r2, -1.0 / 3628800.0);            // -1/10!
-    pc = fma(pc, r2, 1.0 / 40320.0);               //  1/8!
-    pc = fma(pc, r2, -1.0 / 720.0);                // -1/6!
-    pc = fma(pc, r2, 1.0 / 24.0);                  //  1/4!
+    pc = horner(pc, r2, -1.0 / 87178291200.0);        // -1/14!
+    pc = horner(pc, r2, 1.0 / 479001600.0);           //  1/12!
+    pc = horner(pc, r2, -1.0 / 3628800.0);            // -1/10!
+    pc = horner(pc, r2, 1.0 / 40320.0);               //  1/8!
+    pc = horner(pc, r2, -1.0 / 720.0);                // -1/6!
+    pc = horner(pc, r2, 1.0 / 24.0);                  //  1/4!
     const double s0 = fma(-(r * r2), ps, r);                // r - r^3 (1/3! - r^2/5! + ...)
     const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0)); // 1 - r^2/2 + r^4 (1/4! - ...)
     const int q = (int)n;

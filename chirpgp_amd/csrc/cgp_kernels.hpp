@@ -85,39 +85,50 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
     // 64 steps all lanes evaluate their increment at once, prefix-sum it across the wave and store 64 cumulative
     // values with one coalesced 512-B store.
     const bool want_nll = io.nll != nullptr;
-    double cum = 0.0, ychunk = 0.0, S_l = 1.0, innov_l = 0.0;
-    for (int64_t t = 0; t < T; t++) {
-        double y;
-        if (WAVE) {
-            if ((t & 63) == 0) ychunk = (t + lane < T) ? ys[t + lane] : 0.0;
-            y = readlane_f64(ychunk, (int)(t & 63));
-        } else {
-            y = ys[t];
-        }
-        Vec<D> mp; Sym<D> Pp;
-        double S, innov;
-        pred.predict(lane, lds, mf, Pf, mp, Pp);
-        Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
-        if (WAVE) {
-            if (want_nll) {
-                const int slot = (int)(t & 63);
+    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    if constexpr (WAVE) {
+        for (int64_t t0 = 0; t0 < T; t0 += 64) {
+            // 64 measurements with one coalesced 512-B load.  The empty asm consumes the loaded register here, so the
+            // compiler's s_waitcnt vmcnt(0) for it sits in this outer loop and not in front of every step's v_readlane
+            // (where it would also wait for the previous step's ten output stores to be acknowledged).
+            double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+            asm volatile("" : "+v"(ychunk));
+            const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+            for (int slot = 0; slot < nsteps; slot++) {
+                const int64_t t = t0 + slot;
+                const double y = readlane_f64(ychunk, slot);
+                Vec<D> mp; Sym<D> Pp;
+                double S, innov;
+                pred.predict(lane, lds, mf, Pf, mp, Pp);
+                Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
                 if (lane == slot) { S_l = S; innov_l = innov; }
-                if (slot == 63 || t == T - 1) {
-                    double v = (lane <= slot) ? nll_increment(S_l, innov_l) : 0.0;
-                    CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
-                        const double up = __shfl_up(v, delta, 64);
-                        if (lane >= delta) v += up;
-                    }
-                    v += cum;
-                    if (nll && lane <= slot) nll[t - slot + lane] = v;
-                    cum = readlane_f64(v, slot);
+                if (writer) {
+                    if (mfs) store_vec<D>(mfs + t * D, mf);
+                    if (Pfs) store_sym_full<D>(Pfs + t * D * D, Pf);
                 }
             }
-        } else if (want_nll) {
-            cum += nll_increment(S, innov);
-            if (nll) nll[t] = cum;
+            if (want_nll) {
+                double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
+                CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+                    const double up = __shfl_up(v, delta, 64);
+                    if (lane >= delta) v += up;
+                }
+                v += cum;
+                if (nll && lane < nsteps) nll[t0 + lane] = v;
+                cum = readlane_f64(v, nsteps - 1);
+            }
         }
-        if (writer) {
+    } else {
+        for (int64_t t = 0; t < T; t++) {
+            const double y = ys[t];
+            Vec<D> mp; Sym<D> Pp;
+            double S, innov;
+            pred.predict(lane, lds, mf, Pf, mp, Pp);
+            Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+            if (want_nll) {
+                cum += nll_increment(S, innov);
+                if (nll) nll[t] = cum;
+            }
             if (mfs) store_vec<D>(mfs + t * D, mf);
             if (Pfs) store_sym_full<D>(Pfs + t * D * D, Pf);
         }
