@@ -175,13 +175,14 @@ def main():
     # the single collective of the path: gather the per-trial final NLL (B doubles per rank) -- after the timed region
     gather_ms = None
     if world > 1:
+        from chirpgp_amd import parallel
         last = f[2][:, -1].contiguous()
-        out = torch.empty(world * B, dtype=torch.float64, device='cuda')
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, last)
+        out = parallel.all_gather_trials(last, world * B)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        assert out.shape[0] == world * B
 
     if rank == 0:
         filt_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
