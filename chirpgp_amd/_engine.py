@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libchirpgp_hip.so')
 F_EKF, F_SGP, F_CD_EKF, F_CD_SGP, F_EKF_KPT = range(5)
 S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
 M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
-NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN = 0x1, 0x2, 0x4, 0x8
+NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL = 0x1, 0x2, 0x4, 0x8, 0x10
 MAX_D = 8
 
 _vp = C.c_void_p

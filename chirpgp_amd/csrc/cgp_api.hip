@@ -144,7 +144,11 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;
     case CGP_M_HARMONIC_LCD:
-    case CGP_M_LASCALA_LCD:  rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st); break;
+    case CGP_M_LASCALA_LCD:
+        // d = 4 EKF, one wavefront per trial: the lane-cooperative kernel (covariance spread over a 16-lane DPP row)
+        if (method == CGP_F_EKF && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4(io, ma, st);
+        else rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st);
+        break;
     case CGP_M_LINEAR_SDE:   rc = dispatch_filter_sde_linear(method, model->d, wave, io, ma, st); break;
     case CGP_M_HARMONIC_SDE: rc = dispatch_filter_sde_harm(method, model->n_harm, wave, io, ma, st); break;
     case CGP_M_KPT:          rc = dispatch_filter_kpt(model->n_harm, wave, io, ma, st); break;

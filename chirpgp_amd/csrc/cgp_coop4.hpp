@@ -1,0 +1,179 @@
+// cgp_coop4.hpp -- lane-cooperative EKF step for the d = 4 chirp model (BASELINE config C2's filter).
+//
+// Why: with one trial per wavefront the generic filter kernel executes every float64 instruction of a step on 64
+// identical lanes: 303 VALU + 42 SALU instructions and 1917 cycles per step (profiles/r01_v4_ekf_eks_pmc.json), i.e. the
+// SIMD retires one useful lane-operation per 4-cycle instruction slot.  Here the 4 x 4 covariance algebra is spread
+// over a 16-lane DPP row instead -- lane (i, j) = (lane >> 2 & 3, lane & 3) owns P[i][j] -- and only the scalar chain
+// that cannot be split (softplus -> sincos of the state's frequency component, the mean) stays replicated:
+//
+//     Q  = P J^T          Q[i][j]  = sum_l J[j][l] P[i][l]        P[i][l]: quad broadcast (DPP quad_perm)
+//     Pp = J Q + Sigma    Pp[i][j] = sum_r J[i][l_r] Q[l_r][j]    Q[l_r][j]: row rotation by 4 r lanes (DPP row_ror)
+//     PH[j] (column sums over rows: row_ror 4, 8), PH[i] (quad sums), S, 1/S uniform; Pf[i][j] = Pp - PH[i] PH[j] / S
+//
+// The four 16-lane rows of the wavefront carry identical copies (DPP row operations never cross a row).  J = blockdiag(
+// rho Rot(theta), M32) + (d/du_v column) is assembled per lane as a few FMAs with per-lane 0/1/constant coefficients
+// fixed at kernel start, so no per-step selects are needed.  Which row a rotated operand came from is discovered at
+// start-up by rotating the row index itself, so the code does not depend on the rotation direction convention.
+//
+// Outputs: lanes 0..15 store Pf[t] as one coalesced 128-B row; lane 0 stores mf[t]; the NLL goes through the same
+// 64-step latch / prefix-sum as the generic kernel.
+#pragma once
+#include "cgp_kernels.hpp"
+
+namespace cgp {
+
+template <int CTRL> CGP_DEV int dpp_i32(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, false); }
+template <int CTRL> CGP_DEV double dpp_f64(double x) {
+    const int lo = dpp_i32<CTRL>(__double2loint(x));
+    const int hi = dpp_i32<CTRL>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+constexpr int kQuadBcast0 = 0x00, kQuadBcast1 = 0x55, kQuadBcast2 = 0xAA, kQuadBcast3 = 0xFF;
+constexpr int kQuadSwap1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int kQuadSwap2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int kRowRor4 = 0x124, kRowRor8 = 0x128, kRowRor12 = 0x12C;
+
+// J[i][l] of the chirp LCD model as  b * s + g0 * jv0 + g1 * jv1 + k  for l != i  (c only sits on the diagonal).
+struct OffDiagCoef { double b, g0, g1, k; };
+CGP_DEV OffDiagCoef offdiag_coef(int i, int l, const double (&M)[4]) {
+    OffDiagCoef o{0.0, 0.0, 0.0, 0.0};
+    if (i == 0 && l == 1) o.b = -1.0;
+    if (i == 1 && l == 0) o.b = 1.0;
+    if (i == 0 && l == 2) o.g0 = 1.0;
+    if (i == 1 && l == 2) o.g1 = 1.0;
+    if (i == 2 && l == 3) o.k = M[1];
+    if (i == 3 && l == 2) o.k = M[2];
+    return o;
+}
+
+__global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma) {
+    const int lane = threadIdx.x;
+    const int li = (lane >> 2) & 3, lj = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicLCD<1> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    const double rho = model.rho, dt = model.dt, fs = model.fs;
+    const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
+
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double H0 = Hp[0], H1 = Hp[1], H2 = Hp[2], H3 = Hp[3];
+    const double Hi = Hp[li], Hj = Hp[lj];
+    const double Xi = io.Xi[trial * io.Xi_stride];
+
+    // Sigma[i][j] of this lane (models.py:302-308)
+    double Sig = 0.0;
+    if (li == lj) Sig = (li < 2) ? model.q : (li == 2 ? model.MS[0] : model.MS[2]);
+    else if (li + lj == 5) Sig = model.MS[1];
+
+    // J[j][l], l = 0..3 (row j, for Q = P J^T)
+    const double ac0 = (lj == 0) ? 1.0 : 0.0, bc0 = (lj == 1) ? 1.0 : 0.0;       // J[j][0] = ac0 c + bc0 s
+    const double ac1 = (lj == 1) ? 1.0 : 0.0, bc1 = (lj == 0) ? -1.0 : 0.0;      // J[j][1] = ac1 c + bc1 s
+    const double wc0 = (lj == 0) ? 1.0 : 0.0, wc1 = (lj == 1) ? 1.0 : 0.0;       // J[j][2] = wc0 jv0 + wc1 jv1 + kc2
+    const double kc2 = (lj == 2) ? M0 : (lj == 3 ? M2 : 0.0);
+    const double kc3 = (lj == 2) ? M1 : (lj == 3 ? M3 : 0.0);                    // J[j][3]
+    // J[i][l_r]: r = 0 is the diagonal, r = 1..3 whatever row the rotation by 4 r lanes delivers
+    const double ar0 = (li < 2) ? 1.0 : 0.0, kr0 = (li == 2) ? M0 : (li == 3 ? M3 : 0.0);
+    const OffDiagCoef r1 = offdiag_coef(li, dpp_i32<kRowRor4>(li), model.M);
+    const OffDiagCoef r2 = offdiag_coef(li, dpp_i32<kRowRor8>(li), model.M);
+    const OffDiagCoef r3 = offdiag_coef(li, dpp_i32<kRowRor12>(li), model.M);
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    double u0 = m0p[0], u1 = m0p[1], u2 = m0p[2], u3 = m0p[3];
+    const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
+    double P = (li >= lj) ? P0p[li * 4 + lj] : P0p[lj * 4 + li];     // lower triangle, like the generic kernels
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * 4 : nullptr;
+    double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * 16 : nullptr;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+
+    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const int64_t t = t0 + slot;
+            const double y = readlane_f64(ychunk, slot);
+            // ---- replicated scalar chain: rotation of the chirp block at frequency g(u2) (models.py:296-301) and N1
+            double sp, dsp;
+            softplus_pair(u2, sp, dsp);
+            const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
+            double s1, c1;
+            fast_sincos(dt * w, s1, c1);
+            const double c = c1 * rho, s = s1 * rho;
+            const double f0 = fma(c, u0, -s * u1), f1 = fma(s, u0, c * u1);
+            const double f2 = fma(M0, u2, M1 * u3), f3 = fma(M2, u2, M3 * u3);
+            const double dth = dt * dw;
+            const double jv0 = -dth * f1, jv1 = dth * f0;             // d f0 / d u2, d f1 / d u2
+            // ---- per-lane Jacobian entries
+            const double Jc0 = fma(ac0, c, bc0 * s);
+            const double Jc1 = fma(ac1, c, bc1 * s);
+            const double Jc2 = fma(wc0, jv0, fma(wc1, jv1, kc2));
+            const double Jr0 = fma(ar0, c, kr0);
+            const double Jr1 = fma(r1.b, s, fma(r1.g0, jv0, fma(r1.g1, jv1, r1.k)));
+            const double Jr2 = fma(r2.b, s, fma(r2.g0, jv0, fma(r2.g1, jv1, r2.k)));
+            const double Jr3 = fma(r3.b, s, fma(r3.g0, jv0, fma(r3.g1, jv1, r3.k)));
+            // ---- Q = P J^T
+            double Q = Jc0 * dpp_f64<kQuadBcast0>(P);
+            Q = fma(Jc1, dpp_f64<kQuadBcast1>(P), Q);
+            Q = fma(Jc2, dpp_f64<kQuadBcast2>(P), Q);
+            Q = fma(kc3, dpp_f64<kQuadBcast3>(P), Q);
+            // ---- Pp = J Q + Sigma
+            double Pp = fma(Jr0, Q, Sig);
+            Pp = fma(Jr1, dpp_f64<kRowRor4>(Q), Pp);
+            Pp = fma(Jr2, dpp_f64<kRowRor8>(Q), Pp);
+            Pp = fma(Jr3, dpp_f64<kRowRor12>(Q), Pp);
+            // ---- update (filters_smoothers.py:55-68)
+            double PHj = Pp * Hi;                                     // PH[j] = sum_i Pp[i][j] H[i]: sum over the rows
+            PHj += dpp_f64<kRowRor4>(PHj);
+            PHj += dpp_f64<kRowRor8>(PHj);
+            double PHi = Pp * Hj;                                     // PH[i] = sum_j Pp[i][j] H[j]: sum over the quad
+            PHi += dpp_f64<kQuadSwap1>(PHi);
+            PHi += dpp_f64<kQuadSwap2>(PHi);
+            double S = Hj * PHj;
+            S += dpp_f64<kQuadSwap1>(S);
+            S += dpp_f64<kQuadSwap2>(S);
+            S += Xi;
+            const double pred = fma(H3, f3, fma(H2, f2, fma(H1, f1, H0 * f0)));
+            const double innov = y - pred;
+            const double rS = rcp_nr(S);
+            P = fma(-(PHi * rS), PHj, Pp);                            // Pf = Pp - K (Pp H)^T
+            const double g = rS * innov;
+            u0 = fma(dpp_f64<kQuadBcast0>(PHj), g, f0);               // mf = mp + K innov, K = PH / S
+            u1 = fma(dpp_f64<kQuadBcast1>(PHj), g, f1);
+            u2 = fma(dpp_f64<kQuadBcast2>(PHj), g, f2);
+            u3 = fma(dpp_f64<kQuadBcast3>(PHj), g, f3);
+            if (lane == slot) { S_l = S; innov_l = innov; }
+            if (Pfs && lane < 16) Pfs[t * 16 + lane] = P;
+            if (mfs && lane == 0) {
+                *reinterpret_cast<double2*>(mfs + t * 4) = make_double2(u0, u1);
+                *reinterpret_cast<double2*>(mfs + t * 4 + 2) = make_double2(u2, u3);
+            }
+        }
+        if (want_nll) {
+            double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
+            CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+                const double up = __shfl_up(v, delta, 64);
+                if (lane >= delta) v += up;
+            }
+            v += cum;
+            if (nll && lane < nsteps) nll[t0 + lane] = v;
+            cum = readlane_f64(v, nsteps - 1);
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+inline int launch_ekf4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL(ekf4_coop_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace cgp

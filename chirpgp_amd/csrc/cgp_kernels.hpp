@@ -259,6 +259,7 @@ int dispatch_filter_disc_harm(int method, int key, bool wave, const FilterIO&, c
 int dispatch_filter_sde_linear(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_sde_harm(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_kpt(int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_coop4(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_disc_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_disc_harm(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_sde_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);

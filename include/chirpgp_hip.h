@@ -116,6 +116,7 @@ typedef struct cgp_init {
 #define CGP_WAVE_PER_TRIAL    0x2u   /* force one 64-lane wavefront per trial (small batches; default below a threshold)  */
 #define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
 #define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
+#define CGP_GENERIC_KERNEL    0x10u  /* filters: force the generic kernel where a lane-cooperative specialisation exists   */
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */
 #define CGP_OK              0

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 WAVE = dict(flags=0x2)
 THREAD = dict(flags=0x4)
-WAVE_SEQ = dict(flags=0x2 | 0x8)     # wave per trial, smoothers forced to the step-by-step scan
+WAVE_SEQ = dict(flags=0x2 | 0x8 | 0x10)     # wave per trial, step-by-step smoother scan, generic (non-cooperative) filter kernels
 SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
           pytest.param(THREAD, id='lane_per_trial')]
 
@@ -245,7 +245,11 @@ def test_full_size_properties_and_parity():
     assert torch.equal(mss[:, -1], mfs[:, -1]) and torch.equal(Pss[:, -1], Pfs[:, -1])
     # cumulative nll is non-decreasing only in expectation; but it must equal the running sum of its own increments
     # symmetric covariances
-    assert torch.equal(Pfs, Pfs.transpose(-1, -2)) and torch.equal(Pss, Pss.transpose(-1, -2))
+    # symmetric covariances: exactly for the smoother (packed storage); to rounding for the lane-cooperative filter, whose
+    # lanes (i, j) and (j, i) sum in different orders -- like the reference's own (F P) F^T, which is not bit-symmetric either
+    scale = Pfs.abs().amax(dim=(-1, -2), keepdim=True)
+    assert float(((Pfs - Pfs.transpose(-1, -2)).abs() / scale).max()) < 1e-12
+    assert torch.equal(Pss, Pss.transpose(-1, -2))
     # smoothing never increases the marginal variance (up to rounding)
     dvar = torch.diagonal(Pfs - Pss, dim1=-2, dim2=-1)
     assert float(dvar.min()) > -1e-9 * float(torch.diagonal(Pfs, dim1=-2, dim2=-1).abs().max())
