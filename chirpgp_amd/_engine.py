@@ -28,7 +28,7 @@ class CgpModel(C.Structure):
 
 
 class CgpSigma(C.Structure):
-    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _vp), ('w', _vp)]
+    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _vp), ('w', _vp), ('group_start', _vp), ('n_groups', C.c_int32)]
 
 
 class CgpInit(C.Structure):
@@ -200,14 +200,43 @@ def _model_struct(spec, gamma, B, keep):
     return m
 
 
-def _sigma_struct(sgps, d, keep):
+_sigma_cache = {}
+
+
+def _sigma_struct(sgps, d, keep, nonlinear_coord=None):
+    """cgp_sigma for a SigmaPoints.  With `nonlinear_coord` = v (the chirp models: v = d - 2) the points are reordered so
+    that points sharing xi[0..v] are contiguous and the group boundaries are passed along: the kernels then evaluate the
+    transcendental part of the model once per group (include/chirpgp_hip.h, cgp_sigma).  Reordering only changes the
+    order of summation."""
     if sgps is None:
         return None
-    xi, w = dev_const(sgps.xi), dev_const(sgps.w)
-    if xi.ndim != 2 or xi.shape[1] != d or w.shape != (xi.shape[0],):
-        raise ValueError(f'sigma points must be (s, {d}) with (s,) weights; got {tuple(xi.shape)}, {tuple(w.shape)}')
-    keep += [xi, w]
-    return CgpSigma(int(xi.shape[0]), int(d), _ptr(xi), _ptr(w))
+    torch = _torch()
+    xi_h, w_h = np.asarray(sgps.xi, dtype=np.float64), np.asarray(sgps.w, dtype=np.float64)
+    if xi_h.ndim != 2 or xi_h.shape[1] != d or w_h.shape != (xi_h.shape[0],):
+        raise ValueError(f'sigma points must be (s, {d}) with (s,) weights; got {xi_h.shape}, {w_h.shape}')
+    key = (torch.cuda.current_device(), nonlinear_coord, xi_h.shape, xi_h.tobytes(), w_h.tobytes())
+    hit = _sigma_cache.get(key)
+    if hit is None:
+        gs = None
+        if nonlinear_coord is not None:
+            v = int(nonlinear_coord)
+            prefix = xi_h[:, :v + 1] + 0.0          # exact grouping (-0.0 folded into +0.0)
+            _, inverse = np.unique(prefix, axis=0, return_inverse=True)
+            order = np.argsort(inverse.ravel(), kind='stable')
+            xi_h, w_h, inv = xi_h[order], w_h[order], inverse.ravel()[order]
+            starts = np.flatnonzero(np.r_[True, inv[1:] != inv[:-1], True]).astype(np.int32)
+            gs = torch.from_numpy(starts).cuda()
+        if len(_sigma_cache) >= 64:
+            _sigma_cache.clear()
+        hit = _sigma_cache[key] = (dev(xi_h), dev(w_h), gs)
+    xi, w, gs = hit
+    keep += [xi, w, gs]
+    return CgpSigma(int(xi.shape[0]), int(d), _ptr(xi), _ptr(w), _ptr(gs), int(gs.numel() - 1) if gs is not None else 0)
+
+
+def _nonlinear_coord(spec):
+    """State coordinate the model is nonlinear in (chirp / harmonic / La Scala models: d - 2), None for linear models."""
+    return int(spec.d) - 2 if int(spec.model_id) in (M_HARMONIC_LCD, M_LASCALA_LCD, M_HARMONIC_SDE) else None
 
 
 def _out(t, like_numpy, squeeze):
@@ -233,7 +262,7 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     ctx = context(ys_d.device.index)
     keep = [ys_d]
     model = _model_struct(spec, gamma, B, keep)
-    sig = _sigma_struct(sgps, d, keep)
+    sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
     init = CgpInit()
     if H is not None:
         Ht, init.H_stride = _batched_operand(H, 1, B, 'H')
@@ -281,7 +310,7 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
     ctx = context(m.device.index)
     keep = [m, P]
     model = _model_struct(spec, gamma, B, keep)
-    sig = _sigma_struct(sgps, d, keep)
+    sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
     mss, Pss = torch.empty_like(m), torch.empty_like(P)
     lib, st = load_library(), _stream()
     rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,

@@ -47,6 +47,7 @@ static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sig
     if (need_sigma) {
         if (!sg || !sg->xi || !sg->w || sg->s < 1) return fail(ctx, CGP_E_ARG, "sigma-point methods need a cgp_sigma");
         if (sg->d != m->d) return fail(ctx, CGP_E_ARG, "cgp_sigma.d != model.d");
+        if (sg->group_start && (sg->n_groups < 1 || sg->n_groups > sg->s)) return fail(ctx, CGP_E_ARG, "cgp_sigma.n_groups outside 1..s");
     }
     return CGP_OK;
 }
@@ -57,6 +58,8 @@ static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt) 
     a.gamma = m->gamma; a.gamma_stride = m->gamma_stride;
     a.model_id = m->model_id;
     a.sg.xi = sg ? sg->xi : nullptr; a.sg.w = sg ? sg->w : nullptr; a.sg.s = sg ? sg->s : 0;
+    a.sg.group_start = sg ? sg->group_start : nullptr; a.sg.n_groups = (sg && sg->group_start) ? sg->n_groups : 0;
+    a.sg.lds_xi = nullptr; a.sg.lds_w = nullptr; a.sg.lds_gs = nullptr; a.sg.staged = false;
     a.dt = dt;
     return a;
 }
@@ -86,6 +89,18 @@ __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* _
         }
         o0[i] = a;
         if (o1) o1[i] = b;
+    }
+}
+
+// The wave-uniform variants: one input element per wavefront (all 64 lanes evaluate the same argument).
+__global__ void __launch_bounds__(64) debug_math_uniform_kernel(int op, const double* __restrict__ x, int64_t n,
+                                                                double* __restrict__ o0, double* __restrict__ o1) {
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const double v = x[i];
+        double a, b;
+        if (op == 5) softplus_pair_uniform(v, a, b);
+        else fast_sincos_uniform(v, a, b);
+        if (threadIdx.x == 0) { o0[i] = a; if (o1) o1[i] = b; }
     }
 }
 
@@ -207,12 +222,13 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
 
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream) {
     if (!ctx) return CGP_E_ARG;
-    if (n < 0 || op < 0 || op > 4) return fail(ctx, CGP_E_ARG, "bad op or n");
+    if (n < 0 || op < 0 || op > 6) return fail(ctx, CGP_E_ARG, "bad op or n");
     if (n == 0) return CGP_OK;
     if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, op, x, n, out0, out1);
+    if (op >= 5) hipLaunchKernelGGL(debug_math_uniform_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), 0, (hipStream_t)stream, op, x, n, out0, out1);
+    else hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, op, x, n, out0, out1);
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
 }
 

@@ -102,10 +102,10 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
             const double y = readlane_f64(ychunk, slot);
             // ---- replicated scalar chain: rotation of the chirp block at frequency g(u2) (models.py:296-301) and N1
             double sp, dsp;
-            softplus_pair(u2, sp, dsp);
+            softplus_pair_uniform(u2, sp, dsp);
             const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
             double s1, c1;
-            fast_sincos(dt * w, s1, c1);
+            fast_sincos_uniform(dt * w, s1, c1);
             const double c = c1 * rho, s = s1 * rho;
             const double f0 = fma(c, u0, -s * u1), f1 = fma(s, u0, c * u1);
             const double f2 = fma(M0, u2, M1 * u3), f3 = fma(M2, u2, M3 * u3);

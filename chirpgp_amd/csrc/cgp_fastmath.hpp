@@ -140,6 +140,92 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     cs = ((q + 1) & 2) ? -b : b;
 }
 
+// exp(x) without the overflow / underflow / NaN handling, for arguments known to lie in (-700, 700).
+CGP_DEV double fast_exp_core(double x) {
+    const double k = __builtin_rint(x * kLog2e);
+    double r = fma(-k, kLn2Hi, x);
+    r = fma(-k, kLn2Lo, r);
+    double p = 1.0 / 6227020800.0;
+    p = horner(p, r, 1.0 / 479001600.0);
+    p = horner(p, r, 1.0 / 39916800.0);
+    p = horner(p, r, 1.0 / 3628800.0);
+    p = horner(p, r, 1.0 / 362880.0);
+    p = horner(p, r, 1.0 / 40320.0);
+    p = horner(p, r, 1.0 / 5040.0);
+    p = horner(p, r, 1.0 / 720.0);
+    p = horner(p, r, 1.0 / 120.0);
+    p = horner(p, r, 1.0 / 24.0);
+    p = horner(p, r, 1.0 / 6.0);
+    p = horner(p, r, 0.5);
+    p = horner(p, r, 1.0);
+    p = horner(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
+// sin / cos for a WAVE-UNIFORM argument: the fallback test is one scalar compare on the exponent bits.
+CGP_DEV void fast_sincos_uniform(double x, double& sn, double& cs) {
+    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffff;
+    if (hx >= 0x40F86A00) {            // |x| >= 1e5, inf, NaN
+        sincos(x, &sn, &cs);
+        return;
+    }
+    const double n = __builtin_rint(x * kTwoOverPi);
+    double r = fma(-n, kPio2_1, x);
+    r = fma(-n, kPio2_2, r);
+    r = fma(-n, kPio2_3, r);
+    const double r2 = r * r;
+    double ps = -1.0 / 355687428096000.0;
+    ps = horner(ps, r2, 1.0 / 1307674368000.0);
+    ps = horner(ps, r2, -1.0 / 6227020800.0);
+    ps = horner(ps, r2, 1.0 / 39916800.0);
+    ps = horner(ps, r2, -1.0 / 362880.0);
+    ps = horner(ps, r2, 1.0 / 5040.0);
+    ps = horner(ps, r2, -1.0 / 120.0);
+    ps = horner(ps, r2, 1.0 / 6.0);
+    double pc = 1.0 / 20922789888000.0;
+    pc = horner(pc, r2, -1.0 / 87178291200.0);
+    pc = horner(pc, r2, 1.0 / 479001600.0);
+    pc = horner(pc, r2, -1.0 / 3628800.0);
+    pc = horner(pc, r2, 1.0 / 40320.0);
+    pc = horner(pc, r2, -1.0 / 720.0);
+    pc = horner(pc, r2, 1.0 / 24.0);
+    const double s0 = fma(-(r * r2), ps, r);
+    const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+    // quadrant: swap by selects, signs by flipping the sign bit with a wave-uniform mask
+    const int q = __builtin_amdgcn_readfirstlane((int)n);
+    const bool swap = (q & 1) != 0;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    const int sa = (q & 2) << 30, sb = ((q + 1) & 2) << 30;
+    sn = __hiloint2double(__double2hiint(a) ^ sa, __double2loint(a));
+    cs = __hiloint2double(__double2hiint(b) ^ sb, __double2loint(b));
+}
+
+// softplus log(exp(x) + 1) and its derivative exp(x) / (exp(x) + 1) for a WAVE-UNIFORM x (one scalar branch).
+// For 6 <= x < 700 -- every frequency above g(6) = 6.0025 Hz -- it uses the algebraically identical
+//     log(exp(x) + 1) = x + log1p(t),  exp(x) / (exp(x) + 1) = 1 / (1 + t),  t = exp(-x) <= 2.5e-3,
+// with the 6-term series of log1p (truncation t^7 / 7 < 1e-19): one exp and one reciprocal instead of exp, a full
+// log and a reciprocal.  Both forms are within an ulp or two of the exact value; elsewhere (and for inf / NaN) the
+// naive form of models.py:50 is evaluated as is, overflow behaviour included.
+CGP_DEV void softplus_pair_uniform(double x, double& sp, double& dsp) {
+    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    if (hx >= 0x40180000 && hx < 0x4085E000) {           // 6.0 <= x < 700.0 (positive doubles order like their bits)
+        const double t = fast_exp_core(-x);
+        double p = -1.0 / 6.0;
+        p = horner(p, t, 0.2);
+        p = horner(p, t, -0.25);
+        p = horner(p, t, 1.0 / 3.0);
+        p = horner(p, t, -0.5);
+        p = horner(p, t, 1.0);
+        sp = fma(p, t, x);
+        dsp = rcp_nr(1.0 + t);
+        return;
+    }
+    const double e = fast_exp(x);
+    const double z = e + 1.0;
+    sp = fast_log_ge1(z);
+    dsp = e * rcp_nr(z);
+}
+
 // Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of
 // jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)) (filters_smoothers.py:44-45, 68).
 CGP_DEV double nll_increment(double S, double innov) {

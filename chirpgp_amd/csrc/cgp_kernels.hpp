@@ -64,6 +64,8 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
 
     Pred pred;
     pred.setup(ma, trial);
+    __shared__ double sigbuf[Pred::USES_SIGMA ? kSigLdsDoubles : 1];
+    if constexpr (Pred::USES_SIGMA && WAVE) pred.sg.stage(sigbuf, lane, 64, D);
     Vec<D> H, mf;
     Sym<D> Pf;
     if (io.H) load_vec<D>(io.H + trial * io.H_stride, H);
@@ -147,6 +149,8 @@ __global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs m
 
     Step step;
     step.setup(ma, trial);
+    __shared__ double sigbuf[Step::USES_SIGMA ? kSigLdsDoubles : 1];
+    if constexpr (Step::USES_SIGMA && WAVE) step.sg.stage(sigbuf, lane, 64, D);
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
@@ -186,6 +190,8 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
 
     Elem elem;
     elem.setup(ma, trial);
+    __shared__ double sigbuf[Elem::USES_SIGMA ? kSigLdsDoubles : 1];
+    if constexpr (Elem::USES_SIGMA) elem.sg.stage(sigbuf, lane, 64, D);
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;

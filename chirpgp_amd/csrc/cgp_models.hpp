@@ -44,6 +44,11 @@ template <int D_> struct LinearDisc {
         load_mat<D>(p, F);
         load_sym<D>(p + D * D, Sigma);
     }
+    // sigma-point interface: nothing to share between the points of a group
+    static constexpr int IVC = 0;
+    struct Pre {};
+    CGP_DEV void precompute(double, Pre&) const {}
+    CGP_DEV void mean_pre(const Vec<D>& u, const Pre&, Vec<D>& f) const { matvec<D>(F, u, f); }
     CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const { matvec<D>(F, u, f); }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
         matvec<D>(F, u, f);
@@ -89,16 +94,22 @@ template <int NH> struct HarmonicLCD {
             c[k] = ck * rho; s[k] = sk * rho;
         }
     }
-    CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const {
-        const double w = (kTwoPi * softplus(u.v[IV])) * fs;
-        double c[NH], s[NH];
-        rotations(w, c, s);
+    // sigma-point interface: the rotations depend on u_v only, so points that share chi_v share them
+    static constexpr int IVC = IV;
+    struct Pre { double c[NH], s[NH]; };
+    CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus(uv)) * fs, p.c, p.s); }
+    CGP_DEV void mean_pre(const Vec<D>& u, const Pre& p, Vec<D>& f) const {
         CGP_UNROLL for (int k = 0; k < NH; k++) {
-            f.v[2 * k] = c[k] * u.v[2 * k] - s[k] * u.v[2 * k + 1];
-            f.v[2 * k + 1] = s[k] * u.v[2 * k] + c[k] * u.v[2 * k + 1];
+            f.v[2 * k] = p.c[k] * u.v[2 * k] - p.s[k] * u.v[2 * k + 1];
+            f.v[2 * k + 1] = p.s[k] * u.v[2 * k] + p.c[k] * u.v[2 * k + 1];
         }
         f.v[IV] = M[0] * u.v[IV] + M[1] * u.v[IV + 1];
         f.v[IV + 1] = M[2] * u.v[IV] + M[3] * u.v[IV + 1];
+    }
+    CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const {
+        Pre p;
+        precompute(u.v[IV], p);
+        mean_pre(u, p, f);
     }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
         double sp, dsp;
@@ -156,6 +167,10 @@ template <int D_> struct LinearSDE {
     static constexpr int D = D_;
     Mat<D> A;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { load_mat<D>(p, A); }
+    static constexpr int IVC = 0;
+    struct Pre {};
+    CGP_DEV void precompute(double, Pre&) const {}
+    CGP_DEV void drift_pre(const Vec<D>& u, const Pre&, Vec<D>& a) const { matvec<D>(A, u, a); }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const { matvec<D>(A, u, a); }
     CGP_DEV void drift_jp(const Vec<D>& u, const Sym<D>& P, Vec<D>& a, Mat<D>& T) const {
         matvec<D>(A, u, a);
@@ -171,8 +186,16 @@ template <int NH> struct HarmonicSDE {
     static constexpr int IV = D - 2;
     double lam, gam, fs;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { lam = p[0]; gam = sqrt(3.0) / p[1]; fs = p[2]; }
+    static constexpr int IVC = IV;
+    struct Pre { double w; };
+    CGP_DEV void precompute(double uv, Pre& p) const { p.w = (kTwoPi * softplus(uv)) * fs; }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
-        const double w = (kTwoPi * softplus(u.v[IV])) * fs;
+        Pre p;
+        precompute(u.v[IV], p);
+        drift_pre(u, p, a);
+    }
+    CGP_DEV void drift_pre(const Vec<D>& u, const Pre& p, Vec<D>& a) const {
+        const double w = p.w;
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             const double wk = w * (double)(k + 1);
             a.v[2 * k] = -lam * u.v[2 * k] - wk * u.v[2 * k + 1];

@@ -16,40 +16,76 @@ constexpr int kRedChunk = 32;          // values reduced per LDS pass
 constexpr int kRedLd = 66;             // row pitch in doubles: 64 lanes + 16 B pad (conflict-free ds_read_b128 across rows)
 constexpr int kFanLdsDoubles = kRedChunk * kRedLd + kRedChunk;
 
+// Sigma-point set.  The kernels stage it in LDS once per workgroup when it fits (kSigLdsDoubles): the fan re-reads the
+// points every time step, and a global (L2) load on the T-serial chain costs ~500 cycles against ~100 for LDS.
+constexpr int kSigLdsDoubles = 2048;
 struct SigmaSet {
-    const double* __restrict__ xi;     // [s][d]
-    const double* __restrict__ w;      // [s]
-    int s;
+    const double* __restrict__ xi;          // [s][d]   (global)
+    const double* __restrict__ w;           // [s]
+    const int* __restrict__ group_start;    // [n_groups + 1] or nullptr (every point its own group)
+    int s, n_groups;
+    const double* lds_xi;                   // LDS copies (valid when staged)
+    const double* lds_w;
+    const int* lds_gs;
+    bool staged;
+    CGP_DEV int groups() const { return group_start ? n_groups : s; }
+    CGP_DEV int begin(int g) const { if (!group_start) return g; return staged ? lds_gs[g] : group_start[g]; }
+    CGP_DEV int end(int g) const { if (!group_start) return g + 1; return staged ? lds_gs[g + 1] : group_start[g + 1]; }
+    CGP_DEV double weight(int p) const { return staged ? lds_w[p] : w[p]; }
+    CGP_DEV double coord(int idx) const { return staged ? lds_xi[idx] : xi[idx]; }
+    // Cooperative copy into `buf` (kSigLdsDoubles doubles of LDS); all `nthreads` threads of the block must call it.
+    CGP_DEV void stage(double* buf, int tid, int nthreads, int d) {
+        staged = false;
+        const int nxi = s * d, ngs = group_start ? n_groups + 1 : 0;
+        if (xi == nullptr || nxi + s + (ngs + 1) / 2 > kSigLdsDoubles) return;
+        for (int i = tid; i < nxi; i += nthreads) buf[i] = xi[i];
+        for (int i = tid; i < s; i += nthreads) buf[nxi + i] = w[i];
+        int* gs = reinterpret_cast<int*>(buf + nxi + s);
+        for (int i = tid; i < ngs; i += nthreads) gs[i] = group_start[i];
+        __syncthreads();
+        lds_xi = buf; lds_w = buf + nxi; lds_gs = gs;
+        staged = true;
+    }
 };
 
-// All-lane sum of R per-lane partials through LDS: every lane ends with bitwise-identical totals
-// (rows are summed in lane order by one lane each, then re-read by all).
+// All-lane sum of R per-lane partials through LDS: every lane ends with bitwise-identical totals.
+// The workgroup IS one wavefront, whose DS instructions execute in order, so no s_barrier is needed between the
+// phases -- only a wavefront-scope fence that keeps the compiler from reordering the LDS accesses.
+// Pass of up to 16 values: lane (r, q) = (lane >> 2, lane & 3) sums one quarter (16 lanes' worth, read as eight
+// 16-byte pairs) of row r, the four quarters meet with two cross-lane steps, lane q == 0 publishes the total and every
+// lane reads the totals back (broadcast reads).  Idle lanes contribute zeros; the summation order is fixed.
+constexpr int kRedPass = 16;
+CGP_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 template <int R>
-CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int nl) {
+CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int /*nl*/) {
     double* tot = lds + kRedChunk * kRedLd;
-    CGP_UNROLL for (int base = 0; base < R; base += kRedChunk) {
-        constexpr int dummy = 0; (void)dummy;
-        const int n = (R - base < kRedChunk) ? (R - base) : kRedChunk;
-        CGP_UNROLL for (int r = 0; r < kRedChunk; r++)
-            if (base + r < R) lds[r * kRedLd + lane] = acc[base + r];
-        __syncthreads();
-        if (lane < n) {
-            const double* row = lds + lane * kRedLd;
-            double s = row[0];
-            for (int j = 1; j < nl; j++) s += row[j];
-            tot[lane] = s;
+    const int r = lane >> 2, q = lane & 3;
+    CGP_UNROLL for (int base = 0; base < R; base += kRedPass) {
+        CGP_UNROLL for (int k = 0; k < kRedPass; k++)
+            if (base + k < R) lds[k * kRedLd + lane] = acc[base + k];
+        wave_lds_fence();
+        const double2* row = reinterpret_cast<const double2*>(lds + r * kRedLd + q * 16);
+        double s = 0.0;
+        if (base + r < R) {
+            CGP_UNROLL for (int j = 0; j < 8; j++) { const double2 v = row[j]; s += v.x; s += v.y; }
         }
-        __syncthreads();
-        CGP_UNROLL for (int r = 0; r < kRedChunk; r++)
-            if (base + r < R) acc[base + r] = tot[r];
-        __syncthreads();
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (q == 0) tot[r] = s;
+        wave_lds_fence();
+        CGP_UNROLL for (int k = 0; k < kRedPass; k++)
+            if (base + k < R) acc[base + k] = tot[k];
+        wave_lds_fence();
     }
 }
 
 // chi = m + L xi_p   (quadratures.py:198-201), L lower-triangular packed.
-template <int D> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, const double* __restrict__ xi, Vec<D>& chi) {
+template <int D> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, const SigmaSet& sg, int p, Vec<D>& chi) {
     double x[D];
-    CGP_UNROLL for (int j = 0; j < D; j++) x[j] = xi[j];
+    CGP_UNROLL for (int j = 0; j < D; j++) x[j] = sg.coord(p * D + j);
     CGP_UNROLL for (int i = 0; i < D; i++) {
         double t = L(i, 0) * x[0];
         CGP_UNROLL for (int j = 1; j <= i; j++) t = fma(L(i, j), x[j], t);
@@ -69,24 +105,35 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
     cholesky<D>(Pf, L, inv);
     double acc[R];
     CGP_UNROLL for (int r = 0; r < R; r++) acc[r] = 0.0;
-    const int step = WAVE ? 64 : 1;
-    for (int p = WAVE ? lane : 0; p < sg.s; p += step) {
+    // Fan over groups of points that share chi_v (the coordinate the model is nonlinear in): one lane per group in the
+    // wave shape, a serial loop otherwise; the model's transcendental part runs once per group.
+    const int step = WAVE ? 64 : 1, ng = sg.groups();
+    for (int g = WAVE ? lane : 0; g < ng; g += step) {
+        int p = sg.begin(g);
+        const int pe = sg.end(g);
         Vec<D> chi, f;
-        sigma_point<D>(mf, L, sg.xi + (size_t)p * D, chi);
-        model.mean(chi, f);
-        const double w = sg.w[p];
-        acc[0] += w;
-        CGP_UNROLL for (int i = 0; i < D; i++) acc[1 + i] = fma(w, f.v[i], acc[1 + i]);
-        CGP_UNROLL for (int i = 0; i < D; i++)
-            CGP_UNROLL for (int j = 0; j <= i; j++)
-                acc[1 + D + Sym<D>::idx(i, j)] = fma(w, f.v[i] * f.v[j], acc[1 + D + Sym<D>::idx(i, j)]);
-        if (CROSS) {
+        sigma_point<D>(mf, L, sg, p, chi);
+        typename DM::Pre pre;
+        model.precompute(chi.v[DM::IVC], pre);
+        for (;;) {
+            model.mean_pre(chi, pre, f);
+            const double w = sg.weight(p);
+            acc[0] += w;
+            double wf[D];
+            CGP_UNROLL for (int i = 0; i < D; i++) { wf[i] = w * f.v[i]; acc[1 + i] += wf[i]; }
             CGP_UNROLL for (int i = 0; i < D; i++)
-                CGP_UNROLL for (int j = 0; j < D; j++)
-                    acc[1 + D + NS + i * D + j] = fma(w, chi.v[i] * f.v[j], acc[1 + D + NS + i * D + j]);
+                CGP_UNROLL for (int j = 0; j <= i; j++)
+                    acc[1 + D + Sym<D>::idx(i, j)] = fma(wf[i], f.v[j], acc[1 + D + Sym<D>::idx(i, j)]);
+            if (CROSS) {
+                CGP_UNROLL for (int i = 0; i < D; i++)
+                    CGP_UNROLL for (int j = 0; j < D; j++)
+                        acc[1 + D + NS + i * D + j] = fma(chi.v[i], wf[j], acc[1 + D + NS + i * D + j]);
+            }
+            if (++p >= pe) break;
+            sigma_point<D>(mf, L, sg, p, chi);
         }
     }
-    if (WAVE) wave_allreduce<R>(acc, lds, lane, sg.s < 64 ? sg.s : 64);
+    if (WAVE) wave_allreduce<R>(acc, lds, lane, ng < 64 ? ng : 64);
     CGP_UNROLL for (int i = 0; i < D; i++) mp.v[i] = acc[1 + i];
     // Pp = E[f f^T + Sigma] - mp mp^T ; E[Sigma] = (sum_i w_i) Sigma since Sigma does not depend on the point (N3)
     CGP_UNROLL for (int i = 0; i < NS; i++) Pp.a[i] = acc[1 + D + i];
@@ -110,19 +157,28 @@ CGP_DEV void cd_sgp_common(const SM& model, const SigmaSet& sg, int lane, double
     cholesky<D>(P, L, inv);
     double acc[R];
     CGP_UNROLL for (int r = 0; r < R; r++) acc[r] = 0.0;
-    const int step = WAVE ? 64 : 1;
-    for (int p = WAVE ? lane : 0; p < sg.s; p += step) {
+    const int step = WAVE ? 64 : 1, ng = sg.groups();
+    for (int g = WAVE ? lane : 0; g < ng; g += step) {
+        int p = sg.begin(g);
+        const int pe = sg.end(g);
         Vec<D> chi, a;
-        sigma_point<D>(m, L, sg.xi + (size_t)p * D, chi);
-        model.drift(chi, a);
-        const double w = sg.w[p];
-        CGP_UNROLL for (int i = 0; i < D; i++) acc[i] = fma(w, a.v[i], acc[i]);
-        CGP_UNROLL for (int i = 0; i < D; i++) {
-            const double ci = chi.v[i] - m.v[i];
-            CGP_UNROLL for (int j = 0; j < D; j++) acc[D + i * D + j] = fma(w, ci * a.v[j], acc[D + i * D + j]);
+        sigma_point<D>(m, L, sg, p, chi);
+        typename SM::Pre pre;
+        model.precompute(chi.v[SM::IVC], pre);
+        for (;;) {
+            model.drift_pre(chi, pre, a);
+            const double w = sg.weight(p);
+            double wa[D];
+            CGP_UNROLL for (int i = 0; i < D; i++) { wa[i] = w * a.v[i]; acc[i] += wa[i]; }
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                const double ci = chi.v[i] - m.v[i];
+                CGP_UNROLL for (int j = 0; j < D; j++) acc[D + i * D + j] = fma(ci, wa[j], acc[D + i * D + j]);
+            }
+            if (++p >= pe) break;
+            sigma_point<D>(m, L, sg, p, chi);
         }
     }
-    if (WAVE) wave_allreduce<R>(acc, lds, lane, sg.s < 64 ? sg.s : 64);
+    if (WAVE) wave_allreduce<R>(acc, lds, lane, ng < 64 ? ng : 64);
     CGP_UNROLL for (int i = 0; i < D; i++) dm.v[i] = acc[i];
     CGP_UNROLL for (int i = 0; i < D; i++)
         CGP_UNROLL for (int j = 0; j <= i; j++) dP(i, j) = (acc[D + i * D + j] + acc[D + j * D + i]) + gamma(i, j);
@@ -162,6 +218,7 @@ struct ModelArgs {
 
 // ekf (filters_smoothers.py:251-261) and, with a linear model, kf (:174-181)
 template <class DM, bool WAVE_> struct EkfPredict {
+    static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
@@ -173,6 +230,7 @@ template <class DM, bool WAVE_> struct EkfPredict {
 
 // sgp_filter (filters_smoothers.py:480-487)
 template <class DM, bool WAVE_> struct SgpPredict {
+    static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
@@ -184,6 +242,7 @@ template <class DM, bool WAVE_> struct SgpPredict {
 
 // cd_ekf (filters_smoothers.py:384-394): dm = a(m), dP = P J^T + J P + gamma
 template <class SM, bool WAVE_> struct CdEkfPredict {
+    static constexpr bool USES_SIGMA = false;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
@@ -203,6 +262,7 @@ template <class SM, bool WAVE_> struct CdEkfPredict {
 
 // cd_sgp_filter (filters_smoothers.py:569-579)
 template <class SM, bool WAVE_> struct CdSgpPredict {
+    static constexpr bool USES_SIGMA = true;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     SM model; Sym<D> gamma; SigmaSet sg; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
@@ -223,6 +283,7 @@ template <class SM, bool WAVE_> struct CdSgpPredict {
 
 // eks (filters_smoothers.py:338-346) and, with a linear model, rts (:208-216)
 template <class DM, bool WAVE_> struct EksStep {
+    static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
@@ -236,6 +297,7 @@ template <class DM, bool WAVE_> struct EksStep {
 
 // sgp_smoother (filters_smoothers.py:520-528)
 template <class DM, bool WAVE_> struct SgpsStep {
+    static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
@@ -259,6 +321,7 @@ template <int D> CGP_DEV void pinv_gamma(const Sym<D>& Pf, const Sym<D>& gamma, 
 
 // cd_eks (filters_smoothers.py:423-438), dt negated
 template <class SM, bool WAVE_> struct CdEksStep {
+    static constexpr bool USES_SIGMA = false;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
@@ -286,6 +349,7 @@ template <class SM, bool WAVE_> struct CdEksStep {
 
 // cd_sgp_smoother (filters_smoothers.py:611-629)
 template <class SM, bool WAVE_> struct CdSgpsStep {
+    static constexpr bool USES_SIGMA = true;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     SM model; Sym<D> gamma; SigmaSet sg; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
@@ -394,6 +458,7 @@ CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps
 
 // Per-lane element producers (one lane = one time step, so the fan of the sigma-point variant is a serial loop).
 template <class DM> struct EksElement {
+    static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
@@ -404,6 +469,7 @@ template <class DM> struct EksElement {
     }
 };
 template <class DM> struct SgpsElement {
+    static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }

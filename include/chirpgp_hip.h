@@ -95,12 +95,19 @@ typedef struct cgp_model {
     int64_t       gamma_stride;  /* 0 = shared                                        */
 } cgp_model;
 
-/* Sigma points (quadratures.py:84-231): chi_i = m + chol(P) xi_i, E[z] ~ sum_i w_i z(chi_i). */
+/* Sigma points (quadratures.py:84-231): chi_i = m + chol(P) xi_i, E[z] ~ sum_i w_i z(chi_i).
+ * Optional grouping: the chirp models are nonlinear in ONE state coordinate v = d - 2 only, and with a lower-triangular
+ * chol(P) the point's chi_v depends on xi[0..v] alone (27 distinct arguments among the 81 Gauss-Hermite
+ * points of d = 4).  If the caller orders the points so that points with equal xi[0..v] are contiguous and passes the
+ * n_groups + 1 range boundaries in group_start, the kernels evaluate the transcendental part once per group.
+ * group_start == NULL: every point is its own group.  The order of the points only changes the summation order. */
 typedef struct cgp_sigma {
-    int32_t       s;             /* number of points         */
-    int32_t       d;
-    const double* xi;            /* [s][d]                    */
-    const double* w;             /* [s]                       */
+    int32_t        s;             /* number of points                         */
+    int32_t        d;
+    const double*  xi;            /* [s][d]                                    */
+    const double*  w;             /* [s]                                       */
+    const int32_t* group_start;   /* [n_groups + 1] (device pointer) or NULL   */
+    int32_t        n_groups;      /* ignored when group_start is NULL          */
 } cgp_sigma;
 
 /* Measurement model and initial condition of a filter. */
@@ -146,7 +153,8 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
 
 /* Test hook: evaluates one of the engine's in-kernel float64 elementary functions (csrc/cgp_fastmath.hpp) on n inputs.
  * op: 0 exp, 1 log on [1, inf] (softplus argument), 2 sincos (out0 = sin, out1 = cos), 3 reciprocal,
- *     4 softplus pair (out0 = log(exp(x) + 1), out1 = its derivative).  out1 may be NULL for one-output ops. */
+ *     4 softplus pair (out0 = log(exp(x) + 1), out1 = its derivative), 5 / 6 the wave-uniform variants of 4 / 2.
+ *     out1 may be NULL for one-output ops. */
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ class _Model(C.Structure):
 
 
 class _Sigma(C.Structure):
-    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _dp), ('w', _dp)]
+    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _dp), ('w', _dp), ('group_start', C.c_void_p), ('n_groups', C.c_int32)]
 
 
 class _Init(C.Structure):
@@ -85,7 +85,7 @@ def _sigma_struct(sigma, keep):
         return None
     xi, w = _arr(sigma.xi), _arr(sigma.w)
     keep += [xi, w]
-    return _Sigma(int(xi.shape[0]), int(xi.shape[1]), _p(xi), _p(w))
+    return _Sigma(int(xi.shape[0]), int(xi.shape[1]), _p(xi), _p(w), None, 0)
 
 
 def _strided(x, base_ndim, keep):

@@ -34,7 +34,7 @@ def test_header_symbols_are_exported():
 def test_struct_layouts_match_header():
     _, eng = _lib()
     assert ctypes.sizeof(eng.CgpModel) == 48
-    assert ctypes.sizeof(eng.CgpSigma) == 24
+    assert ctypes.sizeof(eng.CgpSigma) == 40
     assert ctypes.sizeof(eng.CgpInit) == 64
 
 

@@ -55,6 +55,39 @@ def test_log_ge1_and_softplus():
     assert np.max(np.abs(dsp[okd] - want_d[okd]) / np.maximum(want_d[okd], 1e-300)) < 1e-14
 
 
+def test_uniform_variants():
+    """The wave-uniform softplus (regime split at x = 6: x + log1p(exp(-x))) and sincos used by the cooperative EKF."""
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-30, 60, 1500), rng.uniform(5.9, 6.1, 200), rng.uniform(690, 712, 100),
+                        [6., 5.999999999, 7., 36., 37., 699.99, 700., 708., 710., 800., -800., np.inf, -np.inf, np.nan]])
+    sp, dsp = E.debug_math(5, x)
+    with np.errstate(over='ignore', invalid='ignore'):
+        e = np.exp(x)
+        ref_sp, ref_d = np.log(e + 1.), e / (e + 1.)
+    assert np.array_equal(np.isnan(dsp), np.isnan(ref_d)) and np.array_equal(np.isinf(sp), np.isinf(ref_sp))
+    assert np.array_equal(np.isnan(sp), np.isnan(ref_sp))
+    # against the naive form as NumPy evaluates it (for very negative x the naive form itself is inaccurate: models.py:50)
+    fin = np.isfinite(ref_sp) & np.isfinite(x) & (ref_sp > 0)
+    # (a 1-ulp difference in exp(x) moves 1 + exp(x) by an ulp of 1, i.e. log(.) by 2e-16 / sp relative: 1e-13 bound)
+    assert np.max(np.abs(sp[fin] - ref_sp[fin]) / ref_sp[fin]) < 1e-13
+    okd = fin & np.isfinite(ref_d)
+    assert np.max(np.abs(dsp[okd] - ref_d[okd]) / ref_d[okd]) < 1e-14
+    # and against the exact value where the naive form is accurate (x >= 0), which covers the regime-split branch
+    pos = fin & (x >= 0)
+    assert _ulp_err(sp[pos], [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in x[pos]]) < 1e-15
+    posd = okd & (x >= 0)
+    assert _ulp_err(dsp[posd], [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x[posd]]) < 1e-15
+    xs = np.concatenate([rng.uniform(-10, 10, 1500), rng.uniform(-9e4, 9e4, 500), [0., 0.044, 99999.9, 1.0e5, 3.3e7, np.inf, np.nan]])
+    sn, cs = E.debug_math(6, xs)
+    f = np.isfinite(xs)
+    assert max(abs(float(mp.mpf(float(g)) - mp.sin(mp.mpf(float(v))))) for g, v in zip(sn[f], xs[f])) < 3e-16
+    assert max(abs(float(mp.mpf(float(g)) - mp.cos(mp.mpf(float(v))))) for g, v in zip(cs[f], xs[f])) < 3e-16
+    assert np.all(np.isnan(sn[~f])) and np.all(np.isnan(cs[~f]))
+
+
 def test_sincos():
     import mpmath as mp
     from chirpgp_amd import _engine as E
