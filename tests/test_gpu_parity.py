@@ -260,3 +260,36 @@ def test_full_size_properties_and_parity():
     for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
         cs.assert_close(g.cpu().numpy(), w, RTOL, f'full.{n}')
         print(n, f'{cs.max_rel_err(g.cpu().numpy(), w):.2e}')
+
+
+def test_mle_through_the_filter():
+    """'Next' row 8f-1: L-BFGS-B on the engine's batched NLL-only objective (value + central differences = one launch).
+    The batched objective must equal the filter's own last cumulative NLL, its gradient must match a finer difference
+    quotient, and the fit must lower the NLL and give a sane frequency RMSE on the toy chirp (demos/ekfs_mle.py)."""
+    from chirpgp_amd import mle, models as pm
+    from chirpgp_amd.quadratures import gaussian_expectation
+    from chirpgp_amd.toymodels import gen_chirp, meow_freq, constant_mag
+    from chirpgp_amd.tools import rmse
+    fs = _fs()
+    dt, T, Xi = 1e-3, 3141, 0.1
+    ts = np.linspace(dt, dt * T, T)
+    freq, phase = meow_freq(offset=8.)
+    ys = gen_chirp(ts, constant_mag(1.), phase) + np.sqrt(Xi) * np.random.default_rng(555).standard_normal(T)
+    init = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
+    fun = mle.make_objective('ekf', pm.build_chirp_model, ys, Xi, dt)
+    f0, g0 = fun(pm.g_inv(init))
+    _, _, disc, m0, P0, H = pm.build_chirp_model(init)
+    npt.assert_allclose(f0, fs.ekf(disc, H, Xi, m0, P0, dt, ys)[2][-1], rtol=1e-10)
+    th = pm.g_inv(init)
+    for i in (0, 3, 5):
+        e = np.zeros(6)
+        e[i] = 1e-4
+        fd = (fun(th + e)[0] - fun(th - e)[0]) / 2e-4
+        npt.assert_allclose(g0[i], fd, rtol=1e-3, atol=1e-3)
+    opt, res = mle.fit('ekf', pm.build_chirp_model, init, ys, Xi, dt, maxiter=60)
+    assert res.fun < f0 - 1.0 and np.all(np.isfinite(opt)) and np.all(opt > 0)
+    _, _, disc, m0, P0, H = pm.build_chirp_model(opt)
+    mfs, Pfs, _ = fs.ekf(disc, H, Xi, m0, P0, dt, ys)
+    mss, Pss = fs.eks(disc, mfs, Pfs, dt)
+    est = gaussian_expectation(mss[:, 2], np.sqrt(Pss[:, 2, 2]), func=pm.g, force_shape=True)[:, 0]
+    assert rmse(freq(ts), est) < 3.0, rmse(freq(ts), est)
