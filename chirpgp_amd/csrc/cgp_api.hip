@@ -19,7 +19,9 @@ static int fail(cgp_ctx* ctx, int code, const std::string& msg) {
 
 // One wavefront per trial until the batch alone fills every SIMD several times over; beyond that one lane per trial
 // keeps all 64 lanes busy (the per-step work of a trial is far too small to split across lanes).
-static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags) {
+static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, const cgp_sigma* sg = nullptr) {
+    // the wave-per-trial shapes stage the sigma-point set in LDS; a set that does not fit runs one lane per trial
+    if (sg && SigmaSet::stage_bytes(sg->s, sg->d, sg->n_groups, sg->group_start != nullptr) > (size_t)kSigLdsMaxBytes) return false;
     if (flags & CGP_WAVE_PER_TRIAL) return true;
     if (flags & CGP_THREAD_PER_TRIAL) return false;
     const int64_t simds = (int64_t)(ctx ? ctx->num_cus : 256) * 4;
@@ -59,7 +61,7 @@ static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt) 
     a.model_id = m->model_id;
     a.sg.xi = sg ? sg->xi : nullptr; a.sg.w = sg ? sg->w : nullptr; a.sg.s = sg ? sg->s : 0;
     a.sg.group_start = sg ? sg->group_start : nullptr; a.sg.n_groups = (sg && sg->group_start) ? sg->n_groups : 0;
-    a.sg.lds_xi = nullptr; a.sg.lds_w = nullptr; a.sg.lds_gs = nullptr; a.sg.staged = false;
+    a.sg.lds_xi = 0; a.sg.lds_w = 0; a.sg.lds_gs = 0;
     a.dt = dt;
     return a;
 }
@@ -154,7 +156,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt);
-    const bool wave = choose_wave(ctx, B, flags);
+    const bool wave = choose_wave(ctx, B, flags, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;
@@ -192,7 +194,7 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt);
-    const bool wave = choose_wave(ctx, B, flags);
+    const bool wave = choose_wave(ctx, B, flags, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st); break;

@@ -35,6 +35,16 @@ struct SmootherIO {
     uint32_t flags;
 };
 
+// Dynamic LDS (sized by the launch): the staged sigma-point set.  The static LDS in front of it (the 17 152-byte
+// reduction buffer) is a multiple of 16 bytes, so the base stays 16-byte aligned (cdna_hip_programming.md G17).
+CGP_DEV double* dyn_lds() {
+    extern __shared__ double cgp_dyn_lds[];
+    return cgp_dyn_lds;
+}
+inline size_t sigma_lds_bytes(const ModelArgs& ma, int d) {
+    return ma.sg.xi ? SigmaSet::stage_bytes(ma.sg.s, d, ma.sg.n_groups, ma.sg.group_start != nullptr) : 0;
+}
+
 // Linear scalar measurement y = H x + noise (every filter but ekf_for_kpt).
 template <int D> struct LinearMeasurement {
     CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
@@ -64,8 +74,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
 
     Pred pred;
     pred.setup(ma, trial);
-    __shared__ double sigbuf[Pred::USES_SIGMA ? kSigLdsDoubles : 1];
-    if constexpr (Pred::USES_SIGMA && WAVE) pred.sg.stage(sigbuf, lane, 64, D);
+    if constexpr (Pred::USES_SIGMA && WAVE) pred.sg.stage(dyn_lds(), lane, 64, D);
     Vec<D> H, mf;
     Sym<D> Pf;
     if (io.H) load_vec<D>(io.H + trial * io.H_stride, H);
@@ -149,8 +158,7 @@ __global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs m
 
     Step step;
     step.setup(ma, trial);
-    __shared__ double sigbuf[Step::USES_SIGMA ? kSigLdsDoubles : 1];
-    if constexpr (Step::USES_SIGMA && WAVE) step.sg.stage(sigbuf, lane, 64, D);
+    if constexpr (Step::USES_SIGMA && WAVE) step.sg.stage(dyn_lds(), lane, 64, D);
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
@@ -190,8 +198,7 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
 
     Elem elem;
     elem.setup(ma, trial);
-    __shared__ double sigbuf[Elem::USES_SIGMA ? kSigLdsDoubles : 1];
-    if constexpr (Elem::USES_SIGMA) elem.sg.stage(sigbuf, lane, 64, D);
+    if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D);
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
@@ -238,7 +245,8 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
 template <class Elem>
 inline hipError_t launch_tp_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
-    hipLaunchKernelGGL((tp_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
+    hipLaunchKernelGGL((tp_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
     return hipGetLastError();
 }
 
@@ -246,14 +254,16 @@ template <class Pred, class Meas>
 inline hipError_t launch_filter(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
     const unsigned grid = Pred::WAVE ? (unsigned)io.B : (unsigned)((io.B + 63) / 64);
-    hipLaunchKernelGGL((filter_kernel<Pred, Meas>), dim3(grid), dim3(64), 0, stream, io, ma);
+    const size_t dyn = (Pred::USES_SIGMA && Pred::WAVE) ? sigma_lds_bytes(ma, Pred::D) : 0;
+    hipLaunchKernelGGL((filter_kernel<Pred, Meas>), dim3(grid), dim3(64), dyn, stream, io, ma);
     return hipGetLastError();
 }
 template <class Step>
 inline hipError_t launch_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
     const unsigned grid = Step::WAVE ? (unsigned)io.B : (unsigned)((io.B + 63) / 64);
-    hipLaunchKernelGGL((smoother_kernel<Step>), dim3(grid), dim3(64), 0, stream, io, ma);
+    const size_t dyn = (Step::USES_SIGMA && Step::WAVE) ? sigma_lds_bytes(ma, Step::D) : 0;
+    hipLaunchKernelGGL((smoother_kernel<Step>), dim3(grid), dim3(64), dyn, stream, io, ma);
     return hipGetLastError();
 }
 

@@ -24,6 +24,12 @@ CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
     dsp = e * rcp_nr(z);            // inf * NaN = NaN where the reference has inf / inf = NaN
 }
 CGP_DEV double softplus(double x) { return fast_log_ge1(fast_exp(x) + 1.0); }
+// `uniform` = the argument is the same in all lanes of the wavefront (a wave-per-trial kernel evaluating the model at the
+// trial's mean): one scalar branch then picks the cheap large-x form (cgp_fastmath.hpp).
+CGP_DEV void softplus_pair_sel(bool uniform, double x, double& sp, double& dsp) {
+    if (uniform) softplus_pair_uniform(x, sp, dsp);
+    else softplus_pair(x, sp, dsp);
+}
 
 // Closed-form Matern-3/2 discretisation, models.py:61-73.
 CGP_DEV void m32_solution(double ell, double sigma, double dt, double (&M)[4], double (&S)[3]) {
@@ -40,6 +46,7 @@ template <int D_> struct LinearDisc {
     static constexpr int D = D_;
     Mat<D> F;
     Sym<D> Sigma;
+    bool uniform = false;
     CGP_DEV void setup(const double* __restrict__ p, double /*dt*/, int /*model_id*/) {
         load_mat<D>(p, F);
         load_sym<D>(p + D * D, Sigma);
@@ -68,6 +75,7 @@ template <int NH> struct HarmonicLCD {
     static constexpr int IV = D - 2;
     double rho, q, fs, dt;
     double M[4], MS[3];
+    bool uniform = false;      // set by wave-per-trial EKF-type callers: propagate() then sees a wave-uniform state
     CGP_DEV void setup(const double* __restrict__ p, double dt_, int model_id) {
         dt = dt_;
         if (model_id == 2 /* CGP_M_LASCALA_LCD */) {
@@ -113,7 +121,7 @@ template <int NH> struct HarmonicLCD {
     }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
         double sp, dsp;
-        softplus_pair(u.v[IV], sp, dsp);
+        softplus_pair_sel(uniform, u.v[IV], sp, dsp);
         const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         double c[NH], s[NH], jv[2 * NH];
         rotations(w, c, s);
@@ -166,6 +174,7 @@ template <int NH> struct HarmonicLCD {
 template <int D_> struct LinearSDE {
     static constexpr int D = D_;
     Mat<D> A;
+    bool uniform = false;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { load_mat<D>(p, A); }
     static constexpr int IVC = 0;
     struct Pre {};
@@ -185,6 +194,7 @@ template <int NH> struct HarmonicSDE {
     static constexpr int D = 2 * NH + 2;
     static constexpr int IV = D - 2;
     double lam, gam, fs;
+    bool uniform = false;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { lam = p[0]; gam = sqrt(3.0) / p[1]; fs = p[2]; }
     static constexpr int IVC = IV;
     struct Pre { double w; };
@@ -207,7 +217,7 @@ template <int NH> struct HarmonicSDE {
     // a(u) and the non-trivial Jacobian pieces: wk[k] and the d/du_v column jv (N2)
     CGP_DEV void pieces(const Vec<D>& u, Vec<D>& a, double (&wk)[NH], double (&jv)[2 * NH]) const {
         double sp, dsp;
-        softplus_pair(u.v[IV], sp, dsp);
+        softplus_pair_sel(uniform, u.v[IV], sp, dsp);
         const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             wk[k] = w * (double)(k + 1);

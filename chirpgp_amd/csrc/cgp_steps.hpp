@@ -16,35 +16,51 @@ constexpr int kRedChunk = 32;          // values reduced per LDS pass
 constexpr int kRedLd = 66;             // row pitch in doubles: 64 lanes + 16 B pad (conflict-free ds_read_b128 across rows)
 constexpr int kFanLdsDoubles = kRedChunk * kRedLd + kRedChunk;
 
-// Sigma-point set.  The kernels stage it in LDS once per workgroup when it fits (kSigLdsDoubles): the fan re-reads the
-// points every time step, and a global (L2) load on the T-serial chain costs ~500 cycles against ~100 for LDS.
-constexpr int kSigLdsDoubles = 2048;
+// Sigma-point set.  The wave-per-trial kernels stage it in (dynamic) LDS once per workgroup: the fan re-reads the points
+// every time step, and a global (L2) load on the T-serial chain costs ~500 cycles against ~100 for LDS.  Whether a kernel
+// reads the staged copy is a compile-time property (template parameter ST of the accessors): the wave-per-trial shapes
+// always do -- the host routes sets that do not fit to the one-lane-per-trial kernels -- so no per-access branch exists.
+constexpr int kSigLdsMaxBytes = 44 * 1024;   // + 17 KB static reduction buffer < the 64 KB default LDS limit of a launch
+// LDS pointers carry their address space explicitly: the reads become ds_read_* (not flat_load with an aperture test).
+using LdsConstDoublePtr = const __attribute__((address_space(3))) double*;
+using LdsConstIntPtr = const __attribute__((address_space(3))) int*;
 struct SigmaSet {
     const double* __restrict__ xi;          // [s][d]   (global)
     const double* __restrict__ w;           // [s]
     const int* __restrict__ group_start;    // [n_groups + 1] or nullptr (every point its own group)
     int s, n_groups;
-    const double* lds_xi;                   // LDS copies (valid when staged)
-    const double* lds_w;
-    const int* lds_gs;
-    bool staged;
+    // LDS copies as 32-bit LDS addresses (this struct travels in the kernel arguments, where an address_space(3)
+    // pointer member would have different sizes in the host and device layouts).
+    unsigned lds_xi, lds_w, lds_gs;
     CGP_DEV int groups() const { return group_start ? n_groups : s; }
-    CGP_DEV int begin(int g) const { if (!group_start) return g; return staged ? lds_gs[g] : group_start[g]; }
-    CGP_DEV int end(int g) const { if (!group_start) return g + 1; return staged ? lds_gs[g + 1] : group_start[g + 1]; }
-    CGP_DEV double weight(int p) const { return staged ? lds_w[p] : w[p]; }
-    CGP_DEV double coord(int idx) const { return staged ? lds_xi[idx] : xi[idx]; }
-    // Cooperative copy into `buf` (kSigLdsDoubles doubles of LDS); all `nthreads` threads of the block must call it.
+    template <bool ST> CGP_DEV int begin(int g) const {
+        if (!group_start) return g;
+        if constexpr (ST) return ((LdsConstIntPtr)lds_gs)[g]; else return group_start[g];
+    }
+    template <bool ST> CGP_DEV int end(int g) const {
+        if (!group_start) return g + 1;
+        if constexpr (ST) return ((LdsConstIntPtr)lds_gs)[g + 1]; else return group_start[g + 1];
+    }
+    template <bool ST> CGP_DEV double weight(int p) const {
+        if constexpr (ST) return ((LdsConstDoublePtr)lds_w)[p]; else return w[p];
+    }
+    template <bool ST> CGP_DEV double coord(int idx) const {
+        if constexpr (ST) return ((LdsConstDoublePtr)lds_xi)[idx]; else return xi[idx];
+    }
+    static inline size_t stage_bytes(int s, int d, int n_groups, bool grouped) {
+        return ((size_t)s * d + s + (grouped ? (n_groups + 2) / 2 : 0)) * sizeof(double);
+    }
+    // Cooperative copy into `buf` (stage_bytes of LDS); all `nthreads` threads of the block must call it.
     CGP_DEV void stage(double* buf, int tid, int nthreads, int d) {
-        staged = false;
         const int nxi = s * d, ngs = group_start ? n_groups + 1 : 0;
-        if (xi == nullptr || nxi + s + (ngs + 1) / 2 > kSigLdsDoubles) return;
         for (int i = tid; i < nxi; i += nthreads) buf[i] = xi[i];
         for (int i = tid; i < s; i += nthreads) buf[nxi + i] = w[i];
         int* gs = reinterpret_cast<int*>(buf + nxi + s);
         for (int i = tid; i < ngs; i += nthreads) gs[i] = group_start[i];
         __syncthreads();
-        lds_xi = buf; lds_w = buf + nxi; lds_gs = gs;
-        staged = true;
+        lds_xi = (unsigned)(uintptr_t)(LdsConstDoublePtr)buf;
+        lds_w = (unsigned)(uintptr_t)(LdsConstDoublePtr)(buf + nxi);
+        lds_gs = (unsigned)(uintptr_t)(LdsConstIntPtr)gs;
     }
 };
 
@@ -83,9 +99,9 @@ CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int /*nl*/)
 }
 
 // chi = m + L xi_p   (quadratures.py:198-201), L lower-triangular packed.
-template <int D> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, const SigmaSet& sg, int p, Vec<D>& chi) {
+template <int D, bool ST> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, const SigmaSet& sg, int p, Vec<D>& chi) {
     double x[D];
-    CGP_UNROLL for (int j = 0; j < D; j++) x[j] = sg.coord(p * D + j);
+    CGP_UNROLL for (int j = 0; j < D; j++) x[j] = sg.template coord<ST>(p * D + j);
     CGP_UNROLL for (int i = 0; i < D; i++) {
         double t = L(i, 0) * x[0];
         CGP_UNROLL for (int j = 1; j <= i; j++) t = fma(L(i, j), x[j], t);
@@ -95,7 +111,7 @@ template <int D> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>& L, cons
 
 // Sigma-point prediction of a discrete model, filters_smoothers.py:88-121, plus (CROSS) the smoother's
 // D^T = (sum_i w_i chi_i f_i^T - mf mp^T)^T, filters_smoothers.py:525.
-template <class DM, bool WAVE, bool CROSS>
+template <class DM, bool WAVE, bool CROSS, bool ST = WAVE>
 CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, double* lds,
                             const Vec<DM::D>& mf, const Sym<DM::D>& Pf, Vec<DM::D>& mp, Sym<DM::D>& Pp, Mat<DM::D>& DT) {
     constexpr int D = DM::D;
@@ -109,15 +125,15 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
     // wave shape, a serial loop otherwise; the model's transcendental part runs once per group.
     const int step = WAVE ? 64 : 1, ng = sg.groups();
     for (int g = WAVE ? lane : 0; g < ng; g += step) {
-        int p = sg.begin(g);
-        const int pe = sg.end(g);
+        int p = sg.template begin<ST>(g);
+        const int pe = sg.template end<ST>(g);
         Vec<D> chi, f;
-        sigma_point<D>(mf, L, sg, p, chi);
+        sigma_point<D, ST>(mf, L, sg, p, chi);
         typename DM::Pre pre;
         model.precompute(chi.v[DM::IVC], pre);
         for (;;) {
             model.mean_pre(chi, pre, f);
-            const double w = sg.weight(p);
+            const double w = sg.template weight<ST>(p);
             acc[0] += w;
             double wf[D];
             CGP_UNROLL for (int i = 0; i < D; i++) { wf[i] = w * f.v[i]; acc[1 + i] += wf[i]; }
@@ -130,7 +146,7 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
                         acc[1 + D + NS + i * D + j] = fma(chi.v[i], wf[j], acc[1 + D + NS + i * D + j]);
             }
             if (++p >= pe) break;
-            sigma_point<D>(mf, L, sg, p, chi);
+            sigma_point<D, ST>(mf, L, sg, p, chi);
         }
     }
     if (WAVE) wave_allreduce<R>(acc, lds, lane, ng < 64 ? ng : 64);
@@ -148,7 +164,7 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
 
 // Sigma-point moment ODE of an SDE model, filters_smoothers.py:124-137: dm = E[a], dP = C + C^T + gamma,
 // C = E[(chi - m) a^T].
-template <class SM, bool WAVE>
+template <class SM, bool WAVE, bool ST = WAVE>
 CGP_DEV void cd_sgp_common(const SM& model, const SigmaSet& sg, int lane, double* lds, const Sym<SM::D>& gamma,
                            const Vec<SM::D>& m, const Sym<SM::D>& P, Vec<SM::D>& dm, Sym<SM::D>& dP) {
     constexpr int D = SM::D;
@@ -159,15 +175,15 @@ CGP_DEV void cd_sgp_common(const SM& model, const SigmaSet& sg, int lane, double
     CGP_UNROLL for (int r = 0; r < R; r++) acc[r] = 0.0;
     const int step = WAVE ? 64 : 1, ng = sg.groups();
     for (int g = WAVE ? lane : 0; g < ng; g += step) {
-        int p = sg.begin(g);
-        const int pe = sg.end(g);
+        int p = sg.template begin<ST>(g);
+        const int pe = sg.template end<ST>(g);
         Vec<D> chi, a;
-        sigma_point<D>(m, L, sg, p, chi);
+        sigma_point<D, ST>(m, L, sg, p, chi);
         typename SM::Pre pre;
         model.precompute(chi.v[SM::IVC], pre);
         for (;;) {
             model.drift_pre(chi, pre, a);
-            const double w = sg.weight(p);
+            const double w = sg.template weight<ST>(p);
             double wa[D];
             CGP_UNROLL for (int i = 0; i < D; i++) { wa[i] = w * a.v[i]; acc[i] += wa[i]; }
             CGP_UNROLL for (int i = 0; i < D; i++) {
@@ -175,7 +191,7 @@ CGP_DEV void cd_sgp_common(const SM& model, const SigmaSet& sg, int lane, double
                 CGP_UNROLL for (int j = 0; j < D; j++) acc[D + i * D + j] = fma(ci, wa[j], acc[D + i * D + j]);
             }
             if (++p >= pe) break;
-            sigma_point<D>(m, L, sg, p, chi);
+            sigma_point<D, ST>(m, L, sg, p, chi);
         }
     }
     if (WAVE) wave_allreduce<R>(acc, lds, lane, ng < 64 ? ng : 64);
@@ -221,7 +237,7 @@ template <class DM, bool WAVE_> struct EkfPredict {
     static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; }
     CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> T;
         model.propagate(mf, Pf, mp, T, Pp);
@@ -247,6 +263,7 @@ template <class SM, bool WAVE_> struct CdEkfPredict {
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.uniform = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         dt = a.dt;
     }
@@ -286,7 +303,7 @@ template <class DM, bool WAVE_> struct EksStep {
     static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; }
     CGP_DEV void step(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
         model.propagate(mf, Pf, mp, DT, Pp);          // DT = J Pf
@@ -326,6 +343,7 @@ template <class SM, bool WAVE_> struct CdEksStep {
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.uniform = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         dt = -a.dt;
     }
@@ -475,7 +493,7 @@ template <class DM> struct SgpsElement {
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
     CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT;
-        sgp_prediction<DM, false, true>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
+        sgp_prediction<DM, false, true, true>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
         affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
     }
 };

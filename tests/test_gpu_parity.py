@@ -293,3 +293,40 @@ def test_mle_through_the_filter():
     mss, Pss = fs.eks(disc, mfs, Pfs, dt)
     est = gaussian_expectation(mss[:, 2], np.sqrt(Pss[:, 2, 2]), func=pm.g, force_shape=True)[:, 0]
     assert rmse(freq(ts), est) < 3.0, rmse(freq(ts), est)
+
+
+@pytest.mark.parametrize('d', [1, 2, 5, 6, 8])
+def test_linear_models_all_dims(d):
+    """kf / rts / sgp / cd_* on random stable linear models of every compiled dimension, against the C port."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    rng = np.random.default_rng(40 + d)
+    A = -np.eye(d) * rng.uniform(0.5, 2.0, d) + 0.3 * rng.standard_normal((d, d))
+    A = A - np.eye(d) * max(0.0, np.max(np.real(np.linalg.eigvals(A))) + 0.2)
+    Bm = 0.5 * np.eye(d) + 0.1 * rng.standard_normal((d, d))
+    dt = 0.01
+    from chirpgp_amd.tools import lti_sde_to_disc
+    F, Sigma = lti_sde_to_disc(A, Bm, dt)
+    Sigma = 0.5 * (Sigma + Sigma.T)
+    H = rng.standard_normal(d)
+    m0, P0 = rng.standard_normal(d), np.eye(d) * 0.3
+    T = 300
+    ys = rng.standard_normal(T)
+    drift, disp = pm.linear_sde(A, Bm)
+    c = cs.Case(f'lin{d}', d=d, dt=dt, H=H, Xi=0.2, m0=m0, P0=P0, ys=ys, disc=pm.linear_cond_m_cov(F, Sigma),
+                drift=drift, disp=disp, sgps=SigmaPoints.cubature(d))
+    want = bk.run_pairs('port', c)
+    for kw in (WAVE, THREAD):
+        bk.compare(bk.run_pairs('hip', c, hip_kw=kw), want, RTOL, f'linear d={d}')
+
+
+def test_large_sigma_sets_fall_back_to_one_lane_per_trial():
+    """A sigma-point set too large for the LDS stage (Gauss-Hermite order 3 in d = 8: 6561 points) must still be served
+    (by the one-lane-per-trial kernels that read it from global memory), and a mid-size one (d = 6, 729 points) staged."""
+    for nh, T in ((3, 12), (2, 40)):
+        from chirpgp_amd.quadratures import SigmaPoints
+        c = cs.harmonic_case(T=T, nh=nh, seed=51)
+        c.sgps = SigmaPoints.gauss_hermite(2 * nh + 2, 3)
+        got = bk.run_pairs('hip', c, only=('sgp_filter', 'sgp_smoother'))
+        want = bk.run_pairs('port', c, only=('sgp_filter', 'sgp_smoother'))
+        bk.compare(got, want, RTOL, f'gh3 d={2 * nh + 2}')
