@@ -17,15 +17,27 @@ static int fail(cgp_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
-// One wavefront per trial until the batch alone fills every SIMD several times over; beyond that one lane per trial
-// keeps all 64 lanes busy (the per-step work of a trial is far too small to split across lanes).
-static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, const cgp_sigma* sg = nullptr) {
+// Launch-shape choice.  One wavefront per trial is the latency-optimal shape while the batch is about the number of
+// SIMDs (1024): a step then costs its dependent-instruction chain once.  One lane per trial costs more per step but
+// carries 64 trials per wave, so it wins as soon as several wavefronts would have to share a SIMD.  Measured crossovers
+// on MI355X (tools/sweep_b.sh, EKF + EKS, d = 4, T = 2000):
+//     EKF-type filters            wave 1.87 ms vs lane 2.52 ms at B = 2048;  3.55 vs 2.53 at B = 4096   -> 2.5 waves / SIMD
+//     sigma-point filters         the fan is spread over the lanes of the wave, which one lane per trial cannot do -> 8 / SIMD
+//     time-parallel smoothers     throughput-bound at ~2.9 TB/s for every B; the step-by-step lane-per-trial scan is
+//                                 latency-bound (T x 1.9 us) until B ~ 16K                              -> 16 / SIMD
+enum class Shape { EkfFilter, SigmaFilter, AffineSmoother, SerialSmoother };
+static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, Shape shape, const cgp_sigma* sg = nullptr) {
     // the wave-per-trial shapes stage the sigma-point set in LDS; a set that does not fit runs one lane per trial
     if (sg && SigmaSet::stage_bytes(sg->s, sg->d, sg->n_groups, sg->group_start != nullptr) > (size_t)kSigLdsMaxBytes) return false;
     if (flags & CGP_WAVE_PER_TRIAL) return true;
     if (flags & CGP_THREAD_PER_TRIAL) return false;
     const int64_t simds = (int64_t)(ctx ? ctx->num_cus : 256) * 4;
-    return B < simds * 8;
+    switch (shape) {
+    case Shape::EkfFilter:      return 2 * B < 5 * simds;
+    case Shape::SigmaFilter:    return B < 8 * simds;
+    case Shape::AffineSmoother: return B < 16 * simds;
+    default:                    return 2 * B < 5 * simds;
+    }
 }
 
 static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sigma, const cgp_sigma* sg) {
@@ -156,7 +168,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt);
-    const bool wave = choose_wave(ctx, B, flags, sig ? sigma : nullptr);
+    const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : Shape::EkfFilter, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;
@@ -194,7 +206,8 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt);
-    const bool wave = choose_wave(ctx, B, flags, sig ? sigma : nullptr);
+    const bool affine = (method == CGP_S_EKS || method == CGP_S_SGP) && !(flags & CGP_SEQUENTIAL_SCAN);
+    const bool wave = choose_wave(ctx, B, flags, affine ? Shape::AffineSmoother : (sig ? Shape::SigmaFilter : Shape::SerialSmoother), sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st); break;
