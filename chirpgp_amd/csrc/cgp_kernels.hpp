@@ -185,11 +185,14 @@ __global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs m
     }
 }
 
-// Time-parallel discrete smoother (rts / eks / sgp_smoother): one wavefront per trial, one lane per time step,
-// 64 steps per tile, tiles walked from the end of the record to its start.  See "TIME-PARALLEL SMOOTHER" in
-// cgp_steps.hpp.  Loads and stores are per-lane rows of consecutive time steps, i.e. contiguous 64 * 8(d + d^2) bytes
-// per tile.
-template <class Elem>
+// Time-parallel discrete smoother (rts / eks / sgp_smoother): one wavefront per trial, K consecutive time steps per
+// lane, 64 K steps per tile, tiles walked from the end of the record to its start.  See "TIME-PARALLEL SMOOTHER" in
+// cgp_steps.hpp.  Per tile a lane (1) builds the affine maps e_0..e_{K-1} of its steps (the expensive, fully parallel
+// part), (2) composes them into one lane aggregate, (3) the 6-round suffix scan runs on the 64 aggregates, (4) the lane
+// fetches the composed map of all later lanes, applies it to the carry and then walks its own K steps backwards.
+// Cost per 64 steps in wave instructions ~ 734 + 1556 / K (d = 4): K = 4 halves the K = 1 cost.  Loads and stores are
+// per-lane runs of K consecutive rows, i.e. one contiguous 64 K * 8 (d + d^2) byte block per tile.
+template <class Elem, int K>
 __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArgs ma) {
     constexpr int D = Elem::D;
     const int lane = threadIdx.x;
@@ -213,28 +216,55 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
         CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
         CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i];
     }
-    for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
-        const int64_t k = hi - 63 + lane;
-        const bool valid = k >= 0;
-        Affine<D> e;
-        affine_identity<D>(e);
-        if (valid) {
-            Vec<D> mf; Sym<D> Pf;
-            load_vec<D>(mfs + k * D, mf);
-            load_sym<D>(Pfs + k * D * D, Pf);
-            elem.element(mf, Pf, e);
+    for (int64_t hi = T - 2; hi >= 0; hi -= 64 * K) {
+        const int64_t base = hi - (64 * K - 1) + (int64_t)lane * K;      // first (earliest) step of this lane
+        Affine<D> e[K];
+        CGP_UNROLL for (int j = 0; j < K; j++) {
+            affine_identity<D>(e[j]);
+            if (base + j >= 0) {
+                Vec<D> mf; Sym<D> Pf;
+                load_vec<D>(mfs + (base + j) * D, mf);
+                load_sym<D>(Pfs + (base + j) * D * D, Pf);
+                elem.element(mf, Pf, e[j]);
+            }
         }
-        // suffix scan: e_l <- e_l o e_{l+1} o ... o e_63
+        // lane aggregate a = e_0 o e_1 o ... o e_{K-1}
+        Affine<D> a = e[K - 1];
+        CGP_UNROLL for (int j = K - 2; j >= 0; j--) {
+            Affine<D> t = e[j];
+            affine_compose<D>(t, a);
+            a = t;
+        }
+        // suffix scan over lanes: a_l <- a_l o a_{l+1} o ... o a_63
         CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
             Affine<D> o;
-            affine_shfl_down<D>(e, delta, o);
-            if (lane + delta < 64) affine_compose<D>(e, o);
+            affine_shfl_down<D>(a, delta, o);
+            if (lane + delta < 64) affine_compose<D>(a, o);
         }
-        Vec<D> xm; Sym<D> xP;
-        affine_apply<D>(e, ms, Ps, xm, xP);
-        if (valid) {
-            store_vec<D>(mss + k * D, xm);
-            store_sym_full<D>(Pss + k * D * D, xP);
+        Vec<D> xm = ms; Sym<D> xP = Ps;
+        if constexpr (K == 1) {
+            // one step per lane: the scanned map already contains the lane's own step
+            affine_apply<D>(a, ms, Ps, xm, xP);
+            if (base >= 0) {
+                store_vec<D>(mss + base * D, xm);
+                store_sym_full<D>(Pss + base * D * D, xP);
+            }
+        } else {
+            // state entering this lane's run from later times: (a_{l+1} o ... o a_63)(carry); lane 63 takes the carry itself
+            {
+                Affine<D> nxt;
+                affine_shfl_down<D>(a, 1, nxt);
+                if (lane < 63) affine_apply<D>(nxt, ms, Ps, xm, xP);
+            }
+            CGP_UNROLL for (int j = K - 1; j >= 0; j--) {
+                Vec<D> ym; Sym<D> yP;
+                affine_apply<D>(e[j], xm, xP, ym, yP);
+                xm = ym; xP = yP;
+                if (base + j >= 0) {
+                    store_vec<D>(mss + (base + j) * D, xm);
+                    store_sym_full<D>(Pss + (base + j) * D * D, xP);
+                }
+            }
         }
         // carry for the next (earlier) tile: the state at the tile's first step, held by lane 0
         CGP_UNROLL for (int i = 0; i < D; i++) ms.v[i] = readlane_f64(xm.v[i], 0);
@@ -242,11 +272,14 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
     }
 }
 
+// Steps per lane of the time-parallel smoother: bounded by the VGPR budget (K affine maps of D^2 + D + D(D+1)/2 doubles).
+template <int D> struct TpStepsPerLane { static constexpr int value = D <= 4 ? 4 : 1; };
+
 template <class Elem>
 inline hipError_t launch_tp_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
     const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
-    hipLaunchKernelGGL((tp_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
+    hipLaunchKernelGGL((tp_smoother_kernel<Elem, TpStepsPerLane<Elem::D>::value>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
     return hipGetLastError();
 }
 
