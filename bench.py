@@ -68,6 +68,21 @@ def bytes_per_trial_step(d):
     return filt, smooth
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
+    (profiles/r01_v8_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r01_v8_ekf_eks_pmc.json')
+    try:
+        prof = json.load(open(path))
+    except OSError:
+        return None
+    for name, counters in prof.items():
+        if kernel_key in name and 'hbm_bytes_per_launch' in counters:
+            return counters['hbm_bytes_per_launch']
+    return None
+
+
 def cpu_baseline(wl, target_seconds=12.0):
     """The oracle's C port (oracle/c/port.c, OpenMP over trials) timed on the host cores on a bounded sample of the
     SAME workload: as many trials (full T) as fit ~target_seconds, at least one per thread."""
@@ -207,7 +222,9 @@ def main():
                        "sigma_points": int(wl['sgps'].n_points) if args.workload != 'ekf' and args.workload != 'cd_ekf' else None},
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (pmc_traffic('ekf4_coop' if dom[0] == 'filter' else 'tp_smoother')
+                                     if (args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags) else None),
                          "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1]},
             "kernels": {"filter_ms": filt_ms, "smoother_ms": smooth_ms,
                         "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9, "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9},

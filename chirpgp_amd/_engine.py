@@ -46,6 +46,9 @@ _lock = threading.Lock()
 def load_library():
     """dlopen libchirpgp_hip.so and declare the prototypes.  Raises if the library has not been built."""
     global _lib
+    # torch first: PyTorch-ROCm ships its own libamdhip64; loading it before our library makes both use the same HIP
+    # runtime (the reverse order leaves two runtimes in the process and hipGetDeviceCount fails in ours).
+    _torch()
     with _lock:
         if _lib is not None:
             return _lib
