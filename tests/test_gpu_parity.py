@@ -330,3 +330,21 @@ def test_large_sigma_sets_fall_back_to_one_lane_per_trial():
         got = bk.run_pairs('hip', c, only=('sgp_filter', 'sgp_smoother'))
         want = bk.run_pairs('port', c, only=('sgp_filter', 'sgp_smoother'))
         bk.compare(got, want, RTOL, f'gh3 d={2 * nh + 2}')
+
+
+def test_sigma_point_sweep_nll_only():
+    """Config C5's sweep: 3-harmonic model, cubature, one parameter vector per trial, NLL-only, both launch shapes."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    G, T = 7, 300
+    rng = np.random.default_rng(9)
+    params = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * rng.uniform(0.8, 1.2, size=(G, 6))
+    drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, 3)
+    sg = SigmaPoints.cubature(8)
+    ys = np.tile(cs.chirp_measurements(T, 77, num_harmonics=3)[2], (G, 1))
+    want = port.filter(port.F_SGP, disc, sg, H, 0.1, m0, P0, 1e-3, ys, nll_final_only=True)[2]
+    for kw in (WAVE, THREAD):
+        got = fs.sgp_filter(disc, sg, H, 0.1, m0, P0, 1e-3, ys, nll_final_only=True, want=(False, False, True), **kw)[2]
+        cs.assert_close(got, want, RTOL, 'sweep nll')
