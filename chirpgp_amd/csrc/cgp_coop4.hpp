@@ -46,6 +46,63 @@ CGP_DEV OffDiagCoef offdiag_coef(int i, int l, const double (&M)[4]) {
     return o;
 }
 
+// Measurement constants of one trial in the cooperative layout: H replicated, plus H[i] and H[j] of the lane.
+struct Coop4Meas {
+    double H0, H1, H2, H3, Hi, Hj, Xi;
+    CGP_DEV void load(const FilterIO& io, int64_t trial, int li, int lj) {
+        const double* __restrict__ Hp = io.H + trial * io.H_stride;
+        H0 = Hp[0]; H1 = Hp[1]; H2 = Hp[2]; H3 = Hp[3];
+        Hi = Hp[li]; Hj = Hp[lj];
+        Xi = io.Xi[trial * io.Xi_stride];
+    }
+};
+
+// Scalar-measurement update (filters_smoothers.py:55-68) in the cooperative layout: Pp is the lane's entry of the
+// predicted covariance, f0..f3 the (replicated) predicted mean; returns the lane's entry of Pf in P and the updated
+// mean in u0..u3, plus S and the innovation for the NLL.
+CGP_DEV void coop4_update(const Coop4Meas& M, double Pp, double f0, double f1, double f2, double f3, double y,
+                          double& P, double& u0, double& u1, double& u2, double& u3, double& S_out, double& innov_out) {
+    double PHj = Pp * M.Hi;                                   // PH[j] = sum_i Pp[i][j] H[i]: sum over the rows
+    PHj += dpp_f64<kRowRor4>(PHj);
+    PHj += dpp_f64<kRowRor8>(PHj);
+    double PHi = Pp * M.Hj;                                   // PH[i] = sum_j Pp[i][j] H[j]: sum over the quad
+    PHi += dpp_f64<kQuadSwap1>(PHi);
+    PHi += dpp_f64<kQuadSwap2>(PHi);
+    double S = M.Hj * PHj;
+    S += dpp_f64<kQuadSwap1>(S);
+    S += dpp_f64<kQuadSwap2>(S);
+    S += M.Xi;
+    const double pred = fma(M.H3, f3, fma(M.H2, f2, fma(M.H1, f1, M.H0 * f0)));
+    const double innov = y - pred;
+    const double rS = rcp_nr(S);
+    P = fma(-(PHi * rS), PHj, Pp);                            // Pf = Pp - K (Pp H)^T
+    const double g = rS * innov;
+    u0 = fma(dpp_f64<kQuadBcast0>(PHj), g, f0);               // mf = mp + K innov, K = PH / S
+    u1 = fma(dpp_f64<kQuadBcast1>(PHj), g, f1);
+    u2 = fma(dpp_f64<kQuadBcast2>(PHj), g, f2);
+    u3 = fma(dpp_f64<kQuadBcast3>(PHj), g, f3);
+    S_out = S;
+    innov_out = innov;
+}
+
+// NLL of up to 64 latched steps: every lane evaluates its increment, inclusive prefix sum across the wave, one
+// coalesced store; returns the new running total (wave-uniform).
+CGP_DEV double nll_flush_wave(double S_l, double innov_l, int lane, int nsteps, double cum, double* __restrict__ nll_chunk) {
+    double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
+    CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+        const double up = __shfl_up(v, delta, 64);
+        if (lane >= delta) v += up;
+    }
+    v += cum;
+    if (nll_chunk && lane < nsteps) nll_chunk[lane] = v;
+    return readlane_f64(v, nsteps - 1);
+}
+
+// Lane's entry of the (symmetric) initial covariance, read from the lower triangle like the generic kernels do.
+CGP_DEV double coop4_load_sym_entry(const double* __restrict__ p, int li, int lj) {
+    return (li >= lj) ? p[li * 4 + lj] : p[lj * 4 + li];
+}
+
 __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma) {
     const int lane = threadIdx.x;
     const int li = (lane >> 2) & 3, lj = lane & 3;
@@ -57,10 +114,8 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
     const double rho = model.rho, dt = model.dt, fs = model.fs;
     const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
 
-    const double* __restrict__ Hp = io.H + trial * io.H_stride;
-    const double H0 = Hp[0], H1 = Hp[1], H2 = Hp[2], H3 = Hp[3];
-    const double Hi = Hp[li], Hj = Hp[lj];
-    const double Xi = io.Xi[trial * io.Xi_stride];
+    Coop4Meas meas;
+    meas.load(io, trial, li, lj);
 
     // Sigma[i][j] of this lane (models.py:302-308)
     double Sig = 0.0;
@@ -82,7 +137,7 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     double u0 = m0p[0], u1 = m0p[1], u2 = m0p[2], u3 = m0p[3];
     const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
-    double P = (li >= lj) ? P0p[li * 4 + lj] : P0p[lj * 4 + li];     // lower triangle, like the generic kernels
+    double P = coop4_load_sym_entry(P0p, li, lj);
 
     const int64_t T = io.T;
     const double* __restrict__ ys = io.ys + trial * T;
@@ -130,25 +185,8 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
             Pp = fma(Jr2, dpp_f64<kRowRor8>(Q), Pp);
             Pp = fma(Jr3, dpp_f64<kRowRor12>(Q), Pp);
             // ---- update (filters_smoothers.py:55-68)
-            double PHj = Pp * Hi;                                     // PH[j] = sum_i Pp[i][j] H[i]: sum over the rows
-            PHj += dpp_f64<kRowRor4>(PHj);
-            PHj += dpp_f64<kRowRor8>(PHj);
-            double PHi = Pp * Hj;                                     // PH[i] = sum_j Pp[i][j] H[j]: sum over the quad
-            PHi += dpp_f64<kQuadSwap1>(PHi);
-            PHi += dpp_f64<kQuadSwap2>(PHi);
-            double S = Hj * PHj;
-            S += dpp_f64<kQuadSwap1>(S);
-            S += dpp_f64<kQuadSwap2>(S);
-            S += Xi;
-            const double pred = fma(H3, f3, fma(H2, f2, fma(H1, f1, H0 * f0)));
-            const double innov = y - pred;
-            const double rS = rcp_nr(S);
-            P = fma(-(PHi * rS), PHj, Pp);                            // Pf = Pp - K (Pp H)^T
-            const double g = rS * innov;
-            u0 = fma(dpp_f64<kQuadBcast0>(PHj), g, f0);               // mf = mp + K innov, K = PH / S
-            u1 = fma(dpp_f64<kQuadBcast1>(PHj), g, f1);
-            u2 = fma(dpp_f64<kQuadBcast2>(PHj), g, f2);
-            u3 = fma(dpp_f64<kQuadBcast3>(PHj), g, f3);
+            double S, innov;
+            coop4_update(meas, Pp, f0, f1, f2, f3, y, P, u0, u1, u2, u3, S, innov);
             if (lane == slot) { S_l = S; innov_l = innov; }
             if (Pfs && lane < 16) Pfs[t * 16 + lane] = P;
             if (mfs && lane == 0) {
@@ -156,16 +194,7 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
                 *reinterpret_cast<double2*>(mfs + t * 4 + 2) = make_double2(u2, u3);
             }
         }
-        if (want_nll) {
-            double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
-            CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
-                const double up = __shfl_up(v, delta, 64);
-                if (lane >= delta) v += up;
-            }
-            v += cum;
-            if (nll && lane < nsteps) nll[t0 + lane] = v;
-            cum = readlane_f64(v, nsteps - 1);
-        }
+        if (want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, nll ? nll + t0 : nullptr);
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }

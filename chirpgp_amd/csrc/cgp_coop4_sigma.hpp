@@ -1,0 +1,363 @@
+// cgp_coop4_sigma.hpp -- lane-cooperative d = 4 sigma-point kernels (BASELINE configs C3 and C4):
+//     sgp4_coop_kernel      sgp_filter       on the chirp / La Scala LCD model      (filters_smoothers.py:446-490)
+//     cdsgp4_coop_kernel    cd_sgp_filter    on the chirp / La Scala SDE model      (filters_smoothers.py:534-582)
+//     cdsgps4_coop_kernel   cd_sgp_smoother  on the same                            (filters_smoothers.py:585-632)
+//
+// One wavefront per trial.  Three layouts coexist in a step:
+//   * the covariance is DISTRIBUTED, lane (i, j) of every 16-lane row owning P[i][j], for everything that is matrix
+//     algebra (RK4 bookkeeping, G^T P + P G, the Kalman update of cgp_coop4.hpp): one instruction instead of ten;
+//   * the sigma-point FAN runs one group of points per lane (the points of a group share the nonlinear coordinate chi_v,
+//     cgp_steps.hpp); it needs the Cholesky factor in every lane, so the 10 covariance entries are gathered with
+//     v_readlane and the 4 x 4 Cholesky is replicated;
+//   * the fan's partial sums are reduced through LDS (cgp_steps.hpp:wave_allreduce's scheme) and LEFT there: each lane
+//     then reads exactly the totals it owns -- its own second-moment entry, the means -- so the "reduce-scatter" back
+//     to the distributed layout costs one ds_read per lane.
+// The sigma-point set is staged in dynamic LDS by the launch (cgp_kernels.hpp:dyn_lds).
+#pragma once
+#include "cgp_coop4.hpp"
+
+namespace cgp {
+
+// Lower triangle of the distributed covariance -> replicated packed matrix (10 wave-uniform values).
+CGP_DEV void coop4_gather(double P, Sym<4>& S) {
+    CGP_UNROLL for (int i = 0; i < 4; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) S(i, j) = readlane_f64(P, 4 * i + j);
+}
+
+// Wave sum of R <= 32 per-lane partials; the totals stay in LDS at the returned pointer (tot[0..R-1]).
+// Same fixed summation order as wave_allreduce.
+template <int R>
+CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane) {
+    static_assert(R <= kRedChunk, "totals area holds kRedChunk doubles");
+    double* tot = lds + kRedChunk * kRedLd;
+    const int r = lane >> 2, q = lane & 3;
+    CGP_UNROLL for (int base = 0; base < R; base += kRedPass) {
+        CGP_UNROLL for (int k = 0; k < kRedPass; k++)
+            if (base + k < R) lds[k * kRedLd + lane] = acc[base + k];
+        wave_lds_fence();
+        const double2* row = reinterpret_cast<const double2*>(lds + r * kRedLd + q * 16);
+        double s = 0.0;
+        if (base + r < R) {
+            CGP_UNROLL for (int j = 0; j < 8; j++) { const double2 v = row[j]; s += v.x; s += v.y; }
+        }
+        s += dpp_f64<kQuadSwap1>(s);
+        s += dpp_f64<kQuadSwap2>(s);
+        if (q == 0 && base + r < R) tot[base + r] = s;
+        wave_lds_fence();
+    }
+    return tot;
+}
+
+// Shared prologue of the filter kernels: outputs, measurement chunking and NLL latch live in the kernels themselves.
+struct Coop4FilterOut {
+    double* __restrict__ mfs; double* __restrict__ Pfs; double* __restrict__ nll;
+    bool nll_final, want_nll;
+    CGP_DEV void init(const FilterIO& io, int64_t trial) {
+        const int64_t T = io.T;
+        mfs = io.mfs ? io.mfs + trial * T * 4 : nullptr;
+        Pfs = io.Pfs ? io.Pfs + trial * T * 16 : nullptr;
+        nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+        nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+        want_nll = io.nll != nullptr;
+    }
+    CGP_DEV void store(int64_t t, int lane, double P, double u0, double u1, double u2, double u3) const {
+        if (Pfs && lane < 16) Pfs[t * 16 + lane] = P;
+        if (mfs && lane == 0) {
+            *reinterpret_cast<double2*>(mfs + t * 4) = make_double2(u0, u1);
+            *reinterpret_cast<double2*>(mfs + t * 4 + 2) = make_double2(u2, u3);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ sgp_filter, d = 4
+template <class DM>
+__global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma) {
+    static_assert(DM::D == 4, "d = 4 kernel");
+    __shared__ double red[kFanLdsDoubles];
+    const int lane = threadIdx.x;
+    const int li = (lane >> 2) & 3, lj = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    DM model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, 4);
+    Coop4Meas meas;
+    meas.load(io, trial, li, lj);
+    double Sig = 0.0;                                   // the lane's entry of the transition covariance
+    {
+        Sym<4> Sg;
+        CGP_UNROLL for (int k = 0; k < Sym<4>::N; k++) Sg.a[k] = 0.0;
+        model.add_sigma(Sg, 1.0);
+        CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j++) if (li == i && lj == j) Sig = Sg(i, j);
+    }
+    const int s2_idx = 5 + Sym<4>::idx(li, lj);         // this lane's entry among the totals: [wsum, mean x4, second moment x10]
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    double u0 = m0p[0], u1 = m0p[1], u2 = m0p[2], u3 = m0p[3];
+    double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, li, lj);
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    Coop4FilterOut out;
+    out.init(io, trial);
+    const int ng = sg.groups();
+
+    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const double y = readlane_f64(ychunk, slot);
+            // ---- sigma-point prediction (filters_smoothers.py:88-121)
+            Sym<4> Pr, L; Vec<4> inv, m;
+            coop4_gather(P, Pr);
+            m.v[0] = u0; m.v[1] = u1; m.v[2] = u2; m.v[3] = u3;
+            cholesky<4>(Pr, L, inv);
+            double acc[15];
+            CGP_UNROLL for (int k = 0; k < 15; k++) acc[k] = 0.0;
+            for (int g = lane; g < ng; g += 64) {
+                int p = sg.template begin<true>(g);
+                const int pe = sg.template end<true>(g);
+                Vec<4> chi, f;
+                sigma_point<4, true>(m, L, sg, p, chi);
+                typename DM::Pre pre;
+                model.precompute(chi.v[DM::IVC], pre);
+                for (;;) {
+                    model.mean_pre(chi, pre, f);
+                    const double w = sg.template weight<true>(p);
+                    acc[0] += w;
+                    double wf[4];
+                    CGP_UNROLL for (int i = 0; i < 4; i++) { wf[i] = w * f.v[i]; acc[1 + i] += wf[i]; }
+                    CGP_UNROLL for (int i = 0; i < 4; i++)
+                        CGP_UNROLL for (int j = 0; j <= i; j++)
+                            acc[5 + Sym<4>::idx(i, j)] = fma(wf[i], f.v[j], acc[5 + Sym<4>::idx(i, j)]);
+                    if (++p >= pe) break;
+                    sigma_point<4, true>(m, L, sg, p, chi);
+                }
+            }
+            const double* tot = coop_reduce_to_lds<15>(acc, red, lane);
+            const double wsum = tot[0];
+            const double f0 = tot[1], f1 = tot[2], f2 = tot[3], f3 = tot[4];
+            // Pp = E[f f^T + Sigma] - mp mp^T, this lane's entry
+            const double Pp = fma(wsum, Sig, tot[s2_idx]) - tot[1 + li] * tot[1 + lj];
+            // ---- update
+            double S, innov;
+            coop4_update(meas, Pp, f0, f1, f2, f3, y, P, u0, u1, u2, u3, S, innov);
+            if (lane == slot) { S_l = S; innov_l = innov; }
+            out.store(t0 + slot, lane, P, u0, u1, u2, u3);
+        }
+        if (out.want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, out.nll ? out.nll + t0 : nullptr);
+    }
+    if (lane == 0 && io.nll && out.nll_final) io.nll[trial] = cum;
+}
+
+// ------------------------------------------------------------------------------------------------ cd sigma-point moment ODE
+// One evaluation of the sigma-point moment ODE (filters_smoothers.py:124-137) at (m, distributed P):
+// km[l] = E[a_l] (replicated) and this lane's entry of C + C^T + gamma with C = E[(chi - m) a^T].
+template <class SM>
+CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, int ng, double* red, int lane, int cij_idx, int cji_idx,
+                              double gam, const Vec<4>& m, double P, Vec<4>& km, double& kP) {
+    Sym<4> Pr, L; Vec<4> inv;
+    coop4_gather(P, Pr);
+    cholesky<4>(Pr, L, inv);
+    double acc[20];
+    CGP_UNROLL for (int k = 0; k < 20; k++) acc[k] = 0.0;
+    for (int g = lane; g < ng; g += 64) {
+        int p = sg.template begin<true>(g);
+        const int pe = sg.template end<true>(g);
+        Vec<4> chi, a;
+        sigma_point<4, true>(m, L, sg, p, chi);
+        typename SM::Pre pre;
+        model.precompute(chi.v[SM::IVC], pre);
+        for (;;) {
+            model.drift_pre(chi, pre, a);
+            const double w = sg.template weight<true>(p);
+            double wa[4];
+            CGP_UNROLL for (int i = 0; i < 4; i++) { wa[i] = w * a.v[i]; acc[i] += wa[i]; }
+            CGP_UNROLL for (int i = 0; i < 4; i++) {
+                const double ci = chi.v[i] - m.v[i];
+                CGP_UNROLL for (int j = 0; j < 4; j++) acc[4 + i * 4 + j] = fma(ci, wa[j], acc[4 + i * 4 + j]);
+            }
+            if (++p >= pe) break;
+            sigma_point<4, true>(m, L, sg, p, chi);
+        }
+    }
+    const double* tot = coop_reduce_to_lds<20>(acc, red, lane);
+    km.v[0] = tot[0]; km.v[1] = tot[1]; km.v[2] = tot[2]; km.v[3] = tot[3];
+    kP = (tot[cij_idx] + tot[cji_idx]) + gam;
+}
+
+// ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
+template <class SM>
+__global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs ma) {
+    static_assert(SM::D == 4, "d = 4 kernel");
+    __shared__ double red[kFanLdsDoubles];
+    const int lane = threadIdx.x;
+    const int li = (lane >> 2) & 3, lj = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    SM model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, 4);
+    Coop4Meas meas;
+    meas.load(io, trial, li, lj);
+    const double gam = coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, li, lj);
+    const double dt = ma.dt;
+    const int cij_idx = 4 + li * 4 + lj, cji_idx = 4 + lj * 4 + li;
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    Vec<4> u;
+    u.v[0] = m0p[0]; u.v[1] = m0p[1]; u.v[2] = m0p[2]; u.v[3] = m0p[3];
+    double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, li, lj);
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    Coop4FilterOut out;
+    out.init(io, trial);
+    const int ng = sg.groups();
+
+    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const double y = readlane_f64(ychunk, slot);
+            // ---- RK4 on (m, P) (quadratures.py:34-54), same operation order as cgp_steps.hpp:rk4_m_cov
+            Vec<4> tm = u, am, km;
+            double tP = P, aP = 0.0, kP;
+            CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                coop4_cd_sgp_rhs<SM>(model, sg, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
+                const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+                const double half = (stage == 2) ? 1.0 : 0.5;
+                CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = u.v[i] + (dt * km.v[i]) * half; }
+                aP = fma(wgt, kP, aP);
+                tP = P + (dt * kP) * half;
+            }
+            const double f0 = u.v[0] + (dt * am.v[0]) / 6.0, f1 = u.v[1] + (dt * am.v[1]) / 6.0;
+            const double f2 = u.v[2] + (dt * am.v[2]) / 6.0, f3 = u.v[3] + (dt * am.v[3]) / 6.0;
+            const double Pp = P + (dt * aP) / 6.0;
+            // ---- update
+            double S, innov;
+            coop4_update(meas, Pp, f0, f1, f2, f3, y, P, u.v[0], u.v[1], u.v[2], u.v[3], S, innov);
+            if (lane == slot) { S_l = S; innov_l = innov; }
+            out.store(t0 + slot, lane, P, u.v[0], u.v[1], u.v[2], u.v[3]);
+        }
+        if (out.want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, out.nll ? out.nll + t0 : nullptr);
+    }
+    if (lane == 0 && io.nll && out.nll_final) io.nll[trial] = cum;
+}
+
+// ------------------------------------------------------------------------------------------------ cd_sgp_smoother, d = 4
+// Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
+// G is constant over the four stages (hoisted, as in cgp_steps.hpp); its entries reach the lanes through LDS:
+//     (G^T P)[i][j] = sum_r G[l_r][i] P[l_r][j]   (rows l_r by DPP row rotations, G[l_r][i] per lane)
+//     (P G)[i][j]   = sum_l P[i][l] G[l][j]       (quad broadcasts, G[l][j] per lane)
+template <class SM>
+__global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelArgs ma) {
+    static_assert(SM::D == 4, "d = 4 kernel");
+    __shared__ double red[kFanLdsDoubles];
+    __shared__ double gl[16];
+    const int lane = threadIdx.x;
+    const int li = (lane >> 2) & 3, lj = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    SM model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, 4);
+    Sym<4> gamma;
+    load_sym<4>(ma.gamma + trial * ma.gamma_stride, gamma);
+    const double gam = coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, li, lj);
+    const double dt = -ma.dt;
+    const int cij_idx = 4 + li * 4 + lj, cji_idx = 4 + lj * 4 + li;
+    // source rows of the three row rotations, discovered by rotating the row index itself
+    const int lr1 = dpp_i32<kRowRor4>(li), lr2 = dpp_i32<kRowRor8>(li), lr3 = dpp_i32<kRowRor12>(li);
+    const int ng = sg.groups();
+
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * 4;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * 16;
+    double* __restrict__ mss = io.mss + trial * T * 4;
+    double* __restrict__ Pss = io.Pss + trial * T * 16;
+
+    Vec<4> ms;
+    load_vec<4>(mfs + (T - 1) * 4, ms);
+    double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, li, lj);
+    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
+    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+
+    Vec<4> mf; Sym<4> Pf;
+    if (T >= 2) { load_vec<4>(mfs + (T - 2) * 4, mf); load_sym<4>(Pfs + (T - 2) * 16, Pf); }
+    for (int64_t t = T - 2; t >= 0; t--) {
+        // prefetch the next (earlier) filtering result while this step computes
+        Vec<4> mf_n = mf; Sym<4> Pf_n = Pf;
+        if (t >= 1) { load_vec<4>(mfs + (t - 1) * 4, mf_n); load_sym<4>(Pfs + (t - 1) * 16, Pf_n); }
+        Mat<4> PG;
+        pinv_gamma<4>(Pf, gamma, PG);
+        CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j++) gl[i * 4 + j] = PG.a[i][j];
+        wave_lds_fence();
+        const double gr0 = gl[li * 4 + li], gr1 = gl[lr1 * 4 + li], gr2 = gl[lr2 * 4 + li], gr3 = gl[lr3 * 4 + li];
+        const double gc0 = gl[0 * 4 + lj], gc1 = gl[1 * 4 + lj], gc2 = gl[2 * 4 + lj], gc3 = gl[3 * 4 + lj];
+        wave_lds_fence();
+
+        Vec<4> tm = ms, am, km;
+        double tP = Ps, aP = 0.0, kP;
+        CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+#pragma unroll 1
+        for (int stage = 0; stage < 4; stage++) {
+            coop4_cd_sgp_rhs<SM>(model, sg, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
+            CGP_UNROLL for (int i = 0; i < 4; i++) {
+                double s = km.v[i];
+                CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);
+                km.v[i] = s;                                                                        // _m + G^T (m - mf)
+            }
+            double tij = gr0 * tP;                                                                  // (G^T P)[i][j]
+            tij = fma(gr1, dpp_f64<kRowRor4>(tP), tij);
+            tij = fma(gr2, dpp_f64<kRowRor8>(tP), tij);
+            tij = fma(gr3, dpp_f64<kRowRor12>(tP), tij);
+            double tji = gc0 * dpp_f64<kQuadBcast0>(tP);                                            // (P G)[i][j] = (G^T P)[j][i]
+            tji = fma(gc1, dpp_f64<kQuadBcast1>(tP), tji);
+            tji = fma(gc2, dpp_f64<kQuadBcast2>(tP), tji);
+            tji = fma(gc3, dpp_f64<kQuadBcast3>(tP), tji);
+            kP = (kP + (tij + tji)) - 2.0 * gam;
+            const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+            const double half = (stage == 2) ? 1.0 : 0.5;
+            CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = ms.v[i] + (dt * km.v[i]) * half; }
+            aP = fma(wgt, kP, aP);
+            tP = Ps + (dt * kP) * half;
+        }
+        CGP_UNROLL for (int i = 0; i < 4; i++) ms.v[i] = ms.v[i] + (dt * am.v[i]) / 6.0;
+        Ps = Ps + (dt * aP) / 6.0;
+        if (lane < 16) Pss[t * 16 + lane] = Ps;
+        if (lane == 0) store_vec<4>(mss + t * 4, ms);
+        mf = mf_n; Pf = Pf_n;
+    }
+}
+
+template <class DM>
+inline int launch_sgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL((sgp4_coop_kernel<DM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+template <class SM>
+inline int launch_cdsgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL((cdsgp4_coop_kernel<SM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+template <class SM>
+inline int launch_cdsgps4_coop(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL((cdsgps4_coop_kernel<SM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace cgp
