@@ -48,6 +48,45 @@ CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane
     return tot;
 }
 
+// The sigma points a lane owns never change (lane g always evaluates group g), so they are read from LDS once into
+// registers: up to kCacheM members of (xi[4], w).  `ok` is wave-uniform: it is false when the set has more than 64
+// groups or a group has more members than the cache holds, and the kernels then read the staged set every step.
+constexpr int kCacheM = 3;
+struct LanePoints {
+    double xi[kCacheM][4], w[kCacheM];
+    int n;
+    bool ok;
+    CGP_DEV void load(const SigmaSet& sg, int lane) {
+        const int ng = sg.groups();
+        n = 0;
+        int longest = 0;
+        CGP_UNROLL for (int k = 0; k < kCacheM; k++) { w[k] = 0.0; CGP_UNROLL for (int j = 0; j < 4; j++) xi[k][j] = 0.0; }
+        if (lane < ng) {
+            const int p0 = sg.template begin<true>(lane), p1 = sg.template end<true>(lane);
+            longest = p1 - p0;
+            n = longest < kCacheM ? longest : kCacheM;
+            CGP_UNROLL for (int k = 0; k < kCacheM; k++)
+                if (k < n) {
+                    w[k] = sg.template weight<true>(p0 + k);
+                    CGP_UNROLL for (int j = 0; j < 4; j++) xi[k][j] = sg.template coord<true>((p0 + k) * 4 + j);
+                }
+        }
+        CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
+            const int o = __shfl_xor(longest, delta, 64);
+            longest = o > longest ? o : longest;
+        }
+        ok = ng <= 64 && longest <= kCacheM;
+    }
+    // chi = m + L xi[k]
+    CGP_DEV void point(int k, const Vec<4>& m, const Sym<4>& L, Vec<4>& chi) const {
+        CGP_UNROLL for (int i = 0; i < 4; i++) {
+            double t = L(i, 0) * xi[k][0];
+            CGP_UNROLL for (int j = 1; j <= i; j++) t = fma(L(i, j), xi[k][j], t);
+            chi.v[i] = m.v[i] + t;
+        }
+    }
+};
+
 // Shared prologue of the filter kernels: outputs, measurement chunking and NLL latch live in the kernels themselves.
 struct Coop4FilterOut {
     double* __restrict__ mfs; double* __restrict__ Pfs; double* __restrict__ nll;
@@ -102,6 +141,8 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
     Coop4FilterOut out;
     out.init(io, trial);
     const int ng = sg.groups();
+    LanePoints pts;
+    pts.load(sg, lane);
 
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -117,6 +158,27 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
             cholesky<4>(Pr, L, inv);
             double acc[15];
             CGP_UNROLL for (int k = 0; k < 15; k++) acc[k] = 0.0;
+            if (pts.ok) {
+                if (pts.n > 0) {
+                    Vec<4> chi, f;
+                    pts.point(0, m, L, chi);
+                    typename DM::Pre pre;
+                    model.precompute(chi.v[DM::IVC], pre);
+                    CGP_UNROLL for (int k = 0; k < kCacheM; k++) {
+                        if (k < pts.n) {
+                            if (k > 0) pts.point(k, m, L, chi);
+                            model.mean_pre(chi, pre, f);
+                            const double w = pts.w[k];
+                            acc[0] += w;
+                            double wf[4];
+                            CGP_UNROLL for (int i = 0; i < 4; i++) { wf[i] = w * f.v[i]; acc[1 + i] += wf[i]; }
+                            CGP_UNROLL for (int i = 0; i < 4; i++)
+                                CGP_UNROLL for (int j = 0; j <= i; j++)
+                                    acc[5 + Sym<4>::idx(i, j)] = fma(wf[i], f.v[j], acc[5 + Sym<4>::idx(i, j)]);
+                        }
+                    }
+                }
+            } else
             for (int g = lane; g < ng; g += 64) {
                 int p = sg.template begin<true>(g);
                 const int pe = sg.template end<true>(g);
@@ -157,13 +219,34 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
 // One evaluation of the sigma-point moment ODE (filters_smoothers.py:124-137) at (m, distributed P):
 // km[l] = E[a_l] (replicated) and this lane's entry of C + C^T + gamma with C = E[(chi - m) a^T].
 template <class SM>
-CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, int ng, double* red, int lane, int cij_idx, int cji_idx,
-                              double gam, const Vec<4>& m, double P, Vec<4>& km, double& kP) {
+CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, const LanePoints& pts, int ng, double* red, int lane,
+                              int cij_idx, int cji_idx, double gam, const Vec<4>& m, double P, Vec<4>& km, double& kP) {
     Sym<4> Pr, L; Vec<4> inv;
     coop4_gather(P, Pr);
     cholesky<4>(Pr, L, inv);
     double acc[20];
     CGP_UNROLL for (int k = 0; k < 20; k++) acc[k] = 0.0;
+    if (pts.ok) {
+        if (pts.n > 0) {
+            Vec<4> chi, a;
+            pts.point(0, m, L, chi);
+            typename SM::Pre pre;
+            model.precompute(chi.v[SM::IVC], pre);
+            CGP_UNROLL for (int k = 0; k < kCacheM; k++) {
+                if (k < pts.n) {
+                    if (k > 0) pts.point(k, m, L, chi);
+                    model.drift_pre(chi, pre, a);
+                    const double w = pts.w[k];
+                    double wa[4];
+                    CGP_UNROLL for (int i = 0; i < 4; i++) { wa[i] = w * a.v[i]; acc[i] += wa[i]; }
+                    CGP_UNROLL for (int i = 0; i < 4; i++) {
+                        const double ci = chi.v[i] - m.v[i];
+                        CGP_UNROLL for (int j = 0; j < 4; j++) acc[4 + i * 4 + j] = fma(ci, wa[j], acc[4 + i * 4 + j]);
+                    }
+                }
+            }
+        }
+    } else
     for (int g = lane; g < ng; g += 64) {
         int p = sg.template begin<true>(g);
         const int pe = sg.template end<true>(g);
@@ -218,6 +301,8 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
     Coop4FilterOut out;
     out.init(io, trial);
     const int ng = sg.groups();
+    LanePoints pts;
+    pts.load(sg, lane);
 
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -232,7 +317,7 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
             CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
-                coop4_cd_sgp_rhs<SM>(model, sg, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
+                coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
                 const double half = (stage == 2) ? 1.0 : 0.5;
                 CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = u.v[i] + (dt * km.v[i]) * half; }
@@ -280,6 +365,8 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
     // source rows of the three row rotations, discovered by rotating the row index itself
     const int lr1 = dpp_i32<kRowRor4>(li), lr2 = dpp_i32<kRowRor8>(li), lr3 = dpp_i32<kRowRor12>(li);
     const int ng = sg.groups();
+    LanePoints pts;
+    pts.load(sg, lane);
 
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * 4;
@@ -312,7 +399,7 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
         CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
 #pragma unroll 1
         for (int stage = 0; stage < 4; stage++) {
-            coop4_cd_sgp_rhs<SM>(model, sg, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
+            coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
             CGP_UNROLL for (int i = 0; i < 4; i++) {
                 double s = km.v[i];
                 CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);
