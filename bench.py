@@ -87,18 +87,32 @@ def cpu_baseline(wl, target_seconds=12.0):
     """The oracle's C port (oracle/c/port.c, OpenMP over trials) timed on the host cores on a bounded sample of the
     SAME workload: as many trials (full T) as fit ~target_seconds, at least one per thread."""
     from oracle import port
+    import copy
     k = wl['kind']
-    if k != 'ekf':
-        return None
     threads = port.num_threads()
     T = wl['T']
     ys = wl['ys']
     n = min(ys.shape[0], max(threads, 8))
+    drift_g = copy.copy(wl['drift'])
+    drift_g.gamma = wl['disp'].outer()
+    label = {'ekf': 'EKF+EKS', 'sgp': 'sgp_filter+sgp_smoother', 'harmonic': 'sgp_filter+sgp_smoother (cubature, d=8)',
+             'cd_sgp': 'cd_sgp_filter+cd_sgp_smoother', 'cd_ekf': 'cd_ekf+cd_eks'}[k]
 
     def once(nn):
         t0 = time.perf_counter()
-        f = port.filter(port.F_EKF, wl['disc'], None, wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys[:nn])
-        port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], f[0], f[1])
+        a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys[:nn])
+        if k == 'ekf':
+            f = port.filter(port.F_EKF, wl['disc'], None, *a)
+            port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], f[0], f[1])
+        elif k in ('sgp', 'harmonic'):
+            f = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a)
+            port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], f[0], f[1])
+        elif k == 'cd_sgp':
+            f = port.filter(port.F_CD_SGP, drift_g, wl['sgps'], *a)
+            port.smoother(port.S_CD_SGP, drift_g, wl['sgps'], wl['dt'], f[0], f[1])
+        else:
+            f = port.filter(port.F_CD_EKF, drift_g, None, *a)
+            port.smoother(port.S_CD_EKS, drift_g, None, wl['dt'], f[0], f[1])
         return time.perf_counter() - t0
     t = once(n)                                   # warm-up + calibration
     per_trial = t / n
@@ -107,7 +121,7 @@ def cpu_baseline(wl, target_seconds=12.0):
     n2 = min(n2, ys.shape[0])
     best = min(once(n2) for _ in range(2))
     return {"value": n2 * T / best, "unit": "trial-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n2} of {ys.shape[0]} trials x T={T} (EKF+EKS, oracle/c/port.c, OpenMP, best of 2, {best:.2f} s)"}
+            "sample": f"{n2} of {ys.shape[0]} trials x T={T} ({label}, oracle/c/port.c, OpenMP, best of 2, {best:.2f} s)"}
 
 
 def main():

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Times every BASELINE.json configuration at its full per-GPU size (C1 plumbing case via a small script).
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/configs.jsonl
+: > $OUT
+run() { echo "# $*" >> $OUT; python bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" >> $OUT 2>/dev/null || echo '{"error": true}' >> $OUT; }
+run --workload ekf
+run --workload sgp
+run --workload cd_sgp --batch 512 --T 50000
+run --workload harmonic
+run --workload cd_ekf
+python - <<'PY'
+import json, time, numpy as np, torch
+import bench
+from chirpgp_amd import filters_smoothers as fs
+for l in open('gpurun_out/configs.jsonl'):
+    if l.startswith('#'): print(l.strip(), end='  '); continue
+    d = json.loads(l)
+    if 'error' in d: print('ERROR'); continue
+    k = d['kernels']
+    print(f"{d['value']:.3e} steps/s  filter {k['filter_ms']:.2f} ms ({k['filter_GBs']:.0f} GB/s)  smoother {k['smoother_ms']:.2f} ms ({k['smoother_GBs']:.0f} GB/s)")
+# C1: linear KF + RTS, d = 4, T = 1000, B = 1 (frozen-frequency chirp LCD)
+wl = bench.make_workload(1, 1000)
+disc = wl['disc']
+F = np.stack([disc(np.eye(4)[j] * 0 + np.array([0, 0, 7., 0]) + np.eye(4)[j] * (0 if j == 2 else 1), 1e-3)[0] - disc(np.array([0, 0, 7., 0]), 1e-3)[0] for j in range(4)], axis=1)
+F[:, 2] = disc(np.array([0, 0, 8., 0]), 1e-3)[0] - disc(np.array([0, 0, 7., 0]), 1e-3)[0]
+Sigma = disc(np.array([0, 0, 7., 0]), 1e-3)[1]
+ys = torch.from_numpy(wl['ys'][0]).cuda()
+for _ in range(3):
+    r = fs.kf(F, Sigma, wl['H'], wl['Xi'], wl['m0'], wl['P0'], ys); s = fs.rts(F, Sigma, r[0], r[1])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    r = fs.kf(F, Sigma, wl['H'], wl['Xi'], wl['m0'], wl['P0'], ys); s = fs.rts(F, Sigma, r[0], r[1])
+torch.cuda.synchronize()
+print(f"# C1 kf+rts d=4 T=1000 B=1: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per pass (launch-latency bound)")
+PY
