@@ -348,3 +348,46 @@ def test_sigma_point_sweep_nll_only():
     for kw in (WAVE, THREAD):
         got = fs.sgp_filter(disc, sg, H, 0.1, m0, P0, 1e-3, ys, nll_final_only=True, want=(False, False, True), **kw)[2]
         cs.assert_close(got, want, RTOL, 'sweep nll')
+
+
+def test_c_abi_argument_errors():
+    """Misuse through the C-ABI returns CGP_E_ARG / CGP_E_UNSUPPORTED with a message, never a launch."""
+    import ctypes as C
+    import torch
+    from chirpgp_amd import _engine as E
+    lib, ctx = E.load_library(), E.context()
+    d = 4
+    params = torch.zeros(5, dtype=torch.float64, device='cuda')
+    buf = torch.zeros(64, dtype=torch.float64, device='cuda')
+    model = E.CgpModel(E.M_HARMONIC_LCD, d, 1, 5, params.data_ptr(), 0, None, 0)
+    init = E.CgpInit(buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0)
+    args = (C.byref(init), 0.1, buf.data_ptr(), 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
+    assert lib.cgp_filter(ctx, E.F_CD_EKF, C.byref(model), None, *args) == -1            # SDE method, discrete model
+    assert b'SDE model' in lib.cgp_last_error(ctx)
+    assert lib.cgp_filter(ctx, E.F_SGP, C.byref(model), None, *args) == -1               # sigma method without points
+    assert lib.cgp_filter(ctx, 99, C.byref(model), None, *args) == -1
+    bad = E.CgpModel(E.M_HARMONIC_LCD, 6, 1, 5, params.data_ptr(), 0, None, 0)           # d inconsistent with n_harm
+    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(bad), None, *args) == -1
+    lin9 = E.CgpModel(E.M_LINEAR, 9, 0, 162, params.data_ptr(), 0, None, 0)
+    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(lin9), None, *args) == -2                # not compiled in
+    lin7 = E.CgpModel(E.M_LINEAR, 7, 0, 98, params.data_ptr(), 0, None, 0)
+    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(lin7), None, *args) == -2
+    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(model), None, C.byref(init), 0.1, buf.data_ptr(), 0, 4, None, None, None, 0, None) == 0   # B = 0
+    from chirpgp_amd import filters_smoothers as fs
+    with pytest.raises(NotImplementedError):
+        fs.kf(np.eye(9), np.eye(9), np.ones(9), 0.1, np.zeros(9), np.eye(9), np.zeros(5))
+
+
+def test_filter_means_only_large_batch():
+    """The CRLB job's shape (tetralith/jobs/crlb_ekf.py): many short records, only the filtering means kept."""
+    from chirpgp_amd.models import model_chirp, disc_chirp_lcd
+    from oracle import port
+    fs = _fs()
+    _, _, m0, P0, H = model_chirp(0.1, 0.1, 1., 1., 0.1)
+    disc = disc_chirp_lcd(0.1, 0.1, 1., 1.)
+    B, T = 3000, 50
+    ys = np.random.default_rng(1).standard_normal((B, T))
+    mfs, Pfs, nll = fs.ekf(disc, H, 0.1, m0, P0, 0.01, ys, want=(True, False, False))
+    assert Pfs is None and nll is None and mfs.shape == (B, T, 4)
+    want = port.filter(port.F_EKF, disc, None, H, 0.1, m0, P0, 0.01, ys[::100])[0]
+    cs.assert_close(mfs[::100], want, RTOL, 'means only')
