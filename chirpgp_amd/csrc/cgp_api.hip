@@ -182,6 +182,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     case CGP_M_LINEAR_SDE:   rc = dispatch_filter_sde_linear(method, model->d, wave, io, ma, st); break;
     case CGP_M_HARMONIC_SDE:
         if (method == CGP_F_CD_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4_cdsgp(io, ma, st);
+        else if (method == CGP_F_CD_EKF && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4_cdekf(io, ma, st);
         else rc = dispatch_filter_sde_harm(method, model->n_harm, wave, io, ma, st);
         break;
     case CGP_M_KPT:          rc = dispatch_filter_kpt(model->n_harm, wave, io, ma, st); break;
@@ -220,6 +221,7 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     case CGP_M_LINEAR_SDE:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;
     case CGP_M_HARMONIC_SDE:
         if (method == CGP_S_CD_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdsgp(io, ma, st);
+        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdeks(io, ma, st);
         else rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st);
         break;
     default: rc = CGP_E_ARG;

@@ -312,6 +312,8 @@ int dispatch_filter_coop4(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop4_cdsgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_coop4_cdsgp(const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_coop4_cdekf(const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_coop4_cdeks(const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_disc_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_disc_harm(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_sde_linear(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
