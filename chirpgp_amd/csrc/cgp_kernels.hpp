@@ -236,11 +236,7 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
             a = t;
         }
         // suffix scan over lanes: a_l <- a_l o a_{l+1} o ... o a_63
-        CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
-            Affine<D> o;
-            affine_shfl_down<D>(a, delta, o);
-            if (lane + delta < 64) affine_compose<D>(a, o);
-        }
+        CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) affine_compose_from_lane<D>(a, delta, lane + delta < 64);
         Vec<D> xm = ms; Sym<D> xP = Ps;
         if constexpr (K == 1) {
             // one step per lane: the scanned map already contains the lane's own step

@@ -413,24 +413,40 @@ template <int D> CGP_DEV void affine_identity(Affine<D>& e) {
     CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) e.C.a[i] = 0.0;
 }
 
-// a <- a o b : first b (the later time steps), then a.
+// a <- a o b : first b (the later time steps), then a.  Written row by row so that only one D-vector of the
+// intermediate product G_a C_b is live at a time and the new G overwrites the old one row by row: for d = 8 an affine
+// map is 108 doubles and the register file holds 256 of them.
 template <int D> CGP_DEV void affine_compose(Affine<D>& a, const Affine<D>& b) {
-    Vec<D> c; Mat<D> T, G;
+    // c <- G_a c_b + c_a
     CGP_UNROLL for (int i = 0; i < D; i++) {
         double s = a.c.v[i];
         CGP_UNROLL for (int k = 0; k < D; k++) s = fma(a.G.a[i][k], b.c.v[k], s);
-        c.v[i] = s;
+        a.c.v[i] = s;
     }
-    mul_dense_sym<D>(a.G, b.C, T);                      // T = G_a C_b
-    Sym<D> Cn;
-    mul_nt_sym_add<D>(T, a.G, a.C, Cn);                 // G_a C_b G_a^T + C_a
-    CGP_UNROLL for (int i = 0; i < D; i++)
+    // C <- G_a C_b G_a^T + C_a   (row i of T = G_a C_b, then its products with rows j <= i of G_a)
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double t[D];
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            double s = a.G.a[i][0] * b.C(0, j);
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(a.G.a[i][k], b.C(k, j), s);
+            t[j] = s;
+        }
+        CGP_UNROLL for (int j = 0; j <= i; j++) {
+            double s = t[0] * a.G.a[j][0];
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(t[k], a.G.a[j][k], s);
+            a.C(i, j) = s + a.C(i, j);
+        }
+    }
+    // G <- G_a G_b, row by row in place
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double r[D];
         CGP_UNROLL for (int j = 0; j < D; j++) {
             double s = a.G.a[i][0] * b.G.a[0][j];
             CGP_UNROLL for (int k = 1; k < D; k++) s = fma(a.G.a[i][k], b.G.a[k][j], s);
-            G.a[i][j] = s;
+            r[j] = s;
         }
-    a.G = G; a.c = c; a.C = Cn;
+        CGP_UNROLL for (int j = 0; j < D; j++) a.G.a[i][j] = r[j];
+    }
 }
 
 CGP_DEV double shfl_down_f64(double x, int delta) { return __shfl_down(x, delta, 64); }
@@ -443,25 +459,92 @@ template <int D> CGP_DEV void affine_shfl_down(const Affine<D>& e, int delta, Af
     CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) o.C.a[i] = shfl_down_f64(e.C.a[i], delta);
 }
 
-// The element of one time step from its (mp, Pp, DT).
+// a <- a o (the map held by lane + delta), fetching that map piecewise so that it is never resident as a whole:
+// first its c and C (D + D(D+1)/2 doubles), then, once the new c and C are done, its G.  `active` lanes compose, the
+// others only take part in the shuffles.  The scheduling barriers keep the compiler from hoisting the second batch of
+// shuffles above the first phase (which would put both maps in registers at once: 216 doubles at d = 8).
+template <int D> CGP_DEV void affine_compose_from_lane(Affine<D>& a, int delta, bool active) {
+    {
+        Vec<D> bc; Sym<D> bC;
+        CGP_UNROLL for (int i = 0; i < D; i++) bc.v[i] = shfl_down_f64(a.c.v[i], delta);
+        CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) bC.a[i] = shfl_down_f64(a.C.a[i], delta);
+        if (active) {
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                double s = a.c.v[i];
+                CGP_UNROLL for (int k = 0; k < D; k++) s = fma(a.G.a[i][k], bc.v[k], s);
+                a.c.v[i] = s;
+            }
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                double t[D];
+                CGP_UNROLL for (int j = 0; j < D; j++) {
+                    double s = a.G.a[i][0] * bC(0, j);
+                    CGP_UNROLL for (int k = 1; k < D; k++) s = fma(a.G.a[i][k], bC(k, j), s);
+                    t[j] = s;
+                }
+                CGP_UNROLL for (int j = 0; j <= i; j++) {
+                    double s = t[0] * a.G.a[j][0];
+                    CGP_UNROLL for (int k = 1; k < D; k++) s = fma(t[k], a.G.a[j][k], s);
+                    a.C(i, j) = s + a.C(i, j);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        Mat<D> bG;
+        CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) bG.a[i][j] = shfl_down_f64(a.G.a[i][j], delta);
+        if (active) {
+            CGP_UNROLL for (int i = 0; i < D; i++) {
+                double r[D];
+                CGP_UNROLL for (int j = 0; j < D; j++) {
+                    double s = a.G.a[i][0] * bG.a[0][j];
+                    CGP_UNROLL for (int k = 1; k < D; k++) s = fma(a.G.a[i][k], bG.a[k][j], s);
+                    r[j] = s;
+                }
+                CGP_UNROLL for (int j = 0; j < D; j++) a.G.a[i][j] = r[j];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The element of one time step from its (mp, Pp, DT).  Row c of G = (Pp^{-1} DT)^T is the solution for the right-hand
+// side DT[:, c], so the gain is produced row by row with no transposed copy; C = Pf - G Pp G^T is then formed row by
+// row from Pp (DT is dead after the solves).
 template <int D>
 CGP_DEV void affine_from_prediction(const Vec<D>& mf, const Sym<D>& Pf, const Vec<D>& mp, const Sym<D>& Pp, const Mat<D>& DT,
                                     Affine<D>& e) {
-    smoother_gain<D>(DT, Pp, e.G);
+    {
+        Sym<D> L; Vec<D> inv;
+        cholesky<D>(Pp, L, inv);
+        CGP_UNROLL for (int c = 0; c < D; c++) {
+            Vec<D> col;
+            CGP_UNROLL for (int i = 0; i < D; i++) col.v[i] = DT.a[i][c];
+            cho_solve_vec<D>(L, inv, col);
+            CGP_UNROLL for (int i = 0; i < D; i++) e.G.a[c][i] = col.v[i];
+        }
+    }
     CGP_UNROLL for (int i = 0; i < D; i++) {
         double s = mf.v[i];
         CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-e.G.a[i][k], mp.v[k], s);
         e.c.v[i] = s;
     }
-    CGP_UNROLL for (int i = 0; i < D; i++)
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double t[D];
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            double s = e.G.a[i][0] * Pp(0, j);
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(e.G.a[i][k], Pp(k, j), s);
+            t[j] = s;
+        }
         CGP_UNROLL for (int j = 0; j <= i; j++) {
             double s = Pf(i, j);
-            CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-e.G.a[j][k], DT.a[k][i], s);      // (G DT)(j, i)
+            CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-t[k], e.G.a[j][k], s);
             e.C(i, j) = s;
         }
+    }
 }
 
-// Applies a composed map to the carry.
+// Applies a map to a state, row by row.
 template <int D>
 CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps, Vec<D>& xm, Sym<D>& xP) {
     CGP_UNROLL for (int i = 0; i < D; i++) {
@@ -469,9 +552,19 @@ CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps
         CGP_UNROLL for (int k = 0; k < D; k++) s = fma(e.G.a[i][k], ms.v[k], s);
         xm.v[i] = s;
     }
-    Mat<D> T;
-    mul_dense_sym<D>(e.G, Ps, T);
-    mul_nt_sym_add<D>(T, e.G, e.C, xP);
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double t[D];
+        CGP_UNROLL for (int j = 0; j < D; j++) {
+            double s = e.G.a[i][0] * Ps(0, j);
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(e.G.a[i][k], Ps(k, j), s);
+            t[j] = s;
+        }
+        CGP_UNROLL for (int j = 0; j <= i; j++) {
+            double s = t[0] * e.G.a[j][0];
+            CGP_UNROLL for (int k = 1; k < D; k++) s = fma(t[k], e.G.a[j][k], s);
+            xP(i, j) = s + e.C(i, j);
+        }
+    }
 }
 
 // Per-lane element producers (one lane = one time step, so the fan of the sigma-point variant is a serial loop).
