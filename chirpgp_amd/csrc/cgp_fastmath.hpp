@@ -165,7 +165,7 @@ CGP_DEV double fast_exp_core(double x) {
 // sin / cos for a WAVE-UNIFORM argument: the fallback test is one scalar compare on the exponent bits.
 CGP_DEV void fast_sincos_uniform(double x, double& sn, double& cs) {
     const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffff;
-    if (hx >= 0x40F86A00) {            // |x| >= 1e5, inf, NaN
+    if (__builtin_expect(hx >= 0x40F86A00, 0)) {            // |x| >= 1e5, inf, NaN (out of line: rare)
         sincos(x, &sn, &cs);
         return;
     }
@@ -208,7 +208,7 @@ CGP_DEV void fast_sincos_uniform(double x, double& sn, double& cs) {
 // naive form of models.py:50 is evaluated as is, overflow behaviour included.
 CGP_DEV void softplus_pair_uniform(double x, double& sp, double& dsp) {
     const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    if (hx >= 0x40180000 && hx < 0x4085E000) {           // 6.0 <= x < 700.0 (positive doubles order like their bits)
+    if (__builtin_expect(hx >= 0x40180000 && hx < 0x4085E000, 1)) {   // 6.0 <= x < 700.0 (positive doubles order like their bits)
         const double t = fast_exp_core(-x);
         double p = -1.0 / 6.0;
         p = horner(p, t, 0.2);
