@@ -19,9 +19,11 @@ __all__ = ['kf', 'rts', 'ekf', 'ekf_for_kpt', 'eks', 'cd_ekf', 'cd_eks',
            'sgp_filter', 'sgp_smoother', 'cd_sgp_filter', 'cd_sgp_smoother']
 
 
-def _discrete(cond_m_cov):
+def _discrete(cond_m_cov, dt=None):
     if isinstance(cond_m_cov, M.DiscreteModel):
         return cond_m_cov
+    if hasattr(cond_m_cov, 'at') and dt is not None:          # dt-dependent linear descriptors (disc_m32)
+        return cond_m_cov.at(dt)
     raise TypeError('cond_m_cov must be a chirpgp_amd.models descriptor (e.g. disc_chirp_lcd(...), '
                     'linear_cond_m_cov(F, Sigma)); arbitrary Python callables cannot run inside the HIP kernels')
 
@@ -67,7 +69,7 @@ def rts(F, Sigma, mfs, Pfs, **kw):
 
 def ekf(cond_m_cov, H, Xi, m0, P0, dt, ys, **kw):
     """Extended Kalman filter (filters_smoothers.py:222-264)."""
-    return E.run_filter(E.F_EKF, _discrete(cond_m_cov), None, None, H, Xi, m0, P0, dt, ys, **kw)
+    return E.run_filter(E.F_EKF, _discrete(cond_m_cov, dt), None, None, H, Xi, m0, P0, dt, ys, **kw)
 
 
 def ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw):
@@ -83,7 +85,7 @@ def ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw):
 
 def eks(cond_m_cov, mfs, Pfs, dt, **kw):
     """Extended Kalman smoother (filters_smoothers.py:317-349)."""
-    return E.run_smoother(E.S_EKS, _discrete(cond_m_cov), None, None, dt, mfs, Pfs, **kw)
+    return E.run_smoother(E.S_EKS, _discrete(cond_m_cov, dt), None, None, dt, mfs, Pfs, **kw)
 
 
 def cd_ekf(a, b, H, Xi, m0, P0, dt, ys, **kw):
@@ -98,13 +100,13 @@ def cd_eks(a, b, mfs, Pfs, dt, **kw):
 
 def sgp_filter(cond_m_cov, sgps, H, Xi, m0, P0, dt, ys, **kw):
     """Sigma-point (Gauss-Hermite / cubature) filter on a discretised model (filters_smoothers.py:446-490)."""
-    spec = _discrete(cond_m_cov)
+    spec = _discrete(cond_m_cov, dt)
     return E.run_filter(E.F_SGP, spec, _sgps(sgps, spec.d), None, H, Xi, m0, P0, dt, ys, **kw)
 
 
 def sgp_smoother(cond_m_cov, sgps, mfs, Pfs, dt, **kw):
     """Sigma-point smoother (filters_smoothers.py:493-531)."""
-    spec = _discrete(cond_m_cov)
+    spec = _discrete(cond_m_cov, dt)
     return E.run_smoother(E.S_SGP, spec, _sgps(sgps, spec.d), None, dt, mfs, Pfs, **kw)
 
 

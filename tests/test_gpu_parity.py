@@ -391,3 +391,52 @@ def test_filter_means_only_large_batch():
     assert Pfs is None and nll is None and mfs.shape == (B, T, 4)
     want = port.filter(port.F_EKF, disc, None, H, 0.1, m0, P0, 0.01, ys[::100])[0]
     cs.assert_close(mfs[::100], want, RTOL, 'means only')
+
+
+@pytest.mark.parametrize('kw', SHAPES)
+def test_per_trial_measurement_model(kw):
+    """H, Xi, m0, P0 all with a leading batch axis (strides in cgp_init), through the cooperative and generic kernels."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    import copy
+    fs = _fs()
+    B, T = 5, 260
+    rng = np.random.default_rng(12)
+    params = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * rng.uniform(0.9, 1.1, size=(B, 6))
+    drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+    Hb = np.tile(H, (B, 1)) * rng.uniform(0.8, 1.2, size=(B, 1)) + 0.05 * rng.standard_normal((B, 4))
+    Xib = rng.uniform(0.05, 0.2, size=B)
+    ys = np.stack([cs.chirp_measurements(T, 400 + i)[2] for i in range(B)])
+    sg = SigmaPoints.gauss_hermite(4, 3)
+    dg = copy.copy(drift)
+    dg.gamma = disp.outer()
+    pairs = [
+        (lambda: fs.ekf(disc, Hb, Xib, m0, P0, 1e-3, ys, **kw), lambda: port.filter(port.F_EKF, disc, None, Hb, Xib, m0, P0, 1e-3, ys)),
+        (lambda: fs.sgp_filter(disc, sg, Hb, Xib, m0, P0, 1e-3, ys, **kw), lambda: port.filter(port.F_SGP, disc, sg, Hb, Xib, m0, P0, 1e-3, ys)),
+        (lambda: fs.cd_ekf(drift, disp, Hb, Xib, m0, P0, 1e-3, ys, **kw), lambda: port.filter(port.F_CD_EKF, dg, None, Hb, Xib, m0, P0, 1e-3, ys)),
+        (lambda: fs.cd_sgp_filter(drift, disp, sg, Hb, Xib, m0, P0, 1e-3, ys[:, :80], **kw),
+         lambda: port.filter(port.F_CD_SGP, dg, sg, Hb, Xib, m0, P0, 1e-3, ys[:, :80])),
+    ]
+    for i, (got, want) in enumerate(pairs):
+        for g, w, n in zip(got(), want(), ('mfs', 'Pfs', 'nll')):
+            cs.assert_close(g, w, RTOL, f'pair{i}.{n}')
+    # NLL-only through the cooperative sigma-point kernel
+    last = fs.sgp_filter(disc, sg, Hb, Xib, m0, P0, 1e-3, ys, nll_final_only=True, want=(False, False, True), **kw)[2]
+    cs.assert_close(last, port.filter(port.F_SGP, disc, sg, Hb, Xib, m0, P0, 1e-3, ys, nll_final_only=True)[2], RTOL, 'nll-only')
+
+
+def test_disc_m32_matches_kf():
+    """models.py:408-416: the exact Matern-3/2 discretisation as cond_m_cov gives the Kalman filter of its (F, Sigma)."""
+    from chirpgp_amd import models as pm
+    fs = _fs()
+    spec = pm.disc_m32(1.1, 2.2)
+    F, Sigma = spec(np.eye(2)[0], 1e-2)[0], spec(np.zeros(2), 1e-2)[1]
+    F = np.stack([spec(np.eye(2)[j], 1e-2)[0] for j in range(2)], axis=1)
+    ys = np.random.default_rng(2).standard_normal(200)
+    H, m0, P0 = np.array([1., 0.]), np.zeros(2), np.eye(2)
+    a = fs.ekf(spec, H, 0.5, m0, P0, 1e-2, ys)
+    b = fs.kf(F, Sigma, H, 0.5, m0, P0, ys)
+    for x, y in zip(a, b):
+        npt.assert_allclose(x, y, rtol=1e-12, atol=1e-14)
+    npt.assert_allclose(fs.eks(spec, a[0], a[1], 1e-2)[0], fs.rts(F, Sigma, b[0], b[1])[0], rtol=1e-12, atol=1e-14)
