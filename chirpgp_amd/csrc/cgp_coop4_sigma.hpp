@@ -25,11 +25,27 @@ CGP_DEV void coop4_gather(double P, Sym<4>& S) {
 }
 
 // Wave sum of R <= 32 per-lane partials; the totals stay in LDS at the returned pointer (tot[0..R-1]).
-// Same fixed summation order as wave_allreduce.
+// Same fixed summation order as wave_allreduce.  When only the first 32 lanes carry partials (`narrow`, wave-uniform:
+// at most 32 groups of sigma points, e.g. the 27 groups of Gauss-Hermite order 3 in d = 4) two lanes share a row --
+// lane (r, h) = (lane >> 1, lane & 1) sums entries [16 h, 16 h + 16) -- and all R <= 32 rows are done in ONE pass.
 template <int R>
-CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane) {
+CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane, bool narrow) {
     static_assert(R <= kRedChunk, "totals area holds kRedChunk doubles");
     double* tot = lds + kRedChunk * kRedLd;
+    if (narrow) {
+        CGP_UNROLL for (int k = 0; k < R; k++) lds[k * kRedLd + lane] = acc[k];
+        wave_lds_fence();
+        const int r = lane >> 1, h = lane & 1;
+        const double2* row = reinterpret_cast<const double2*>(lds + r * kRedLd + h * 16);
+        double s = 0.0;
+        if (r < R) {
+            CGP_UNROLL for (int j = 0; j < 8; j++) { const double2 v = row[j]; s += v.x; s += v.y; }
+        }
+        s += dpp_f64<kQuadSwap1>(s);
+        if (h == 0 && r < R) tot[r] = s;
+        wave_lds_fence();
+        return tot;
+    }
     const int r = lane >> 2, q = lane & 3;
     CGP_UNROLL for (int base = 0; base < R; base += kRedPass) {
         CGP_UNROLL for (int k = 0; k < kRedPass; k++)
@@ -199,7 +215,7 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
                     sigma_point<4, true>(m, L, sg, p, chi);
                 }
             }
-            const double* tot = coop_reduce_to_lds<15>(acc, red, lane);
+            const double* tot = coop_reduce_to_lds<15>(acc, red, lane, ng <= 32);
             const double wsum = tot[0];
             const double f0 = tot[1], f1 = tot[2], f2 = tot[3], f3 = tot[4];
             // Pp = E[f f^T + Sigma] - mp mp^T, this lane's entry
@@ -267,7 +283,7 @@ CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, const LanePoi
             sigma_point<4, true>(m, L, sg, p, chi);
         }
     }
-    const double* tot = coop_reduce_to_lds<20>(acc, red, lane);
+    const double* tot = coop_reduce_to_lds<20>(acc, red, lane, ng <= 32);
     km.v[0] = tot[0]; km.v[1] = tot[1]; km.v[2] = tot[2]; km.v[3] = tot[3];
     kP = (tot[cij_idx] + tot[cji_idx]) + gam;
 }
