@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
 
+    FastMathRegs fm;
+    fm.init();
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
@@ -157,10 +159,10 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
             const double y = readlane_f64(ychunk, slot);
             // ---- replicated scalar chain: rotation of the chirp block at frequency g(u2) (models.py:296-301) and N1
             double sp, dsp;
-            softplus_pair_uniform(u2, sp, dsp);
+            softplus_pair_uniform(fm, u2, sp, dsp);
             const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
             double s1, c1;
-            fast_sincos_uniform(dt * w, s1, c1);
+            fast_sincos_uniform(fm, dt * w, s1, c1);
             const double c = c1 * rho, s = s1 * rho;
             const double f0 = fma(c, u0, -s * u1), f1 = fma(s, u0, c * u1);
             const double f2 = fma(M0, u2, M1 * u3), f3 = fma(M2, u2, M3 * u3);

@@ -44,9 +44,10 @@ struct Coop4SdeJac {
         kc3 = (lj == 2) ? 1.0 : (lj == 3 ? -2.0 * gam : 0.0);
     }
     // Drift a(m) (replicated) and the lane's Jacobian entries at m (wave-uniform state).
-    CGP_DEV void eval(const Vec<4>& m, Vec<4>& a, double (&Jr)[4], double (&Jc)[4]) const {
+    template <class FM>
+    CGP_DEV void eval(const FM& fm, const Vec<4>& m, Vec<4>& a, double (&Jr)[4], double (&Jc)[4]) const {
         double sp, dsp;
-        softplus_pair_uniform(m.v[2], sp, dsp);
+        softplus_pair_uniform(fm, m.v[2], sp, dsp);
         const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         a.v[0] = -lam * m.v[0] - w * m.v[1];
         a.v[1] = w * m.v[0] - lam * m.v[1];
@@ -87,6 +88,8 @@ __global__ void __launch_bounds__(64) cdekf4_coop_kernel(FilterIO io, ModelArgs 
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
     Coop4SdeJac jac;
     jac.init(model, li, lj);
+    FastMathRegs fm;
+    fm.init();
     Coop4Meas meas;
     meas.load(io, trial, li, lj);
     const double gam = coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, li, lj);
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(64) cdekf4_coop_kernel(FilterIO io, ModelArgs 
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 double Jr[4], Jc[4];
-                jac.eval(tm, km, Jr, Jc);
+                jac.eval(fm, tm, km, Jr, Jc);
                 const double kP = coop4_lyapunov(Jr, Jc, tP, gam);                   // J P + P J^T + gamma
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
                 const double half = (stage == 2) ? 1.0 : 0.5;
@@ -146,6 +149,7 @@ __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArg
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
     Coop4SdeJac jac;
     jac.init(model, li, lj);
+    FastMathImm fm;   // 300 registers with the pinned table: the literal form is faster here
     Sym<4> gamma;
     load_sym<4>(ma.gamma + trial * ma.gamma_stride, gamma);
     const double gam = coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, li, lj);
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArg
 #pragma unroll 1
         for (int stage = 0; stage < 4; stage++) {
             double Jr[4], Jc[4];
-            jac.eval(tm, km, Jr, Jc);
+            jac.eval(fm, tm, km, Jr, Jc);
             CGP_UNROLL for (int i = 0; i < 4; i++) {
                 double s = km.v[i];
                 CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);

@@ -226,6 +226,87 @@ CGP_DEV void softplus_pair_uniform(double x, double& sp, double& dsp) {
     dsp = e * rcp_nr(z);
 }
 
+// The polynomial coefficients of the wave-uniform softplus / sincos pinned in VGPRs for the lifetime of a kernel.
+// Floating-point immediates are "free to rematerialise" for the compiler, so inside the step loop it rebuilds each
+// coefficient with s_mov + v_mov pairs right before the v_fma that uses it (18 v_mov + 9 hazard nops per step in the
+// cooperative EKF); passing every constant once through an empty asm makes it an opaque loop-invariant value that
+// simply stays in its register pair (46 pairs).
+struct FastMathRegs {
+    double ex[14];      // 1/13! ... 1/2!, 1, 1     (exp Taylor, Horner order)
+    double lp[6];       // -1/6, 1/5, -1/4, 1/3, -1/2, 1   (log1p)
+    double sn[8];       // -1/17!, 1/15!, ..., 1/3!
+    double cs[7];       // 1/16!, -1/14!, ..., 1/4!
+    double log2e, ln2hi, ln2lo, two_over_pi, pio2_1, pio2_2, pio2_3;
+    CGP_DEV static double pin(double x) { asm volatile("" : "+v"(x)); return x; }
+    CGP_DEV void init() {
+        const double ex_[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                                1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+        const double lp_[6] = {-1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5, 1.0};
+        const double sn_[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0,
+                               -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
+        const double cs_[7] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0,
+                               1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0};
+        CGP_UNROLL for (int i = 0; i < 14; i++) ex[i] = pin(ex_[i]);
+        CGP_UNROLL for (int i = 0; i < 6; i++) lp[i] = pin(lp_[i]);
+        CGP_UNROLL for (int i = 0; i < 8; i++) sn[i] = pin(sn_[i]);
+        CGP_UNROLL for (int i = 0; i < 7; i++) cs[i] = pin(cs_[i]);
+        log2e = pin(kLog2e); ln2hi = pin(kLn2Hi); ln2lo = pin(kLn2Lo);
+        two_over_pi = pin(kTwoOverPi); pio2_1 = pin(kPio2_1); pio2_2 = pin(kPio2_2); pio2_3 = pin(kPio2_3);
+    }
+};
+
+// Same call shape with the coefficients left as literals, for kernels with no registers to spare.
+struct FastMathImm {};
+CGP_DEV void softplus_pair_uniform(const FastMathImm&, double x, double& sp, double& dsp) { softplus_pair_uniform(x, sp, dsp); }
+CGP_DEV void fast_sincos_uniform(const FastMathImm&, double x, double& sn, double& cs) { fast_sincos_uniform(x, sn, cs); }
+
+// softplus_pair_uniform / fast_sincos_uniform with pinned coefficients (identical arithmetic).
+CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp) {
+    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    if (__builtin_expect(hx >= 0x40180000 && hx < 0x4085E000, 1)) {
+        const double nx = -x;
+        const double k = __builtin_rint(nx * R.log2e);
+        double r = fma(-k, R.ln2hi, nx);
+        r = fma(-k, R.ln2lo, r);
+        double p = R.ex[0];
+        CGP_UNROLL for (int i = 1; i < 14; i++) p = horner(p, r, R.ex[i]);
+        const double t = __builtin_amdgcn_ldexp(p, (int)k);
+        double q = R.lp[0];
+        CGP_UNROLL for (int i = 1; i < 6; i++) q = horner(q, t, R.lp[i]);
+        sp = fma(q, t, x);
+        dsp = rcp_nr(1.0 + t);
+        return;
+    }
+    const double e = fast_exp(x);
+    const double z = e + 1.0;
+    sp = fast_log_ge1(z);
+    dsp = e * rcp_nr(z);
+}
+CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, double& cs) {
+    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffff;
+    if (__builtin_expect(hx >= 0x40F86A00, 0)) {
+        sincos(x, &sn, &cs);
+        return;
+    }
+    const double n = __builtin_rint(x * R.two_over_pi);
+    double r = fma(-n, R.pio2_1, x);
+    r = fma(-n, R.pio2_2, r);
+    r = fma(-n, R.pio2_3, r);
+    const double r2 = r * r;
+    double ps = R.sn[0];
+    CGP_UNROLL for (int i = 1; i < 8; i++) ps = horner(ps, r2, R.sn[i]);
+    double pc = R.cs[0];
+    CGP_UNROLL for (int i = 1; i < 7; i++) pc = horner(pc, r2, R.cs[i]);
+    const double s0 = fma(-(r * r2), ps, r);
+    const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+    const int q = __builtin_amdgcn_readfirstlane((int)n);
+    const bool swap = (q & 1) != 0;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    const int sa = (q & 2) << 30, sb = ((q + 1) & 2) << 30;
+    sn = __hiloint2double(__double2hiint(a) ^ sa, __double2loint(a));
+    cs = __hiloint2double(__double2hiint(b) ^ sb, __double2loint(b));
+}
+
 // Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of
 // jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)) (filters_smoothers.py:44-45, 68).
 CGP_DEV double nll_increment(double S, double innov) {
