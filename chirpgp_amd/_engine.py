@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libchirpgp_hip.so')
 F_EKF, F_SGP, F_CD_EKF, F_CD_SGP, F_EKF_KPT = range(5)
 S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
 M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
-NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL = 0x1, 0x2, 0x4, 0x8, 0x10
+NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL, SIM_FIXED_X0 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 MAX_D = 8
 
 _vp = C.c_void_p
@@ -37,7 +37,7 @@ class CgpInit(C.Structure):
 
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
-           'cgp_gaussian_expectation', 'cgp_debug_math')
+           'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox')
 
 _lib = None
 _lock = threading.Lock()
@@ -73,6 +73,13 @@ def load_library():
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_debug_math.restype = C.c_int
         lib.cgp_debug_math.argtypes = [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp]
+        lib.cgp_simulate.restype = C.c_int
+        lib.cgp_simulate.argtypes = [_vp, C.POINTER(CgpModel), C.POINTER(CgpInit), C.c_double, C.c_uint64, C.c_int64,
+                                     C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_add_noise.restype = C.c_int
+        lib.cgp_add_noise.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]
+        lib.cgp_debug_philox.restype = C.c_int
+        lib.cgp_debug_philox.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, _vp]
         _lib = lib
         return lib
 
@@ -266,23 +273,7 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     keep = [ys_d]
     model = _model_struct(spec, gamma, B, keep)
     sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
-    init = CgpInit()
-    if H is not None:
-        Ht, init.H_stride = _batched_operand(H, 1, B, 'H')
-        if Ht.shape[-1] != d:
-            raise ValueError(f'H must have {d} entries')
-        init.H = _ptr(Ht)
-        keep.append(Ht)
-    Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
-    if Xit.numel() not in (1, B):
-        raise ValueError('Xi must be a scalar or have one entry per trial')
-    init.Xi, init.Xi_stride = _ptr(Xit), (1 if Xit.numel() > 1 else 0)
-    m0t, init.m0_stride = _batched_operand(m0, 1, B, 'm0')
-    P0t, init.P0_stride = _batched_operand(P0, 2, B, 'P0')
-    if m0t.shape[-1] != d or tuple(P0t.shape[-2:]) != (d, d):
-        raise ValueError(f'm0 / P0 must be ({d},) / ({d}, {d})')
-    init.m0, init.P0 = _ptr(m0t), _ptr(P0t)
-    keep += [Xit, m0t, P0t]
+    init = _init_struct(H, Xi, m0, P0, d, B, keep)
     opts = dict(dtype=torch.float64, device=ys_d.device)
     mfs = torch.empty((B, T, d), **opts) if want[0] else None
     Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
@@ -348,3 +339,86 @@ def debug_math(op, x):
     rc = load_library().cgp_debug_math(ctx, int(op), _ptr(xd), xd.numel(), _ptr(o0), _ptr(o1), _stream())
     _check(ctx, rc, 'cgp_debug_math')
     return o0.cpu().numpy(), o1.cpu().numpy()
+
+
+def _init_struct(H, Xi, m0, P0, d, B, keep):
+    init = CgpInit()
+    if H is not None:
+        Ht, init.H_stride = _batched_operand(H, 1, B, 'H')
+        if Ht.shape[-1] != d:
+            raise ValueError(f'H must have {d} entries')
+        init.H = _ptr(Ht)
+        keep.append(Ht)
+    if Xi is not None:
+        Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
+        if Xit.numel() not in (1, B):
+            raise ValueError('Xi must be a scalar or have one entry per trial')
+        init.Xi, init.Xi_stride = _ptr(Xit), (1 if Xit.numel() > 1 else 0)
+        keep.append(Xit)
+    m0t, init.m0_stride = _batched_operand(m0, 1, B, 'm0')
+    if m0t.shape[-1] != d:
+        raise ValueError(f'm0 must be ({d},)')
+    init.m0 = _ptr(m0t)
+    keep.append(m0t)
+    if P0 is not None:
+        P0t, init.P0_stride = _batched_operand(P0, 2, B, 'P0')
+        if tuple(P0t.shape[-2:]) != (d, d):
+            raise ValueError(f'P0 must be ({d}, {d})')
+        init.P0 = _ptr(P0t)
+        keep.append(P0t)
+    return init
+
+
+def run_simulate(spec, H, Xi, m0, P0, dt, T, seed, B, trial0=0, want=(True, True), flags=0, device=None):
+    """cgp_simulate: B trajectories xs (B, T, d) and measurements ys (B, T) as CUDA tensors (None where not wanted)."""
+    torch = _torch()
+    d = int(spec.d)
+    if d > MAX_D:
+        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    B, T = int(B), int(T)
+    ctx = context(device)
+    keep = []
+    model = _model_struct(spec, None, B, keep)
+    init = _init_struct(H if want[1] else None, Xi if want[1] else None, m0, P0, d, B, keep)
+    opts = dict(dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device() if device is None else device))
+    xs = torch.empty((B, T, d), **opts) if want[0] else None
+    ys = torch.empty((B, T), **opts) if want[1] else None
+    lib, st = load_library(), _stream()
+    fl = int(flags) | (SIM_FIXED_X0 if P0 is None else 0)
+    rc = _timed('simulate', lambda: lib.cgp_simulate(ctx, C.byref(model), C.byref(init), float(dt), int(seed) & (2 ** 64 - 1),
+                                                     int(trial0), B, T, _ptr(xs), _ptr(ys), fl, st))
+    _check(ctx, rc, 'cgp_simulate')
+    return xs, ys
+
+
+def add_noise(clean, Xi, seed, B, trial0=0):
+    """cgp_add_noise: (B, T) CUDA tensor clean + sqrt(Xi) e; clean is (T,) (shared) or (B, T)."""
+    torch = _torch()
+    c = dev(clean)
+    if c.ndim == 1:
+        stride, T = 0, int(c.shape[0])
+    elif c.ndim == 2 and c.shape[0] == B:
+        stride, T = int(c.shape[1]), int(c.shape[1])
+    else:
+        raise ValueError(f'clean must be (T,) or ({B}, T), got {tuple(c.shape)}')
+    Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
+    if Xit.numel() not in (1, B):
+        raise ValueError('Xi must be a scalar or have one entry per trial')
+    ctx = context(c.device.index)
+    ys = torch.empty((int(B), T), dtype=torch.float64, device=c.device)
+    rc = _timed('add_noise', lambda: load_library().cgp_add_noise(ctx, _ptr(c), stride, _ptr(Xit), 1 if Xit.numel() > 1 else 0,
+                                                                  int(seed) & (2 ** 64 - 1), int(trial0), int(B), T, _ptr(ys), _stream()))
+    _check(ctx, rc, 'cgp_add_noise')
+    return ys
+
+
+def debug_philox(ctr, key):
+    """Raw Philox4x32-10 blocks on the device (test hook): ctr (n, 4) uint32, key (2,) uint32 -> (n, 4) uint32."""
+    torch = _torch()
+    c = torch.from_numpy(np.ascontiguousarray(np.asarray(ctr, dtype=np.uint32)).view(np.int32)).cuda()
+    k = torch.from_numpy(np.ascontiguousarray(np.asarray(key, dtype=np.uint32)).view(np.int32)).cuda()
+    ctx = context(c.device.index)
+    out = torch.empty_like(c)
+    rc = load_library().cgp_debug_philox(ctx, _ptr(c), _ptr(k), c.shape[0], _ptr(out), _stream())
+    _check(ctx, rc, 'cgp_debug_philox')
+    return out.cpu().numpy().view(np.uint32)

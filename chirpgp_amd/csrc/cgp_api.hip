@@ -3,19 +3,9 @@
 #include <cstring>
 #include <string>
 #include "cgp_kernels.hpp"
-
-struct cgp_ctx {
-    int device;
-    int num_cus;
-    std::string err;
-};
+#include "cgp_ctx.hpp"
 
 namespace cgp {
-
-static int fail(cgp_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
-    return code;
-}
 
 // Launch-shape choice.  One wavefront per trial is the latency-optimal shape while the batch is about the number of
 // SIMDs (1024): a step then costs its dependent-instruction chain once.  One lane per trial costs more per step but

@@ -7,7 +7,7 @@ import math
 import numpy as np
 
 __all__ = ['gen_chirp', 'gen_harmonic_chirp', 'constant_mag', 'damped_exp_mag', 'random_ou_mag', 'affine_freq',
-           'polynomial_freq', 'meow_freq', 'tiled_meow']
+           'polynomial_freq', 'meow_freq', 'tiled_meow', 'noisy_copies']
 
 
 def gen_chirp(ts, magnitude_func, phase_func, base_phase=0.):
@@ -76,3 +76,11 @@ def tiled_meow(T, dt=1e-3, mag=500., scale=5., offset=8., window=3141):
     local = (k % window + 1) * dt
     f, p = meow_freq(mag, scale, offset)
     return (k + 1) * dt, f(local), (k // window) * (offset * window * dt) + p(local)
+
+
+def noisy_copies(clean, Xi, key, batch, trial0=0):
+    """(batch, T) CUDA tensor of clean + sqrt(Xi) N(0, 1) -- the Monte-Carlo measurements of demos/ekfs_mle.py:33-35 drawn
+    on the device (include/chirpgp_hip.h: cgp_add_noise), so only the T clean samples cross PCIe.  ``clean`` is (T,)
+    or (batch, T); trial ``trial0 + i`` draws the same noise in every call with the same integer ``key``."""
+    from chirpgp_amd import _engine as E
+    return E.add_noise(clean, Xi, key, int(batch), trial0=trial0)

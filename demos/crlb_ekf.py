@@ -1,67 +1,78 @@
-"""Counterpart of the reference's tetralith/jobs/crlb_ekf.py on the MI355X engine: simulate many chirp-SDE trajectories,
-run the EKF on all of them in one batched launch (the reference's jax.vmap over ys), and report the mean and standard
-deviation of the squared filtering errors of the chirp and of the frequency state per time step.
+"""Counterpart of the reference's tetralith/jobs/crlb_ekf.py on the MI355X engine: simulate many chirp-SDE trajectories
+on the device (cgp_simulate), run the EKF on all of them in one batched launch (the reference's jax.vmap over ys), and
+report the mean and standard deviation of the squared filtering errors of the chirp and of the frequency state per
+time step.  Nothing but the per-step error statistics (T doubles each) leaves HBM.
 
-    python demos/crlb_ekf.py [-lam 0.1 -b 0.1 -delta 0.1 -ell 1 -sigma 1 -Xi 0.1] [--num-mcs 100000] [--T 500]
+    python demos/crlb_ekf.py [-lam 0.1 -b 0.1 -delta 0.1 -ell 1 -sigma 1 -Xi 0.1] [--num-mcs 1000000] [--T 500] [--chunk 250000]
+
+With torch.distributed initialised (python -m torch.distributed.run --nproc-per-node N demos/crlb_ekf.py ...) every rank
+takes a contiguous block of the trials -- the counter-based generator gives trial i the same draws on any rank -- and
+the per-step error sums are all-reduced (the natural collective of this job, 4 T doubles).
 """
 import argparse
-import math
 import os
 import sys
 import time
 
-import numpy as np
+import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from chirpgp_amd import filters_smoothers as fs                    # noqa: E402
-from chirpgp_amd.models import model_chirp, disc_chirp_lcd          # noqa: E402
-
-
-def simulate(m_and_cov, m0, P0, H, Xi, dt, T, n, rng):
-    """Vectorised simulation of n trajectories of the discretised chirp SDE (crlb_ekf.py:39-57): the transition
-    covariance does not depend on the state, so only the conditional mean is evaluated per step (NumPy, host)."""
-    _, state_cov = m_and_cov(np.zeros(4), dt)
-    chol_cov = np.linalg.cholesky(state_cov + 1e-300 * np.eye(4))
-    x = m0[:, None] + np.linalg.cholesky(P0) @ rng.standard_normal((4, n))
-    p = m_and_cov.params
-    lam, ell, sigma = p[0], p[2], p[3]
-    from chirpgp_amd.models import _m32, g
-    M, _ = _m32(ell, sigma, dt)
-    xs, ys = np.empty((n, T, 4)), np.empty((n, T))
-    for k in range(T):
-        th = dt * 2 * math.pi * g(x[2])
-        c, s = np.cos(th) * math.exp(-lam * dt), np.sin(th) * math.exp(-lam * dt)
-        mean = np.stack([c * x[0] - s * x[1], s * x[0] + c * x[1], M[0, 0] * x[2] + M[0, 1] * x[3], M[1, 0] * x[2] + M[1, 1] * x[3]])
-        x = mean + chol_cov @ rng.standard_normal((4, n))
-        xs[:, k] = x.T
-        ys[:, k] = H @ x + math.sqrt(Xi) * rng.standard_normal(n)
-    return xs, ys
+from chirpgp_amd import filters_smoothers as fs, tools                       # noqa: E402
+from chirpgp_amd.models import model_chirp, disc_chirp_lcd                    # noqa: E402
+from chirpgp_amd.parallel import shard_bounds                                 # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     for name, default in (('-lam', 0.1), ('-b', 0.1), ('-delta', 0.1), ('-ell', 1.0), ('-sigma', 1.0), ('-Xi', 0.1)):
         ap.add_argument(name, type=float, default=default)
-    ap.add_argument('--num-mcs', type=int, default=100000)
+    ap.add_argument('--num-mcs', type=int, default=1000000)
     ap.add_argument('--T', type=int, default=500)
+    ap.add_argument('--chunk', type=int, default=250000, help='trials per launch (bounds the HBM held at once)')
+    ap.add_argument('--seed', type=int, default=666)
     args = ap.parse_args()
+
+    rank, world = 0, 1
+    if 'RANK' in os.environ:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        dist.init_process_group('nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
 
     _, _, m0, P0, H = model_chirp(args.lam, args.b, args.ell, args.sigma, args.delta)
     m_and_cov = disc_chirp_lcd(args.lam, args.b, args.ell, args.sigma)
     dt, T = 0.01, args.T
-    rng = np.random.default_rng(666)
+    lo, hi = shard_bounds(args.num_mcs, rank, world)
+    sums = torch.zeros((4, T), dtype=torch.float64, device='cuda')        # sum e_chirp, e_chirp^2, e_v, e_v^2 per step
+    # warm-up: library load, code-object load and the first allocations are one-off costs of the process
+    _, yw = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, 8, args.seed, batch=64)
+    fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yw, want=(True, False, False))
+    torch.cuda.synchronize()
     t0 = time.time()
-    xss, yss = simulate(m_and_cov, m0, P0, H, args.Xi, dt, T, args.num_mcs, rng)
+    for first in range(lo, hi, args.chunk):
+        n = min(args.chunk, hi - first)
+        xss, yss = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, T, args.seed, batch=n, trial0=first)
+        mfs, _, _ = fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
+        e_chirp = (mfs[:, :, 1] - xss[:, :, 1]) ** 2
+        e_v = (mfs[:, :, 2] - xss[:, :, 2]) ** 2
+        sums += torch.stack([e_chirp.sum(0), (e_chirp ** 2).sum(0), e_v.sum(0), (e_v ** 2).sum(0)])
+        del xss, yss, mfs, e_chirp, e_v
+    if world > 1:
+        dist.all_reduce(sums)
+    torch.cuda.synchronize()
     t1 = time.time()
-    mfs, _, _ = fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
-    t2 = time.time()
-    err_chirp = (mfs[:, :, 1] - xss[:, :, 1]) ** 2
-    err_v = (mfs[:, :, 2] - xss[:, :, 2]) ** 2
-    print(f'{args.num_mcs} trials x {T} steps: simulate {t1 - t0:.2f} s (host), EKF {t2 - t1:.3f} s (GPU incl. transfers)')
-    for k in (0, T // 2, T - 1):
-        print(f'  t = {dt * (k + 1):5.2f}  chirp err {err_chirp[:, k].mean():.4e} +- {err_chirp[:, k].std():.2e}   '
-              f'v err {err_v[:, k].mean():.4e} +- {err_v[:, k].std():.2e}')
+    if rank == 0:
+        n = args.num_mcs
+        mean_c, mean_v = sums[0] / n, sums[2] / n
+        std_c = (sums[1] / n - mean_c ** 2).clamp_min(0).sqrt()
+        std_v = (sums[3] / n - mean_v ** 2).clamp_min(0).sqrt()
+        print(f'{n} trials x {T} steps on {world} GPU(s): simulate + EKF + error statistics {t1 - t0:.3f} s')
+        for k in (0, T // 2, T - 1):
+            print(f'  t = {dt * (k + 1):5.2f}  chirp err {mean_c[k].item():.4e} +- {std_c[k].item():.2e}   '
+                  f'v err {mean_v[k].item():.4e} +- {std_v[k].item():.2e}')
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

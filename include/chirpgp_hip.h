@@ -17,6 +17,10 @@
  *   cgp_smoother (method = CGP_S_CD_EKS)                               cd_eks      filters_smoothers.py:400-443
  *   cgp_smoother (method = CGP_S_CD_SGP)                               cd_sgp_smoother filters_smoothers.py:585-632
  *   cgp_gaussian_expectation                                           gaussian_expectation quadratures.py:234-274
+ *   cgp_simulate                                                       simulate_sde tools.py:119-170 and the
+ *                                                                      state + measurement simulation of
+ *                                                                      tetralith/jobs/crlb_ekf.py:39-58
+ *   cgp_add_noise                                                      y = chirp + sqrt(Xi) N(0, 1), demos/ekfs_mle.py:33-35
  *
  * The leading batch axis B is the reference's jax.vmap(..., in_axes=0) over ys (tetralith/jobs/crlb_ekf.py:68-72).
  *
@@ -124,6 +128,7 @@ typedef struct cgp_init {
 #define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
 #define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
 #define CGP_GENERIC_KERNEL    0x10u  /* filters: force the generic kernel where a lane-cooperative specialisation exists   */
+#define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */
 #define CGP_OK              0
@@ -150,6 +155,27 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
  * (nodes xi[order], weights w[order] already in the reference's scaling): quadratures.py:234-274 with func = g. */
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
                              const double* xi, const double* w, int32_t order, double* out, void* stream);
+
+/* ---- input side: Monte-Carlo data generated in HBM ------------------------------------
+ * Random numbers are counter-based (Philox4x32-10 keyed by `seed`, counter = (global trial number, index, stream),
+ * Box-Muller), so a trial's draws do not depend on B, on the launch shape or on how the batch is sharded over ranks:
+ * pass the number of the shard's first trial in `trial0`.  The reference draws from jax.random, whose streams cannot
+ * be reproduced; the streams here are defined in csrc/cgp_rng.hpp. */
+
+/* x_0 = m0 + chol(P0) z;  x_k = mean(x_{k-1}) + chol(Sigma) dw_k;  y_k = H . x_k + sqrt(Xi) e_k,  k = 1..T
+ * with (mean, Sigma) the discrete model's cond_m_cov (tools.py:148-167; crlb_ekf.py:39-58).
+ * xs [B][T][d] and ys [B][T]: either may be NULL.  Only discrete models (CGP_M_LINEAR, *_LCD).
+ * flags: CGP_SIM_FIXED_X0, CGP_WAVE_PER_TRIAL, CGP_THREAD_PER_TRIAL. */
+int cgp_simulate(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init, double dt, uint64_t seed, int64_t trial0,
+                 int64_t B, int64_t T, double* xs, double* ys, uint32_t flags, void* stream);
+
+/* ys[b][k] = clean[b * clean_stride + k] + sqrt(Xi[b * Xi_stride]) e_{b,k}   (clean_stride = 0: one clean record shared
+ * by all trials).  e is the measurement-noise stream of cgp_simulate. */
+int cgp_add_noise(cgp_ctx* ctx, const double* clean, int64_t clean_stride, const double* Xi, int64_t Xi_stride,
+                  uint64_t seed, int64_t trial0, int64_t B, int64_t T, double* ys, void* stream);
+
+/* Test hook: the raw generator.  out[4 i .. 4 i + 3] = Philox4x32-10(counter = ctr[4 i .. 4 i + 3], key = key[0..1]). */
+int cgp_debug_philox(cgp_ctx* ctx, const uint32_t* ctr, const uint32_t* key, int64_t n, uint32_t* out, void* stream);
 
 /* Test hook: evaluates one of the engine's in-kernel float64 elementary functions (csrc/cgp_fastmath.hpp) on n inputs.
  * op: 0 exp, 1 log on [1, inf] (softplus argument), 2 sincos (out0 = sin, out1 = cos), 3 reciprocal,

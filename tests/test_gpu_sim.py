@@ -1,0 +1,149 @@
+"""GPU tests of the input side: cgp_simulate / cgp_add_noise against oracle/np_sim.py.
+
+Integers (Philox) must match bit for bit; the float64 trajectories to 1e-11 (the device uses its own log / sincos /
+sqrt, accurate to a few ulp, and the recursion carries that forward)."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import np_sim
+from tests import cases as cs
+from tests.test_oracle_sim import KAT
+
+pytestmark = pytest.mark.gpu
+
+WAVE, LANE = 0x2, 0x4
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(LANE, id='lane_per_trial')]
+TOL = dict(rtol=1e-11, atol=1e-11)
+# The chirp models form the Matern-3/2 transition covariance from the reference's closed form (models.py:61-73), which
+# cancels badly at dt = 1e-3 (entries ~ 1e-9 come out of differences of O(1) terms): two correctly rounded exp()
+# implementations already give entries that differ by 1e-7 relative, and chol(Sigma) colours the noise with them.
+TOL_M32 = dict(rtol=1e-6, atol=1e-7)
+
+
+def _E():
+    from chirpgp_amd import _engine as E
+    return E
+
+
+def test_philox_known_answers_and_random_counters_bit_exact():
+    E = _E()
+    for ctr, key, want in KAT:
+        got = E.debug_philox(np.array([ctr], dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert tuple(int(v) for v in got[0]) == want
+    rng = np.random.default_rng(5)
+    ctr = rng.integers(0, 2 ** 32, size=(5000, 4), dtype=np.uint64).astype(np.uint32)
+    key = rng.integers(0, 2 ** 32, size=2, dtype=np.uint64).astype(np.uint32)
+    npt.assert_array_equal(E.debug_philox(ctr, key), np_sim.philox4x32_10(ctr.astype(np.uint64), key))
+
+
+@pytest.mark.parametrize('flags', SHAPES)
+@pytest.mark.parametrize('T', [1, 77, 150])
+def test_simulate_chirp_matches_oracle(flags, T):
+    E = _E()
+    c = cs.chirp_case(T=8)
+    B, seed = 70, 2024
+    xs, ys = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, T, seed, B, flags=flags)
+    oxs, oys = np_sim.simulate(c.o_disc, c.H, c.Xi, c.m0, c.P0, c.dt, T, seed, range(B))
+    npt.assert_allclose(xs.cpu().numpy(), oxs, **TOL_M32)
+    npt.assert_allclose(ys.cpu().numpy(), oys, **TOL_M32)
+
+
+@pytest.mark.parametrize('flags', SHAPES)
+def test_simulate_harmonic_d8_and_linear_d3(flags):
+    E = _E()
+    c = cs.harmonic_case(T=8, nh=3)
+    xs, ys = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 45, 7, 5, flags=flags)
+    oxs, oys = np_sim.simulate(c.o_disc, c.H, c.Xi, c.m0, c.P0, c.dt, 45, 7, range(5))
+    npt.assert_allclose(xs.cpu().numpy(), oxs, **TOL_M32)
+    npt.assert_allclose(ys.cpu().numpy(), oys, **TOL_M32)
+    c = cs.linear_case(0, T=8)                      # d = 3: odd rows, the scalar store path
+    xs, ys = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 33, 8, 67, flags=flags)
+    oxs, oys = np_sim.simulate(c.o_disc, c.H, c.Xi, c.m0, c.P0, c.dt, 33, 8, range(67))
+    npt.assert_allclose(xs.cpu().numpy(), oxs, **TOL)
+    npt.assert_allclose(ys.cpu().numpy(), oys, **TOL)
+
+
+@pytest.mark.parametrize('flags', SHAPES)
+def test_simulate_shards_and_shapes_agree(flags):
+    """Trial trial0 + i draws the same numbers whatever the batch, the shard or the launch shape."""
+    E = _E()
+    c = cs.chirp_case(T=8)
+    full_x, full_y = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 100, 3, 130, flags=flags)
+    part_x, part_y = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 100, 3, 30, trial0=100, flags=flags)
+    npt.assert_array_equal(full_x[100:].cpu().numpy(), part_x.cpu().numpy())
+    npt.assert_array_equal(full_y[100:].cpu().numpy(), part_y.cpu().numpy())
+    other_x, other_y = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 100, 3, 130, flags=flags ^ (WAVE | LANE))
+    npt.assert_allclose(full_x.cpu().numpy(), other_x.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    npt.assert_allclose(full_y.cpu().numpy(), other_y.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    only_y = E.run_simulate(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, 100, 3, 130, want=(False, True), flags=flags)
+    assert only_y[0] is None
+    npt.assert_array_equal(only_y[1].cpu().numpy(), full_y.cpu().numpy())
+
+
+def test_tools_simulators_mirror_reference_signatures():
+    from chirpgp_amd import tools, models as pm
+    c = cs.linear_case(1, T=8)
+    traj = tools.simulate_lgssm(c.F, c.Sigma, np.array([1., -1., 0.5]), 40, 11)
+    assert traj.shape == (40, 3)
+    L = np.linalg.cholesky(c.Sigma)
+    z = np_sim._normals(11, 0, 0, 4 * 40, np_sim.STREAM_STATE).reshape(40, 4)[:, :3]
+    x, want = np.array([1., -1., 0.5]), []
+    for k in range(40):
+        x = c.F @ x + L @ z[k]
+        want.append(x)
+    npt.assert_allclose(traj, np.array(want), **TOL)
+    same = tools.simulate_sde_init(pm.linear_cond_m_cov(c.F, c.Sigma), np.array([1., -1., 0.5]), c.dt, 40, 11)
+    npt.assert_array_equal(same, traj)
+    ch = cs.chirp_case(T=8)
+    one = tools.simulate_sde(ch.disc, ch.m0, ch.P0, ch.dt, 25, 4)
+    many = tools.simulate_sde(ch.disc, ch.m0, ch.P0, ch.dt, 25, 4, batch=3)
+    assert one.shape == (25, 4) and tuple(many.shape) == (3, 25, 4) and many.is_cuda
+    npt.assert_allclose(many[0].cpu().numpy(), one, rtol=1e-12, atol=1e-12)
+    xs, ys = tools.simulate_measurements(ch.disc, ch.H, ch.Xi, ch.m0, ch.P0, ch.dt, 25, 4, batch=3)
+    npt.assert_allclose(xs.cpu().numpy(), many.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    with pytest.raises(TypeError):
+        tools.simulate_sde(lambda x, dt: (x, np.eye(4)), ch.m0, ch.P0, ch.dt, 5, 0)
+
+
+@pytest.mark.parametrize('T', [1, 64, 999])
+def test_add_noise_matches_oracle(T):
+    from chirpgp_amd import toymodels
+    rng = np.random.default_rng(1)
+    clean = rng.standard_normal(T)
+    ys = toymodels.noisy_copies(clean, 0.1, 77, 37)
+    npt.assert_allclose(ys.cpu().numpy(), np_sim.add_noise(clean, 0.1, 77, range(37), T), **TOL)
+    per_trial = rng.standard_normal((5, T))
+    Xi = np.array([0.0, 0.1, 1.0, 4.0, 0.25])
+    ys = toymodels.noisy_copies(per_trial, Xi, 78, 5, trial0=9)
+    npt.assert_allclose(ys.cpu().numpy(), np_sim.add_noise(per_trial, Xi, 78, range(9, 14), T), **TOL)
+    npt.assert_array_equal(ys[0].cpu().numpy(), per_trial[0])          # Xi = 0: no noise at all
+
+
+def test_simulated_statistics_full_batch():
+    """Size-independent property at a Monte-Carlo-sized batch: a stationary linear model stays in its stationary law."""
+    E = _E()
+    from chirpgp_amd import models as pm
+    F = np.array([[0.9, 0.1], [0.0, 0.8]])
+    Sigma = np.array([[0.2, 0.05], [0.05, 0.1]])
+    P = np.eye(2)
+    for _ in range(500):
+        P = F @ P @ F.T + Sigma
+    H, Xi, B = np.array([1.0, -0.5]), 0.3, 200000
+    xs, ys = E.run_simulate(pm.linear_cond_m_cov(F, Sigma), H, Xi, np.zeros(2), P, 0.1, 50, 1, B)
+    x = xs.cpu().numpy()
+    for k in (0, 49):
+        npt.assert_allclose(x[:, k].T @ x[:, k] / B, P, atol=0.02)
+    npt.assert_allclose(x[:, 31].T @ x[:, 30] / B, F @ P, atol=0.02)
+    r = ys.cpu().numpy() - x @ H
+    assert abs(r.var() - Xi) < 0.005 and abs(r.mean()) < 0.005
+
+
+def test_simulate_rejects_bad_arguments():
+    E = _E()
+    from chirpgp_amd import models as pm
+    c = cs.chirp_case(T=8)
+    with pytest.raises(RuntimeError, match='discrete'):
+        E.run_simulate(c.drift, c.H, c.Xi, c.m0, c.P0, c.dt, 10, 0, 4)
+    with pytest.raises(ValueError):
+        E.run_simulate(c.disc, c.H[:3], c.Xi, c.m0, c.P0, c.dt, 10, 0, 4)
