@@ -17,6 +17,8 @@ F_EKF, F_SGP, F_CD_EKF, F_CD_SGP, F_EKF_KPT = range(5)
 S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
 M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
 NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL, SIM_FIXED_X0 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+LITERAL_SIGMA_SUM = 0x40
+SIGMA_STANDARD = 0x1
 MAX_D = 8
 
 _vp = C.c_void_p
@@ -28,7 +30,8 @@ class CgpModel(C.Structure):
 
 
 class CgpSigma(C.Structure):
-    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _vp), ('w', _vp), ('group_start', _vp), ('n_groups', C.c_int32)]
+    _fields_ = [('s', C.c_int32), ('d', C.c_int32), ('xi', _vp), ('w', _vp), ('group_start', _vp), ('n_groups', C.c_int32),
+                ('flags', C.c_uint32)]
 
 
 class CgpInit(C.Structure):
@@ -227,7 +230,7 @@ def _sigma_struct(sgps, d, keep, nonlinear_coord=None):
     key = (torch.cuda.current_device(), nonlinear_coord, xi_h.shape, xi_h.tobytes(), w_h.tobytes())
     hit = _sigma_cache.get(key)
     if hit is None:
-        gs = None
+        gs, sflags = None, 0
         if nonlinear_coord is not None:
             v = int(nonlinear_coord)
             prefix = xi_h[:, :v + 1] + 0.0          # exact grouping (-0.0 folded into +0.0)
@@ -236,12 +239,27 @@ def _sigma_struct(sgps, d, keep, nonlinear_coord=None):
             xi_h, w_h, inv = xi_h[order], w_h[order], inverse.ravel()[order]
             starts = np.flatnonzero(np.r_[True, inv[1:] != inv[:-1], True]).astype(np.int32)
             gs = torch.from_numpy(starts).cuda()
+            sflags = SIGMA_STANDARD if _is_standard(xi_h, w_h, starts, v) else 0
         if len(_sigma_cache) >= 64:
             _sigma_cache.clear()
-        hit = _sigma_cache[key] = (dev(xi_h), dev(w_h), gs)
-    xi, w, gs = hit
+        hit = _sigma_cache[key] = (dev(xi_h), dev(w_h), gs, sflags)
+    xi, w, gs, sflags = hit
     keep += [xi, w, gs]
-    return CgpSigma(int(xi.shape[0]), int(d), _ptr(xi), _ptr(w), _ptr(gs), int(gs.numel() - 1) if gs is not None else 0)
+    return CgpSigma(int(xi.shape[0]), int(d), _ptr(xi), _ptr(w), _ptr(gs), int(gs.numel() - 1) if gs is not None else 0, sflags)
+
+
+def _is_standard(xi, w, starts, v, tol=1e-13):
+    """The assertion behind CGP_SIGMA_STANDARD (include/chirpgp_hip.h): unit weight, zero mean, identity second moment,
+    and groups whose members differ in the last coordinate only, with zero weighted mean there."""
+    d = xi.shape[1]
+    if v != d - 2:
+        return False
+    if abs(w.sum() - 1) > tol or np.abs(w @ xi).max() > tol or np.abs((xi.T * w) @ xi - np.eye(d)).max() > tol:
+        return False
+    for a, b in zip(starts[:-1], starts[1:]):
+        if np.abs(xi[a:b, :d - 1] - xi[a, :d - 1]).max() != 0 or abs(w[a:b] @ xi[a:b, d - 1]) > tol * 0.1:
+            return False
+    return True
 
 
 def _nonlinear_coord(spec):

@@ -56,7 +56,7 @@ static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sig
     return CGP_OK;
 }
 
-static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt) {
+static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt, uint32_t flags) {
     ModelArgs a;
     a.params = m->params; a.param_stride = m->param_stride;
     a.gamma = m->gamma; a.gamma_stride = m->gamma_stride;
@@ -64,6 +64,7 @@ static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt) 
     a.sg.xi = sg ? sg->xi : nullptr; a.sg.w = sg ? sg->w : nullptr; a.sg.s = sg ? sg->s : 0;
     a.sg.group_start = sg ? sg->group_start : nullptr; a.sg.n_groups = (sg && sg->group_start) ? sg->n_groups : 0;
     a.sg.lds_xi = 0; a.sg.lds_w = 0; a.sg.lds_gs = 0;
+    a.sg.flags = (sg && !(flags & CGP_LITERAL_SIGMA_SUM)) ? sg->flags : 0u;
     a.dt = dt;
     return a;
 }
@@ -157,7 +158,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.m0 = init->m0; io.m0_stride = init->m0_stride;
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
-    const ModelArgs ma = model_args(model, sigma, dt);
+    const ModelArgs ma = model_args(model, sigma, dt, flags);
     const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : Shape::EkfFilter, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
@@ -200,7 +201,7 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
 
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
-    const ModelArgs ma = model_args(model, sigma, dt);
+    const ModelArgs ma = model_args(model, sigma, dt, flags);
     const bool affine = (method == CGP_S_EKS || method == CGP_S_SGP) && !(flags & CGP_SEQUENTIAL_SCAN);
     const bool wave = choose_wave(ctx, B, flags, affine ? Shape::AffineSmoother : (sig ? Shape::SigmaFilter : Shape::SerialSmoother), sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;

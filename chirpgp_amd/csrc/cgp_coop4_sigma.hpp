@@ -24,6 +24,17 @@ CGP_DEV void coop4_gather(double P, Sym<4>& S) {
         CGP_UNROLL for (int j = 0; j <= i; j++) S(i, j) = readlane_f64(P, 4 * i + j);
 }
 
+// Sum of 16 consecutive doubles (eight 16-byte reads) as a balanced tree: four independent chains instead of one
+// 16-deep chain of dependent adds (8 cycles each on the serial path of a step).
+CGP_DEV double row_sum16(const double2* row) {
+    double2 a = row[0], b = row[1], c = row[2], d = row[3];
+    const double2 e = row[4], f = row[5], g = row[6], h = row[7];
+    a.x += e.x; a.y += e.y; b.x += f.x; b.y += f.y; c.x += g.x; c.y += g.y; d.x += h.x; d.y += h.y;
+    a.x += c.x; a.y += c.y; b.x += d.x; b.y += d.y;
+    a.x += b.x; a.y += b.y;
+    return a.x + a.y;
+}
+
 // Wave sum of R <= 32 per-lane partials; the totals stay in LDS at the returned pointer (tot[0..R-1]).
 // Same fixed summation order as wave_allreduce.  When only the first 32 lanes carry partials (`narrow`, wave-uniform:
 // at most 32 groups of sigma points, e.g. the 27 groups of Gauss-Hermite order 3 in d = 4) two lanes share a row --
@@ -39,7 +50,7 @@ CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane
         const double2* row = reinterpret_cast<const double2*>(lds + r * kRedLd + h * 16);
         double s = 0.0;
         if (r < R) {
-            CGP_UNROLL for (int j = 0; j < 8; j++) { const double2 v = row[j]; s += v.x; s += v.y; }
+            s = row_sum16(row);
         }
         s += dpp_f64<kQuadSwap1>(s);
         if (h == 0 && r < R) tot[r] = s;
@@ -54,7 +65,7 @@ CGP_DEV const double* coop_reduce_to_lds(double (&acc)[R], double* lds, int lane
         const double2* row = reinterpret_cast<const double2*>(lds + r * kRedLd + q * 16);
         double s = 0.0;
         if (base + r < R) {
-            CGP_UNROLL for (int j = 0; j < 8; j++) { const double2 v = row[j]; s += v.x; s += v.y; }
+            s = row_sum16(row);
         }
         s += dpp_f64<kQuadSwap1>(s);
         s += dpp_f64<kQuadSwap2>(s);
@@ -288,8 +299,91 @@ CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, const LanePoi
     kP = (tot[cij_idx] + tot[cji_idx]) + gam;
 }
 
-// ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
+
+// ---- the same right-hand side with the linear structure of the chirp SDE taken out of the quadrature ---------------
+// For a CGP_SIGMA_STANDARD set (sum w = 1, sum w xi = 0, sum w xi xi^T = I; members of a group differ in xi_3 only, with
+// zero weighted mean) and the chirp drift a = (-lam chi_0 - om chi_1, om chi_0 - lam chi_1, chi_3, -g^2 chi_2 - 2 g chi_3),
+// om = om(chi_2), the sums of filters_smoothers.py:124-137 regroup EXACTLY (L lower-triangular, so chi_0..2 and hence
+// a_0, a_1 do not depend on xi_3):
+//     E[a_2] = m_3,  E[a_3] = -g^2 m_2 - 2 g m_3,        C[:, 2] = P[:, 3],  C[:, 3] = -g^2 P[:, 2] - 2 g P[:, 3]
+//     E[a_j] = sum_g W_g a_j(g),   C[i][j] = sum_g W_g d_i(g) a_j(g)   (j < 2),   d = L xi restricted to xi_0..2
+// One point per lane instead of three, 10 partial sums instead of 20, no L[3][3].  A failed Cholesky poisons every
+// output with NaN like the literal sums do.
+struct CollapsedPoint {
+    double xi0, xi1, xi2, W;
+    CGP_DEV void load(const SigmaSet& sg, int lane) {
+        xi0 = xi1 = xi2 = W = 0.0;
+        if (lane < sg.groups()) {
+            const int p0 = sg.template begin<true>(lane), p1 = sg.template end<true>(lane);
+            xi0 = sg.template coord<true>(p0 * 4); xi1 = sg.template coord<true>(p0 * 4 + 1); xi2 = sg.template coord<true>(p0 * 4 + 2);
+            for (int p = p0; p < p1; p++) W += sg.template weight<true>(p);
+        }
+    }
+};
+// per-lane selectors of the combine: which closed-form column the lane's (i, j) and (j, i) entries come from
+struct CollapsedRole {
+    int tij, tji;                 // indices of C[i][j], C[j][i] among the totals (valid when the column is < 2)
+    int pi, pj;                   // LDS offsets of P[i][2..3], P[j][2..3]
+    double c2j, c3j, c2i, c3i;    // closed-form column coefficients on (P[.][2], P[.][3])
+    bool nlj, nli;
+    CGP_DEV void init(int li, int lj, double g) {
+        tij = 2 + 2 * li + (lj < 2 ? lj : 0); tji = 2 + 2 * lj + (li < 2 ? li : 0);
+        pi = 4 * li + 2; pj = 4 * lj + 2;
+        nlj = lj < 2; nli = li < 2;
+        c2j = lj == 3 ? -(g * g) : 0.0; c3j = lj == 3 ? -2.0 * g : (lj == 2 ? 1.0 : 0.0);
+        c2i = li == 3 ? -(g * g) : 0.0; c3i = li == 3 ? -2.0 * g : (li == 2 ? 1.0 : 0.0);
+    }
+};
 template <class SM>
+CGP_DEV void coop4_cd_sgp_rhs_collapsed(const SM& model, const CollapsedPoint& pt, const CollapsedRole& role, double* red, int lane,
+                                        double gam, const Vec<4>& m, double P, Vec<4>& km, double& kP) {
+    Sym<4> Pr, L; Vec<4> inv;
+    coop4_gather(P, Pr);
+    cholesky<4>(Pr, L, inv);                       // L[3][3] itself is never used: its square root is dead code
+    const double d0 = L(0, 0) * pt.xi0;
+    const double d1 = fma(L(1, 1), pt.xi1, L(1, 0) * pt.xi0);
+    const double d2 = fma(L(2, 2), pt.xi2, fma(L(2, 1), pt.xi1, L(2, 0) * pt.xi0));
+    const double d3 = fma(L(3, 2), pt.xi2, fma(L(3, 1), pt.xi1, L(3, 0) * pt.xi0));
+    const double c0 = m.v[0] + d0, c1 = m.v[1] + d1, c2 = m.v[2] + d2;
+    typename SM::Pre pre;
+    model.precompute(c2, pre);
+    const double wa0 = pt.W * (-model.lam * c0 - pre.w * c1);
+    const double wa1 = pt.W * (pre.w * c0 - model.lam * c1);
+    double* tot = red + kRedChunk * kRedLd;
+    double* prow = red + (kRedChunk - 1) * kRedLd;      // row 31 of the partials area is free here (10 rows used)
+    red[0 * kRedLd + lane] = wa0;
+    red[1 * kRedLd + lane] = wa1;
+    red[2 * kRedLd + lane] = d0 * wa0; red[3 * kRedLd + lane] = d0 * wa1;
+    red[4 * kRedLd + lane] = d1 * wa0; red[5 * kRedLd + lane] = d1 * wa1;
+    red[6 * kRedLd + lane] = d2 * wa0; red[7 * kRedLd + lane] = d2 * wa1;
+    red[8 * kRedLd + lane] = d3 * wa0; red[9 * kRedLd + lane] = d3 * wa1;
+    if (lane < 16) prow[lane] = P;
+    wave_lds_fence();
+    {
+        const int r = lane >> 1, h = lane & 1;
+        const double2* row = reinterpret_cast<const double2*>(red + r * kRedLd + h * 16);
+        double s = 0.0;
+        if (r < 10) {
+            s = row_sum16(row);
+        }
+        s += dpp_f64<kQuadSwap1>(s);
+        if (h == 0 && r < 10) tot[r] = s;
+    }
+    wave_lds_fence();
+    const double poison = L(0, 0) - L(0, 0);      // 0, or NaN when the factorisation failed (cholesky() poisons L)
+    const double g = model.gam;
+    km.v[0] = tot[0]; km.v[1] = tot[1];
+    km.v[2] = m.v[3] + poison;
+    km.v[3] = fma(-(g * g), m.v[2], -2.0 * g * m.v[3]) + poison;
+    const double2 Pi = *reinterpret_cast<const double2*>(prow + role.pi), Pj = *reinterpret_cast<const double2*>(prow + role.pj);
+    const double cij = role.nlj ? tot[role.tij] : fma(role.c2j, Pi.x, role.c3j * Pi.y);
+    const double cji = role.nli ? tot[role.tji] : fma(role.c2i, Pj.x, role.c3i * Pj.y);
+    kP = ((cij + cji) + gam) + poison;
+    wave_lds_fence();
+}
+
+// ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
+template <class SM, bool COLLAPSED>
 __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
     __shared__ double red[kFanLdsDoubles];
@@ -318,7 +412,10 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
     out.init(io, trial);
     const int ng = sg.groups();
     LanePoints pts;
-    pts.load(sg, lane);
+    CollapsedPoint cpt;
+    CollapsedRole role;
+    if constexpr (COLLAPSED) { cpt.load(sg, lane); role.init(li, lj, model.gam); }
+    else pts.load(sg, lane);
 
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -333,7 +430,8 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
             CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
-                coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
+                if constexpr (COLLAPSED) coop4_cd_sgp_rhs_collapsed<SM>(model, cpt, role, red, lane, gam, tm, tP, km, kP);
+                else coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
                 const double half = (stage == 2) ? 1.0 : 0.5;
                 CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = u.v[i] + (dt * km.v[i]) * half; }
@@ -359,7 +457,7 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
 // G is constant over the four stages (hoisted, as in cgp_steps.hpp); its entries reach the lanes through LDS:
 //     (G^T P)[i][j] = sum_r G[l_r][i] P[l_r][j]   (rows l_r by DPP row rotations, G[l_r][i] per lane)
 //     (P G)[i][j]   = sum_l P[i][l] G[l][j]       (quad broadcasts, G[l][j] per lane)
-template <class SM>
+template <class SM, bool COLLAPSED>
 __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
     __shared__ double red[kFanLdsDoubles];
@@ -382,7 +480,10 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
     const int lr1 = dpp_i32<kRowRor4>(li), lr2 = dpp_i32<kRowRor8>(li), lr3 = dpp_i32<kRowRor12>(li);
     const int ng = sg.groups();
     LanePoints pts;
-    pts.load(sg, lane);
+    CollapsedPoint cpt;
+    CollapsedRole role;
+    if constexpr (COLLAPSED) { cpt.load(sg, lane); role.init(li, lj, model.gam); }
+    else pts.load(sg, lane);
 
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * 4;
@@ -415,7 +516,9 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
         CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
 #pragma unroll 1
         for (int stage = 0; stage < 4; stage++) {
-            coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
+            // (_m, _P), _P includes + gamma
+            if constexpr (COLLAPSED) coop4_cd_sgp_rhs_collapsed<SM>(model, cpt, role, red, lane, gam, tm, tP, km, kP);
+            else coop4_cd_sgp_rhs<SM>(model, sg, pts, ng, red, lane, cij_idx, cji_idx, gam, tm, tP, km, kP);
             CGP_UNROLL for (int i = 0; i < 4; i++) {
                 double s = km.v[i];
                 CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);
@@ -444,6 +547,11 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
     }
 }
 
+// The collapsed quadrature needs the caller's CGP_SIGMA_STANDARD assertion, groups, and one group per lane of a half wave.
+inline bool collapsed_ok(const ModelArgs& ma) {
+    return (ma.sg.flags & CGP_SIGMA_STANDARD) && ma.sg.group_start && ma.sg.n_groups >= 1 && ma.sg.n_groups <= 32;
+}
+
 template <class DM>
 inline int launch_sgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
@@ -453,13 +561,15 @@ inline int launch_sgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
 template <class SM>
 inline int launch_cdsgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
-    hipLaunchKernelGGL((cdsgp4_coop_kernel<SM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    if (collapsed_ok(ma)) hipLaunchKernelGGL((cdsgp4_coop_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgp4_coop_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 template <class SM>
 inline int launch_cdsgps4_coop(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
-    hipLaunchKernelGGL((cdsgps4_coop_kernel<SM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    if (collapsed_ok(ma)) hipLaunchKernelGGL((cdsgps4_coop_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgps4_coop_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

@@ -66,7 +66,7 @@ int cgp_simulate(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init, dou
     ma.gamma = nullptr; ma.gamma_stride = 0;
     ma.model_id = model->model_id;
     ma.sg.xi = nullptr; ma.sg.w = nullptr; ma.sg.s = 0; ma.sg.group_start = nullptr; ma.sg.n_groups = 0;
-    ma.sg.lds_xi = 0; ma.sg.lds_w = 0; ma.sg.lds_gs = 0;
+    ma.sg.lds_xi = 0; ma.sg.lds_w = 0; ma.sg.lds_gs = 0; ma.sg.flags = 0;
     ma.dt = dt;
     // One wavefront per trial draws the noise of 64 steps in parallel and pays ~160 replicated instructions per step;
     // one lane per trial pays the ~750 instructions of a step once per 64 trials: crossover near 8 waves per SIMD.

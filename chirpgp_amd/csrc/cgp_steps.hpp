@@ -29,6 +29,7 @@ struct SigmaSet {
     const double* __restrict__ w;           // [s]
     const int* __restrict__ group_start;    // [n_groups + 1] or nullptr (every point its own group)
     int s, n_groups;
+    unsigned flags;                          // CGP_SIGMA_* with CGP_SIGMA_STANDARD cleared when the launch wants the literal sums
     // LDS copies as 32-bit LDS addresses (this struct travels in the kernel arguments, where an address_space(3)
     // pointer member would have different sizes in the host and device layouts).
     unsigned lds_xi, lds_w, lds_gs;

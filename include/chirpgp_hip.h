@@ -112,7 +112,16 @@ typedef struct cgp_sigma {
     const double*  w;             /* [s]                                       */
     const int32_t* group_start;   /* [n_groups + 1] (device pointer) or NULL   */
     int32_t        n_groups;      /* ignored when group_start is NULL          */
+    uint32_t       flags;         /* CGP_SIGMA_*                               */
 } cgp_sigma;
+
+/* The caller asserts (to ~1e-13) that the set is a standardised rule -- sum w = 1, sum w xi = 0, sum w xi xi^T = I (true
+ * of SigmaPoints.cubature and SigmaPoints.gauss_hermite) -- and, when group_start is given, that the members of a group
+ * differ in the LAST coordinate only with sum_{k in group} w_k xi_k[d-1] = 0.  For the chirp / harmonic models, whose
+ * last two state components are linear, the kernels may then take the moments of the linear components in closed form
+ * and run the quadrature over one representative per group with the group's total weight: an exact regrouping of the
+ * reference's sums (filters_smoothers.py:88-137), different only in rounding. */
+#define CGP_SIGMA_STANDARD    0x1u
 
 /* Measurement model and initial condition of a filter. */
 typedef struct cgp_init {
@@ -128,6 +137,7 @@ typedef struct cgp_init {
 #define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
 #define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
 #define CGP_GENERIC_KERNEL    0x10u  /* filters: force the generic kernel where a lane-cooperative specialisation exists   */
+#define CGP_LITERAL_SIGMA_SUM  0x40u  /* sigma-point methods: sum over every point even when the set is CGP_SIGMA_STANDARD     */
 #define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */

@@ -18,8 +18,9 @@ RTOL = 1e-5
 WAVE = dict(flags=0x2)
 THREAD = dict(flags=0x4)
 WAVE_SEQ = dict(flags=0x2 | 0x8 | 0x10)     # wave per trial, step-by-step smoother scan, generic (non-cooperative) filter kernels
+WAVE_LITERAL = dict(flags=0x2 | 0x40)       # cooperative kernels summing over every sigma point (no collapsed quadrature)
 SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
-          pytest.param(THREAD, id='lane_per_trial')]
+          pytest.param(THREAD, id='lane_per_trial'), pytest.param(WAVE_LITERAL, id='wave_literal_sigma_sum')]
 
 
 def _fs():
