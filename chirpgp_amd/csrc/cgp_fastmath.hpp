@@ -48,12 +48,9 @@ CGP_DEV double div_nr(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
-// exp(x): x = k ln2 + r, Taylor of degree 13 on |r| <= ln2 / 2 (truncation 4e-18), v_ldexp_f64.
-// Overflows to +inf above 709.78 like libm; NaN in -> NaN out.
-CGP_DEV double fast_exp(double x) {
-    const double k = __builtin_rint(x * kLog2e);
-    double r = fma(-k, kLn2Hi, x);
-    r = fma(-k, kLn2Lo, r);
+// sum_{i <= 13} r^i / i!, Horner.  (Estrin's scheme was measured here too: neutral in the sigma-point and lane-per-trial
+// kernels, which have other work to overlap; it pays only in the cooperative EKF, see softplus_pair_uniform below.)
+CGP_DEV double exp_poly(double r) {
     double p = 1.0 / 6227020800.0;
     p = horner(p, r, 1.0 / 479001600.0);
     p = horner(p, r, 1.0 / 39916800.0);
@@ -67,7 +64,16 @@ CGP_DEV double fast_exp(double x) {
     p = horner(p, r, 1.0 / 6.0);
     p = horner(p, r, 0.5);
     p = horner(p, r, 1.0);
-    p = horner(p, r, 1.0);
+    return horner(p, r, 1.0);
+}
+
+// exp(x): x = k ln2 + r, Taylor of degree 13 on |r| <= ln2 / 2 (truncation 4e-18), v_ldexp_f64.
+// Overflows to +inf above 709.78 like libm; NaN in -> NaN out.
+CGP_DEV double fast_exp(double x) {
+    const double k = __builtin_rint(x * kLog2e);
+    double r = fma(-k, kLn2Hi, x);
+    r = fma(-k, kLn2Lo, r);
+    const double p = exp_poly(r);
     double y = __builtin_amdgcn_ldexp(p, (int)k);
     y = (x > 709.782712893384) ? __builtin_inf() : y;
     y = (x < -745.2) ? 0.0 : y;
@@ -145,20 +151,7 @@ CGP_DEV double fast_exp_core(double x) {
     const double k = __builtin_rint(x * kLog2e);
     double r = fma(-k, kLn2Hi, x);
     r = fma(-k, kLn2Lo, r);
-    double p = 1.0 / 6227020800.0;
-    p = horner(p, r, 1.0 / 479001600.0);
-    p = horner(p, r, 1.0 / 39916800.0);
-    p = horner(p, r, 1.0 / 3628800.0);
-    p = horner(p, r, 1.0 / 362880.0);
-    p = horner(p, r, 1.0 / 40320.0);
-    p = horner(p, r, 1.0 / 5040.0);
-    p = horner(p, r, 1.0 / 720.0);
-    p = horner(p, r, 1.0 / 120.0);
-    p = horner(p, r, 1.0 / 24.0);
-    p = horner(p, r, 1.0 / 6.0);
-    p = horner(p, r, 0.5);
-    p = horner(p, r, 1.0);
-    p = horner(p, r, 1.0);
+    const double p = exp_poly(r);
     return __builtin_amdgcn_ldexp(p, (int)k);
 }
 
@@ -268,11 +261,21 @@ CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, 
         const double k = __builtin_rint(nx * R.log2e);
         double r = fma(-k, R.ln2hi, nx);
         r = fma(-k, R.ln2lo, r);
-        double p = R.ex[0];
-        CGP_UNROLL for (int i = 1; i < 14; i++) p = horner(p, r, R.ex[i]);
+        // Estrin's scheme: the degree-13 polynomial in four dependent levels instead of thirteen (this chain is the
+        // start of every step's critical path and nothing else can be issued beside it).  c_i = ex[13 - i].
+        const double r2 = r * r;
+        const double a0 = horner(R.ex[12], r, R.ex[13]), a1 = horner(R.ex[10], r, R.ex[11]), a2 = horner(R.ex[8], r, R.ex[9]);
+        const double a3 = horner(R.ex[6], r, R.ex[7]), a4 = horner(R.ex[4], r, R.ex[5]), a5 = horner(R.ex[2], r, R.ex[3]);
+        const double a6 = horner(R.ex[0], r, R.ex[1]);
+        const double r4 = r2 * r2;
+        const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2), b2 = horner(a5, r2, a4);
+        const double r8 = r4 * r4;
+        const double d0 = horner(b1, r4, b0), d1 = horner(a6, r4, b2);
+        const double p = horner(d1, r8, d0);
         const double t = __builtin_amdgcn_ldexp(p, (int)k);
-        double q = R.lp[0];
-        CGP_UNROLL for (int i = 1; i < 6; i++) q = horner(q, t, R.lp[i]);
+        const double t2 = t * t;
+        const double l0 = horner(R.lp[4], t, R.lp[5]), l1 = horner(R.lp[2], t, R.lp[3]), l2 = horner(R.lp[0], t, R.lp[1]);
+        const double q = horner(horner(l2, t2, l1), t2, l0);
         sp = fma(q, t, x);
         dsp = rcp_nr(1.0 + t);
         return;
