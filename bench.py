@@ -134,6 +134,9 @@ def main():
     ap.add_argument('--T', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--flags', type=int, default=0, help='CGP_* flag bits forwarded to the engine (e.g. 2 = wave per trial)')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='multi-process dry run on fewer GPUs than ranks: ranks share devices and the collectives go over '
+                         'gloo on host copies (RCCL refuses two ranks on one device); timings are then meaningless')
     args = ap.parse_args()
 
     import torch
@@ -143,10 +146,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU')
+    if args.rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    def coll(t):
+        """Tensor as the process group wants it: HBM for RCCL, a host copy for the gloo rehearsal."""
+        return t.cpu() if args.rehearse else t
 
     from chirpgp_amd import filters_smoothers as fs
 
@@ -196,7 +208,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _engine.kernel_events = None
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    tmax = coll(torch.tensor([elapsed], dtype=torch.float64, device='cuda'))
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -205,7 +217,7 @@ def main():
     gather_ms = None
     if world > 1:
         from chirpgp_amd import parallel
-        last = f[2][:, -1].contiguous()
+        last = coll(f[2][:, -1].contiguous())
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         out = parallel.all_gather_trials(last, world * B)
