@@ -253,61 +253,81 @@ struct FastMathImm {};
 CGP_DEV void softplus_pair_uniform(const FastMathImm&, double x, double& sp, double& dsp) { softplus_pair_uniform(x, sp, dsp); }
 CGP_DEV void fast_sincos_uniform(const FastMathImm&, double x, double& sn, double& cs) { fast_sincos_uniform(x, sn, cs); }
 
-// softplus_pair_uniform / fast_sincos_uniform with pinned coefficients (identical arithmetic).
-CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp) {
-    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    if (__builtin_expect(hx >= 0x40180000 && hx < 0x4085E000, 1)) {
-        const double nx = -x;
-        const double k = __builtin_rint(nx * R.log2e);
-        double r = fma(-k, R.ln2hi, nx);
-        r = fma(-k, R.ln2lo, r);
-        // Estrin's scheme: the degree-13 polynomial in four dependent levels instead of thirteen (this chain is the
-        // start of every step's critical path and nothing else can be issued beside it).  c_i = ex[13 - i].
-        const double r2 = r * r;
-        const double a0 = horner(R.ex[12], r, R.ex[13]), a1 = horner(R.ex[10], r, R.ex[11]), a2 = horner(R.ex[8], r, R.ex[9]);
-        const double a3 = horner(R.ex[6], r, R.ex[7]), a4 = horner(R.ex[4], r, R.ex[5]), a5 = horner(R.ex[2], r, R.ex[3]);
-        const double a6 = horner(R.ex[0], r, R.ex[1]);
-        const double r4 = r2 * r2;
-        const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2), b2 = horner(a5, r2, a4);
-        const double r8 = r4 * r4;
-        const double d0 = horner(b1, r4, b0), d1 = horner(a6, r4, b2);
-        const double p = horner(d1, r8, d0);
-        const double t = __builtin_amdgcn_ldexp(p, (int)k);
-        const double t2 = t * t;
-        const double l0 = horner(R.lp[4], t, R.lp[5]), l1 = horner(R.lp[2], t, R.lp[3]), l2 = horner(R.lp[0], t, R.lp[1]);
-        const double q = horner(horner(l2, t2, l1), t2, l0);
-        sp = fma(q, t, x);
-        dsp = rcp_nr(1.0 + t);
-        return;
+// softplus_pair_uniform / fast_sincos_uniform with pinned coefficients, arranged for LATENCY: these two calls are the
+// head of every EKF step's dependent chain (680 of a step's 1200 cycles in the first MFMA kernel; per-op latencies on
+// MI355X from tools/ubench/f64_ops.hip: dependent v_fma_f64 8 cycles, readfirstlane -> scalar compare -> branch 43,
+// v_cmp -> v_cndmask 20, v_rcp_f64 19).  So:
+//   * the common regime is evaluated unconditionally and the regime test is a scalar compare issued at the top and
+//     consumed by a rarely-taken forward branch at the bottom (the fix-up recomputes in the reference's naive form);
+//   * every polynomial is in Estrin form (3-4 dependent levels instead of 6-13);
+//   * the sin / cos quadrant logic stays on the vector ALU, off the critical path, instead of a round trip through
+//     the scalar unit;
+//   * CHECK = false drops the fix-up branches altogether and only ORs the verdict into *uncommon: a branch inside the
+//     step splits it into basic blocks that the instruction scheduler cannot interleave (measured: 167 cycles per step
+//     for the two never-taken branches), so the EKF kernel runs whole 64-step chunks speculatively and repeats a
+//     chunk with CHECK = true if any of its steps left the common regime (cgp_mfma4.hpp).
+template <bool CHECK = true>
+CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp, unsigned* uncommon = nullptr) {
+    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    const bool common = (hx - 0x40180000u) < (0x4085E000u - 0x40180000u);          // 6.0 <= x < 700.0
+    const double nx = -x;
+    const double k = __builtin_rint(nx * R.log2e);
+    double r = fma(-k, R.ln2hi, nx);
+    r = fma(-k, R.ln2lo, r);
+    // exp(r), c_i = ex[13 - i]
+    const double r2 = r * r;
+    const double a0 = horner(R.ex[12], r, R.ex[13]), a1 = horner(R.ex[10], r, R.ex[11]), a2 = horner(R.ex[8], r, R.ex[9]);
+    const double a3 = horner(R.ex[6], r, R.ex[7]), a4 = horner(R.ex[4], r, R.ex[5]), a5 = horner(R.ex[2], r, R.ex[3]);
+    const double a6 = horner(R.ex[0], r, R.ex[1]);
+    const double r4 = r2 * r2;
+    const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2), b2 = horner(a5, r2, a4);
+    const double r8 = r4 * r4;
+    const double d0 = horner(b1, r4, b0), d1 = horner(a6, r4, b2);
+    const double t = __builtin_amdgcn_ldexp(horner(d1, r8, d0), (int)k);
+    // log1p(t) / t = 1 - t/2 + t^2/3 - t^3/4 + t^4/5 - t^5/6
+    const double t2 = t * t;
+    const double l0 = horner(R.lp[4], t, R.lp[5]), l1 = horner(R.lp[2], t, R.lp[3]), l2 = horner(R.lp[0], t, R.lp[1]);
+    const double q = horner(horner(l2, t2, l1), t2, l0);
+    sp = fma(q, t, x);
+    dsp = rcp_nr(1.0 + t);
+    if (!CHECK) *uncommon |= common ? 0u : 1u;     // speculative callers collect the verdict and redo the work if it is set
+    if (CHECK && __builtin_expect(!common, 0)) {            // elsewhere, and for inf / NaN: the naive form of models.py:50 as is
+        const double e = fast_exp(x);
+        const double z = e + 1.0;
+        sp = fast_log_ge1(z);
+        dsp = e * rcp_nr(z);
     }
-    const double e = fast_exp(x);
-    const double z = e + 1.0;
-    sp = fast_log_ge1(z);
-    dsp = e * rcp_nr(z);
 }
-CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, double& cs) {
-    const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffff;
-    if (__builtin_expect(hx >= 0x40F86A00, 0)) {
-        sincos(x, &sn, &cs);
-        return;
-    }
+template <bool CHECK = true>
+CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, double& cs, unsigned* uncommon = nullptr) {
+    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffffu;
+    const bool common = hx < 0x40F86A00u;                                          // |x| < 1e5 (not inf, not NaN)
     const double n = __builtin_rint(x * R.two_over_pi);
     double r = fma(-n, R.pio2_1, x);
     r = fma(-n, R.pio2_2, r);
     r = fma(-n, R.pio2_3, r);
-    const double r2 = r * r;
-    double ps = R.sn[0];
-    CGP_UNROLL for (int i = 1; i < 8; i++) ps = horner(ps, r2, R.sn[i]);
-    double pc = R.cs[0];
-    CGP_UNROLL for (int i = 1; i < 7; i++) pc = horner(pc, r2, R.cs[i]);
-    const double s0 = fma(-(r * r2), ps, r);
-    const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
-    const int q = __builtin_amdgcn_readfirstlane((int)n);
-    const bool swap = (q & 1) != 0;
+    // quadrant: swap mask and sign bits from the integer n, per lane (same in every lane), ready long before the
+    // polynomials are
+    const int qi = (int)n;
+    const bool swap = (qi & 1) != 0;
+    const int sa = (qi & 2) << 30, sb = ((qi + 1) & 2) << 30;
+    const double z = r * r;
+    const double z2 = z * z;
+    // sin: r - r^3 (c0 + c1 z + ... + c7 z^7), c_i = sn[7 - i];  cos: 1 - z/2 + z^2 (c0 + ... + c6 z^6), c_i = cs[6 - i]
+    const double sa0 = horner(R.sn[6], z, R.sn[7]), sa1 = horner(R.sn[4], z, R.sn[5]), sa2 = horner(R.sn[2], z, R.sn[3]);
+    const double sa3 = horner(R.sn[0], z, R.sn[1]);
+    const double ca0 = horner(R.cs[5], z, R.cs[6]), ca1 = horner(R.cs[3], z, R.cs[4]), ca2 = horner(R.cs[1], z, R.cs[2]);
+    const double z4 = z2 * z2;
+    const double sb0 = horner(sa1, z2, sa0), sb1 = horner(sa3, z2, sa2);
+    const double cb0 = horner(ca1, z2, ca0), cb1 = horner(R.cs[0], z2, ca2);
+    const double ps = horner(sb1, z4, sb0), pc = horner(cb1, z4, cb0);
+    const double s0 = fma(-(r * z), ps, r);
+    const double c0 = fma(z2, pc, fma(-0.5, z, 1.0));
     const double a = swap ? c0 : s0, b = swap ? s0 : c0;
-    const int sa = (q & 2) << 30, sb = ((q + 1) & 2) << 30;
     sn = __hiloint2double(__double2hiint(a) ^ sa, __double2loint(a));
     cs = __hiloint2double(__double2hiint(b) ^ sb, __double2loint(b));
+    if (!CHECK) *uncommon |= common ? 0u : 1u;
+    if (CHECK && __builtin_expect(!common, 0)) sincos(x, &sn, &cs);                 // out of line: rare
 }
 
 // Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of

@@ -1,0 +1,200 @@
+// cgp_mfma4.hpp -- the d = 4 EKF step of BASELINE config C2 on the float64 matrix cores.
+//
+// v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 blocks per wavefront, one element of A, B and C / D per
+// lane.  Lane layout on gfx950, found with tools/ubench/mfma_f64_layout.hip:
+//
+//     lane = 16 r + 4 b + q     b = block;   A holds A_b[q][r],   B holds B_b[r][q],   C / D hold D_b[r][q]
+//
+// so a register that carries X[r][q] ("natural" layout) is X as the B operand or the result, and X^T as the A operand.
+// The covariance therefore lives at lane (r, q) = (lane >> 4, lane & 3) -- matrix row = DPP row, column = lane of the
+// quad -- replicated over the four blocks, and one register RJT holding J[q][r] serves twice:
+//
+//     Q  = P J^T            mfma(A = P (symmetric), B = RJT)
+//     Pp = J Q + Sigma      mfma(A = RJT,           B = Q,   C = Sigma)
+//     PH[r] (per row)       mfma(A = Pp,            B = H[r])                the measurement vector is a per-lane constant
+//     PH[q] (per column)    mfma(A = H[r],          B = Pp)
+//     S = H . PH + Xi       mfma(A = H[r],          B = PH[r], C = Xi)       lands in every lane
+//
+// Five matrix instructions replace the 85 DPP moves and FMAs of the cooperative kernel's covariance algebra
+// (cgp_coop4.hpp); what stays on the vector ALU is the scalar chain softplus -> sincos -> mean and the rank-one
+// update.  This is not a GEMM-shaped workload being forced onto MFMA: the products ARE 4 x 4 x 4, and the instruction
+// is used for its latency (one issue slot, 4 passes) on a T-serial chain.
+//
+// Speculation.  The step is one dependent chain, and a branch anywhere in it costs far more than its own cycles: it
+// cuts the step into basic blocks that cannot be interleaved (tools/ekf_variants.py: 167 cycles of a 1070-cycle step
+// for the two never-taken regime checks of softplus and sincos).  So a chunk of 64 steps first runs with NO checks --
+// the common-regime formulas evaluated blindly, the verdicts ORed into a scalar -- and only if some step left the
+// common regime (frequency state below 6, |angle| >= 1e5, inf, NaN) is the chunk repeated from its saved state with
+// the checked step, which reproduces the reference's naive arithmetic there.  After a repeat the kernel stays on the
+// checked step for kCheckedChunks chunks, so a record that lives outside the common regime pays at most 1/16 extra.
+#pragma once
+#include "cgp_coop4.hpp"
+
+namespace cgp {
+
+// A trial's output array as a raw buffer: stores take a 32-bit byte offset per lane and the hardware drops the lanes
+// whose offset is past the end (and all of them if the output is not wanted: zero records).  "Which lanes write" thus
+// becomes data instead of control flow -- an exec-masked store costs a skip branch, and a branch in the middle of a
+// step splits the basic block the scheduler works on (cgp_fastmath.hpp).  kOobOffset marks a lane that never writes;
+// windows are limited to 2 GiB so that marker + a small immediate offset stays out of range.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;
+struct OobWindow {
+    __amdgpu_buffer_rsrc_t rsrc;
+    CGP_DEV void init(double* base, int64_t bytes) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base ? (int)bytes : 0, 0x27000);
+    }
+    CGP_DEV void store(double v, unsigned off) const {
+        u32x2_t d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)off, 0, 0);
+    }
+    CGP_DEV void store2(double a, double b, unsigned off) const {
+        u32x4_t d; d.x = (unsigned)__double2loint(a); d.y = (unsigned)__double2hiint(a);
+        d.z = (unsigned)__double2loint(b); d.w = (unsigned)__double2hiint(b);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)off, 0, 0);
+    }
+};
+constexpr int64_t kOobMaxBytes = 0x7FFFFF00;
+
+CGP_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+constexpr int kCheckedChunks = 16;
+
+struct Ekf4MfmaConst {
+    double M0, M1, M2, M3, rho, ang, dwc;      // M32 block, exp(-lam dt), dt 2 pi fs, dt 2 pi fs (derivative scale)
+    double H0, H1, H2, H3, Hr, Xi, Sig;
+    double kc, ks, k0, k1, kk;                 // J[q][r] = kc c + ks s + k0 jv0 + k1 jv1 + kk
+};
+struct Ekf4State { double P, u0, u1, u2, u3; };
+
+template <bool CHECK>
+CGP_DEV void ekf4_mfma_step(const Ekf4MfmaConst& K, const FastMathRegs& fm, double y, Ekf4State& x, double& S, double& innov,
+                            unsigned* uncommon) {
+    // ---- replicated scalar chain (models.py:296-301, N1)
+    double sp, dsp;
+    softplus_pair_uniform<CHECK>(fm, x.u2, sp, dsp, uncommon);
+    // theta = dt 2 pi g(u2) fs as ONE multiply by the constant dt 2 pi fs (the reference rounds three times,
+    // models.py:296-297: a relative 1e-16 on an angle of ~0.05 rad), two multiplies less on the chain
+    double s1, c1;
+    fast_sincos_uniform<CHECK>(fm, K.ang * sp, s1, c1, uncommon);
+    const double c = c1 * K.rho, s = s1 * K.rho;
+    const double f0 = fma(c, x.u0, -s * x.u1), f1 = fma(s, x.u0, c * x.u1);
+    const double f2 = fma(K.M0, x.u2, K.M1 * x.u3), f3 = fma(K.M2, x.u2, K.M3 * x.u3);
+    const double dth = K.dwc * dsp;
+    const double jv0 = -dth * f1, jv1 = dth * f0;
+    const double RJT = fma(K.k0, jv0, fma(K.k1, jv1, fma(K.kc, c, fma(K.ks, s, K.kk))));
+    // ---- predict: Pp = J P J^T + Sigma
+    const double Q = mfma4(x.P, RJT, 0.0);
+    const double Pp = mfma4(RJT, Q, K.Sig);
+    // ---- update (filters_smoothers.py:55-68)
+    const double PHr = mfma4(Pp, K.Hr, 0.0);
+    const double PHq = mfma4(K.Hr, Pp, 0.0);
+    S = mfma4(K.Hr, PHr, K.Xi);
+    const double pred = fma(K.H3, f3, fma(K.H2, f2, fma(K.H1, f1, K.H0 * f0)));
+    innov = y - pred;
+    const double rS = rcp_nr(S);
+    x.P = fma(-(PHr * rS), PHq, Pp);                            // Pf = Pp - K (Pp H)^T
+    const double g = rS * innov;
+    x.u0 = fma(dpp_f64<kQuadBcast0>(PHq), g, f0);               // mf = mp + K innov
+    x.u1 = fma(dpp_f64<kQuadBcast1>(PHq), g, f1);
+    x.u2 = fma(dpp_f64<kQuadBcast2>(PHq), g, f2);
+    x.u3 = fma(dpp_f64<kQuadBcast3>(PHq), g, f3);
+}
+
+__global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicLCD<1> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    Ekf4MfmaConst K;
+    K.M0 = model.M[0]; K.M1 = model.M[1]; K.M2 = model.M[2]; K.M3 = model.M[3];
+    K.rho = model.rho;
+    K.ang = (model.dt * kTwoPi) * model.fs;
+    K.dwc = K.ang;
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    K.H0 = Hp[0]; K.H1 = Hp[1]; K.H2 = Hp[2]; K.H3 = Hp[3];
+    K.Hr = Hp[r];
+    K.Xi = io.Xi[trial * io.Xi_stride];
+    // Sigma[r][q] (models.py:302-308)
+    K.Sig = 0.0;
+    if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
+    else if (r + q == 5) K.Sig = model.MS[1];
+    // J = [c -s jv0 0; s c jv1 0; 0 0 M0 M1; 0 0 M2 M3], this lane holds J[q][r]
+    K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
+    K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
+    K.k0 = (q == 0 && r == 2) ? 1.0 : 0.0; K.k1 = (q == 1 && r == 2) ? 1.0 : 0.0;
+    K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    Ekf4State x;
+    x.u0 = m0p[0]; x.u1 = m0p[1]; x.u2 = m0p[2]; x.u3 = m0p[3];
+    x.P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    OobWindow mfs, Pfs;
+    mfs.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
+    Pfs.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+    const bool p_writer = ((lane >> 2) & 3) == 0;                        // block 0: lanes 16 r + q
+    const unsigned p_off = 8u * (4 * r + q);
+
+    FastMathRegs fm;
+    fm.init();
+    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    int checked_left = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        const Ekf4State x0 = x;
+        unsigned uncommon = 0;
+        if (checked_left == 0) {
+            // two steps per iteration: the tail of a step that nothing waits for (stores, latches, u0, u1, u3) can then
+            // be issued under the head of the next step's chain
+#pragma unroll 2
+            for (int slot = 0; slot < nsteps; slot++) {
+                double S, innov;
+                ekf4_mfma_step<false>(K, fm, readlane_f64(ychunk, slot), x, S, innov, &uncommon);
+                if (lane == slot) { S_l = S; innov_l = innov; }
+                const unsigned t = (unsigned)(t0 + slot);
+                Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
+                const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
+                mfs.store2(x.u0, x.u1, m_off);
+                mfs.store2(x.u2, x.u3, m_off + 16u);
+            }
+        }
+        if (checked_left > 0 || uncommon != 0) {
+            if (uncommon != 0) { x = x0; checked_left = kCheckedChunks; }
+            for (int slot = 0; slot < nsteps; slot++) {
+                double S, innov;
+                ekf4_mfma_step<true>(K, fm, readlane_f64(ychunk, slot), x, S, innov, nullptr);
+                if (lane == slot) { S_l = S; innov_l = innov; }
+                const unsigned t = (unsigned)(t0 + slot);
+                Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
+                const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
+                mfs.store2(x.u0, x.u1, m_off);
+                mfs.store2(x.u2, x.u3, m_off + 16u);
+            }
+            checked_left--;
+        }
+        if (want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= kOobMaxBytes; }      // the 2 GiB output windows
+
+inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace cgp

@@ -138,6 +138,7 @@ typedef struct cgp_init {
 #define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
 #define CGP_GENERIC_KERNEL    0x10u  /* filters: force the generic kernel where a lane-cooperative specialisation exists   */
 #define CGP_LITERAL_SIGMA_SUM  0x40u  /* sigma-point methods: sum over every point even when the set is CGP_SIGMA_STANDARD     */
+#define CGP_DPP_KERNEL        0x80u  /* d = 4 EKF: the DPP cooperative kernel instead of the matrix-core (MFMA) one             */
 #define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */

@@ -19,7 +19,8 @@ WAVE = dict(flags=0x2)
 THREAD = dict(flags=0x4)
 WAVE_SEQ = dict(flags=0x2 | 0x8 | 0x10)     # wave per trial, step-by-step smoother scan, generic (non-cooperative) filter kernels
 WAVE_LITERAL = dict(flags=0x2 | 0x40)       # cooperative kernels summing over every sigma point (no collapsed quadrature)
-SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
+WAVE_DPP = dict(flags=0x2 | 0x80)           # d = 4 EKF on the DPP cooperative kernel instead of the MFMA one
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_DPP, id='wave_dpp_ekf'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
           pytest.param(THREAD, id='lane_per_trial'), pytest.param(WAVE_LITERAL, id='wave_literal_sigma_sum')]
 
 
@@ -127,6 +128,29 @@ def test_harmonics_long_batched(kw):
     bk.compare(bk.run_pairs('hip', c, cd_T=300, hip_kw=kw), bk.run_pairs('port', c, cd_T=300), RTOL, 'harmonic3')
     c = _batch_case(cs.harmonic_case, 3, T=800, nh=2, freq_scale=1.7)
     bk.compare(bk.run_pairs('hip', c, cd_T=200, hip_kw=kw), bk.run_pairs('port', c, cd_T=200), RTOL, 'harmonic2')
+
+
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='mfma_speculative'), pytest.param(WAVE_DPP, id='dpp'), pytest.param(THREAD, id='lane_per_trial')])
+def test_frequency_state_crossing_the_softplus_regimes(kw):
+    """The wave-per-trial EKF runs 64-step chunks speculatively in the common regime (frequency state >= 6) and repeats a
+    chunk with the reference's naive softplus when a step left it: records that start below, cross and re-cross the
+    boundary, one that stays below (every chunk repeated, then the checked loop), one that stays above."""
+    import math
+    from oracle import np_models as om_
+    T, dt, Xi = 1500, 1e-3, 0.05
+    ts = dt * np.arange(1, T + 1)
+    recs = []
+    for f_lo, f_hi, seed in [(2.0, 14.0, 1), (9.0, 3.0, 2), (1.0, 2.0, 3), (8.0, 20.0, 4)]:
+        freq = f_lo + (f_hi - f_lo) * 0.5 * (1 - np.cos(2 * math.pi * ts / ts[-1] * 1.5))
+        phase = np.cumsum(freq) * dt
+        recs.append(np.sin(2 * math.pi * phase) + math.sqrt(Xi) * np.random.default_rng(seed).standard_normal(T))
+    c = cs.chirp_case(T=8, params=(0.1, 0.5, 0.1, 0.3, 3., float(om_.g_inv(2.0))), Xi=Xi, dt=dt)
+    c.ys = np.stack(recs)
+    want = bk.run_pairs('port', c, only=('ekf', 'eks'))
+    got = bk.run_pairs('hip', c, hip_kw=kw, only=('ekf', 'eks'))
+    u2 = want['ekf'][0][:, :, 2]
+    assert (u2[0] < 6).any() and (u2[0] > 6).any() and (u2[2] < 6).all() and (u2[3, 200:] > 6).all()
+    bk.compare(got, want, RTOL, 'regime_crossing')
 
 
 def test_chirp_lam0_and_cubature():
