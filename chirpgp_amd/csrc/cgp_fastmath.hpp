@@ -266,15 +266,14 @@ CGP_DEV void fast_sincos_uniform(const FastMathImm&, double x, double& sn, doubl
 //     step splits it into basic blocks that the instruction scheduler cannot interleave (measured: 167 cycles per step
 //     for the two never-taken branches), so the EKF kernel runs whole 64-step chunks speculatively and repeats a
 //     chunk with CHECK = true if any of its steps left the common regime (cgp_mfma4.hpp).
-template <bool CHECK = true>
-CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp, unsigned* uncommon = nullptr) {
-    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
-    const bool common = (hx - 0x40180000u) < (0x4085E000u - 0x40180000u);          // 6.0 <= x < 700.0
+// exp(-x) for |x| < 700 (no overflow / underflow / NaN handling): x = -(k ln2 + r), Estrin on r, v_ldexp_f64.
+template <class Regs>
+CGP_DEV double exp_neg_common(const Regs& R, double x) {
     const double nx = -x;
     const double k = __builtin_rint(nx * R.log2e);
     double r = fma(-k, R.ln2hi, nx);
     r = fma(-k, R.ln2lo, r);
-    // exp(r), c_i = ex[13 - i]
+    // c_i = ex[13 - i]
     const double r2 = r * r;
     const double a0 = horner(R.ex[12], r, R.ex[13]), a1 = horner(R.ex[10], r, R.ex[11]), a2 = horner(R.ex[8], r, R.ex[9]);
     const double a3 = horner(R.ex[6], r, R.ex[7]), a4 = horner(R.ex[4], r, R.ex[5]), a5 = horner(R.ex[2], r, R.ex[3]);
@@ -283,13 +282,74 @@ CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, 
     const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2), b2 = horner(a5, r2, a4);
     const double r8 = r4 * r4;
     const double d0 = horner(b1, r4, b0), d1 = horner(a6, r4, b2);
-    const double t = __builtin_amdgcn_ldexp(horner(d1, r8, d0), (int)k);
+    return __builtin_amdgcn_ldexp(horner(d1, r8, d0), (int)k);
+}
+// softplus and its derivative from t = exp(-x), 6 <= x < 700: x + log1p(t), 1 / (1 + t).
+CGP_DEV void softplus_from_exp_neg(const FastMathRegs& R, double x, double t, double& sp, double& dsp) {
     // log1p(t) / t = 1 - t/2 + t^2/3 - t^3/4 + t^4/5 - t^5/6
     const double t2 = t * t;
     const double l0 = horner(R.lp[4], t, R.lp[5]), l1 = horner(R.lp[2], t, R.lp[3]), l2 = horner(R.lp[0], t, R.lp[1]);
     const double q = horner(horner(l2, t2, l1), t2, l0);
     sp = fma(q, t, x);
     dsp = rcp_nr(1.0 + t);
+}
+// 6.0 <= x < 700.0 as one unsigned compare on the high word of a wave-uniform x (false for NaN and negatives).
+CGP_DEV bool softplus_common_regime(double x) {
+    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return (hx - 0x40180000u) < (0x4085E000u - 0x40180000u);
+}
+// |x| < bound for a wave-uniform x, bound = 2^n given by the high word of its double (false for NaN).
+CGP_DEV bool magnitude_below(double x, unsigned bound_hi) {
+    return ((unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffffu) < bound_hi;
+}
+
+// log1p(t) / t on [0, 1/2] as a polynomial of degree 15 (Chebyshev-node interpolant, tools/gen_math_constants.py;
+// relative error 1.7e-17): with t = exp(-x) it carries the softplus  x + t (log1p(t) / t)  for every x >= ln 2, i.e.
+// every frequency above 1.1 Hz, in four Estrin levels -- one more than the six-term series that only reaches x >= 6.
+constexpr double kLog1pOverT[16] = {
+    1.0, -0.499999999999983, 0.33333333333043524, -0.24999999980360632, 0.19999999298210291, -0.16666651430722035,
+    0.14285495922701988, -0.12497821928598722, 0.11095454366589008, -0.09916989080882566, 0.08761369562912116,
+    -0.07344526523759841, 0.05435248977771075, -0.031930229294847796, 0.012725281636614353, -0.002504592860624598};
+
+// Constants of the speculative EKF step (cgp_mfma4.hpp) pinned in VGPRs: exp, the wide log1p tail, the four
+// coefficients of the small-angle rotation.
+struct SpecRegs {
+    double ex[14], lq[16];
+    double log2e, ln2hi, ln2lo;
+    double s3, s5, c4, c6;       // -1/6, 1/120, 1/24, -1/720
+    CGP_DEV void init() {
+        const double ex_[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                                1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+        CGP_UNROLL for (int i = 0; i < 14; i++) ex[i] = FastMathRegs::pin(ex_[i]);
+        CGP_UNROLL for (int i = 0; i < 16; i++) lq[i] = FastMathRegs::pin(kLog1pOverT[i]);
+        log2e = FastMathRegs::pin(kLog2e); ln2hi = FastMathRegs::pin(kLn2Hi); ln2lo = FastMathRegs::pin(kLn2Lo);
+        s3 = FastMathRegs::pin(-1.0 / 6.0); s5 = FastMathRegs::pin(1.0 / 120.0);
+        c4 = FastMathRegs::pin(1.0 / 24.0); c6 = FastMathRegs::pin(-1.0 / 720.0);
+    }
+};
+// ln 2 <= x < 700 (t = exp(-x) <= 1/2) as one unsigned compare on the high word of a wave-uniform x.
+CGP_DEV bool softplus_wide_regime(double x) {
+    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return (hx - 0x3FE62E43u) < (0x4085E000u - 0x3FE62E43u);
+}
+// softplus and its derivative from t = exp(-x) <= 1/2.
+CGP_DEV void softplus_wide(const SpecRegs& R, double x, double t, double& sp, double& dsp) {
+    const double t2 = t * t;
+    const double a0 = horner(R.lq[1], t, R.lq[0]), a1 = horner(R.lq[3], t, R.lq[2]), a2 = horner(R.lq[5], t, R.lq[4]);
+    const double a3 = horner(R.lq[7], t, R.lq[6]), a4 = horner(R.lq[9], t, R.lq[8]), a5 = horner(R.lq[11], t, R.lq[10]);
+    const double a6 = horner(R.lq[13], t, R.lq[12]), a7 = horner(R.lq[15], t, R.lq[14]);
+    const double t4 = t2 * t2;
+    const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2), b2 = horner(a5, t2, a4), b3 = horner(a7, t2, a6);
+    const double t8 = t4 * t4;
+    const double d0 = horner(b1, t4, b0), d1 = horner(b3, t4, b2);
+    sp = fma(horner(d1, t8, d0), t, x);
+    dsp = rcp_nr(1.0 + t);
+}
+
+template <bool CHECK = true>
+CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp, unsigned* uncommon = nullptr) {
+    const bool common = softplus_common_regime(x);
+    softplus_from_exp_neg(R, x, exp_neg_common(R, x), sp, dsp);
     if (!CHECK) *uncommon |= common ? 0u : 1u;     // speculative callers collect the verdict and redo the work if it is set
     if (CHECK && __builtin_expect(!common, 0)) {            // elsewhere, and for inf / NaN: the naive form of models.py:50 as is
         const double e = fast_exp(x);

@@ -22,10 +22,11 @@
 //
 // Speculation.  The step is one dependent chain, and a branch anywhere in it costs far more than its own cycles: it
 // cuts the step into basic blocks that cannot be interleaved (tools/ekf_variants.py: 167 cycles of a 1070-cycle step
-// for the two never-taken regime checks of softplus and sincos).  So a chunk of 64 steps first runs with NO checks --
-// the common-regime formulas evaluated blindly, the verdicts ORed into a scalar -- and only if some step left the
-// common regime (frequency state below 6, |angle| >= 1e5, inf, NaN) is the chunk repeated from its saved state with
-// the checked step, which reproduces the reference's naive arithmetic there.  After a repeat the kernel stays on the
+// for the two never-taken regime checks of softplus and sincos).  So a chunk of 64 steps first runs with NO branches --
+// the common-regime formulas evaluated blindly (ekf4_mfma_step_spec), the verdicts ORed into a scalar -- and only if
+// some step left the common regime (frequency state below ln 2 or above 700, a jump of the rotation angle beyond the
+// increment bound, inf, NaN) is the chunk repeated from its saved state with the checked step, which evaluates the
+// full functions and reproduces the reference's naive arithmetic there.  After a repeat the kernel stays on the
 // checked step for kCheckedChunks chunks, so a record that lives outside the common regime pays at most 1/16 extra.
 #pragma once
 #include "cgp_coop4.hpp"
@@ -62,26 +63,18 @@ CGP_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfm
 constexpr int kCheckedChunks = 16;
 
 struct Ekf4MfmaConst {
-    double M0, M1, M2, M3, rho, ang, dwc;      // M32 block, exp(-lam dt), dt 2 pi fs, dt 2 pi fs (derivative scale)
+    double M0, M1, M2, M3, rho, ang;           // M32 block, exp(-lam dt), dt 2 pi fs
     double H0, H1, H2, H3, Hr, Xi, Sig;
     double kc, ks, k0, k1, kk;                 // J[q][r] = kc c + ks s + k0 jv0 + k1 jv1 + kk
 };
 struct Ekf4State { double P, u0, u1, u2, u3; };
 
-template <bool CHECK>
-CGP_DEV void ekf4_mfma_step(const Ekf4MfmaConst& K, const FastMathRegs& fm, double y, Ekf4State& x, double& S, double& innov,
-                            unsigned* uncommon) {
-    // ---- replicated scalar chain (models.py:296-301, N1)
-    double sp, dsp;
-    softplus_pair_uniform<CHECK>(fm, x.u2, sp, dsp, uncommon);
-    // theta = dt 2 pi g(u2) fs as ONE multiply by the constant dt 2 pi fs (the reference rounds three times,
-    // models.py:296-297: a relative 1e-16 on an angle of ~0.05 rad), two multiplies less on the chain
-    double s1, c1;
-    fast_sincos_uniform<CHECK>(fm, K.ang * sp, s1, c1, uncommon);
+// Everything of a step after the rotation (c1, s1) = (cos, sin)(theta) and the softplus derivative dsp are known.
+CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
     const double c = c1 * K.rho, s = s1 * K.rho;
     const double f0 = fma(c, x.u0, -s * x.u1), f1 = fma(s, x.u0, c * x.u1);
     const double f2 = fma(K.M0, x.u2, K.M1 * x.u3), f3 = fma(K.M2, x.u2, K.M3 * x.u3);
-    const double dth = K.dwc * dsp;
+    const double dth = K.ang * dsp;
     const double jv0 = -dth * f1, jv1 = dth * f0;
     const double RJT = fma(K.k0, jv0, fma(K.k1, jv1, fma(K.kc, c, fma(K.ks, s, K.kk))));
     // ---- predict: Pp = J P J^T + Sigma
@@ -102,6 +95,48 @@ CGP_DEV void ekf4_mfma_step(const Ekf4MfmaConst& K, const FastMathRegs& fm, doub
     x.u3 = fma(dpp_f64<kQuadBcast3>(PHq), g, f3);
 }
 
+// The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
+CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
+    double sp, dsp, s1, c1;
+    softplus_pair_uniform(x.u2, sp, dsp);
+    // theta = dt 2 pi g(u2) fs as ONE multiply by the constant dt 2 pi fs (the reference rounds three times,
+    // models.py:296-297: a relative 1e-16 on an angle of ~0.05 rad)
+    fast_sincos_uniform(K.ang * sp, s1, c1);
+    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+}
+
+// The speculative step.  Softplus: t = exp(-u2), then x + t q(t) with the degree-15 polynomial q = log1p(t) / t, valid for
+// u2 >= ln 2.  Rotation: (cos, sin)(theta) is advanced INCREMENTALLY from the previous step's,
+//     (cos, sin)(theta) = rotation of (cos, sin)(theta_prev) by d = theta - theta_prev,
+// with sin d, cos d to d^5 / d^6 (remainders < 4e-19 while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
+// fresh sincos.  d is an exact difference (Sterbenz), so the angle does not drift; what accumulates is one rounding
+// per step in the rotation, and the pair is re-anchored with the full sincos at the start of every 64-step chunk
+// (relative error <= 64 x 2e-16).  A step with u2 outside [ln 2, 700) or |d| > 2^-7 (or NaN) sets *uncommon and the
+// whole chunk is repeated with the checked step.
+struct Ekf4Anchor { double th, c1, s1; };
+
+CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
+    double sp, dsp;
+    softplus_pair_uniform(u2, sp, dsp);
+    a.th = K.ang * sp;
+    fast_sincos_uniform(a.th, a.s1, a.c1);
+}
+
+CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
+                                 double& innov, unsigned* uncommon) {
+    double sp, dsp;
+    softplus_wide(R, x.u2, exp_neg_common(R, x.u2), sp, dsp);
+    const double th = K.ang * sp;
+    const double d = th - a.th;
+    const double d2 = d * d, d4 = d2 * d2;
+    const double sd = fma(d * d2, horner(R.s5, d2, R.s3), d);                        // d - d^3/6 + d^5/120
+    const double cd = fma(d4, horner(R.c6, d2, R.c4), fma(-0.5, d2, 1.0));           // 1 - d^2/2 + d^4/24 - d^6/720
+    const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
+    *uncommon |= (softplus_wide_regime(x.u2) && magnitude_below(d, 0x3F800000u)) ? 0u : 1u;
+    a.th = th; a.c1 = c1; a.s1 = s1;
+    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+}
+
 __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3;
@@ -114,7 +149,6 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     K.M0 = model.M[0]; K.M1 = model.M[1]; K.M2 = model.M[2]; K.M3 = model.M[3];
     K.rho = model.rho;
     K.ang = (model.dt * kTwoPi) * model.fs;
-    K.dwc = K.ang;
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
     K.H0 = Hp[0]; K.H1 = Hp[1]; K.H2 = Hp[2]; K.H3 = Hp[3];
     K.Hr = Hp[r];
@@ -145,8 +179,8 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     const bool p_writer = ((lane >> 2) & 3) == 0;                        // block 0: lanes 16 r + q
     const unsigned p_off = 8u * (4 * r + q);
 
-    FastMathRegs fm;
-    fm.init();
+    SpecRegs R;
+    R.init();
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     int checked_left = 0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -156,12 +190,11 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
         const Ekf4State x0 = x;
         unsigned uncommon = 0;
         if (checked_left == 0) {
-            // two steps per iteration: the tail of a step that nothing waits for (stores, latches, u0, u1, u3) can then
-            // be issued under the head of the next step's chain
-#pragma unroll 2
+            Ekf4Anchor anchor;
+            ekf4_anchor(K, x.u2, anchor);
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step<false>(K, fm, readlane_f64(ychunk, slot), x, S, innov, &uncommon);
+                ekf4_mfma_step_spec(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
                 if (lane == slot) { S_l = S; innov_l = innov; }
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
@@ -174,7 +207,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
             if (uncommon != 0) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step<true>(K, fm, readlane_f64(ychunk, slot), x, S, innov, nullptr);
+                ekf4_mfma_step_checked(K, readlane_f64(ychunk, slot), x, S, innov);
                 if (lane == slot) { S_l = S; innov_l = innov; }
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
