@@ -103,6 +103,7 @@ CGP_DEV double coop4_load_sym_entry(const double* __restrict__ p, int li, int lj
     return (li >= lj) ? p[li * 4 + lj] : p[lj * 4 + li];
 }
 
+#ifndef CGP_COOP4_HELPERS_ONLY      // cgp_inst_mfma4.hip takes the helpers above and not a second copy of this kernel
 __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma) {
     const int lane = threadIdx.x;
     const int li = (lane >> 2) & 3, lj = lane & 3;
@@ -206,5 +207,7 @@ inline int launch_ekf4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
     hipLaunchKernelGGL(ekf4_coop_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
+
+#endif
 
 }  // namespace cgp

@@ -1,10 +1,9 @@
 // Lane-cooperative d = 4 kernels (chirp / La Scala models): EKF (cgp_coop4.hpp) and the sigma-point filters and
 // continuous-discrete smoother (cgp_coop4_sigma.hpp), the continuous-discrete EKF / EKS (cgp_coop4_cd.hpp).
 #include "cgp_coop4_cd.hpp"
-#include "cgp_mfma4.hpp"
 namespace cgp {
 int dispatch_filter_coop4(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
-    return ((io.flags & CGP_DPP_KERNEL) || !ekf4_mfma_fits(io)) ? launch_ekf4_coop(io, ma, st) : launch_ekf4_mfma(io, ma, st);
+    return ((io.flags & CGP_DPP_KERNEL) || !ekf4_mfma_fits(io)) ? launch_ekf4_coop(io, ma, st) : dispatch_filter_mfma4(io, ma, st);
 }
 int dispatch_filter_coop4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_sgp4_coop<HarmonicLCD<1>>(io, ma, st); }
 int dispatch_filter_coop4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgp4_coop<HarmonicSDE<1>>(io, ma, st); }

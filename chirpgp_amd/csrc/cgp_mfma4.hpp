@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 
-inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= kOobMaxBytes; }      // the 2 GiB output windows
 
 inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
