@@ -70,9 +70,9 @@ def bytes_per_trial_step(d):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
-    (profiles/r01_v13_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
+    (profiles/r01_v15_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
     FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v13_ekf_eks_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_v15_ekf_eks_pmc.json')
     try:
         prof = json.load(open(path))
     except OSError:
@@ -249,7 +249,7 @@ def main():
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic('ekf4_coop' if dom[0] == 'filter' else 'tp_smoother')
+                         "traffic": (pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother')
                                      if (args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags) else None),
                          "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1]},
             "kernels": {"filter_ms": filt_ms, "smoother_ms": smooth_ms,
