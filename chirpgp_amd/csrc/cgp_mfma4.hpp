@@ -132,7 +132,12 @@ CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, doub
     const double sd = fma(d * d2, horner(R.s5, d2, R.s3), d);                        // d - d^3/6 + d^5/120
     const double cd = fma(d4, horner(R.c6, d2, R.c4), fma(-0.5, d2, 1.0));           // 1 - d^2/2 + d^4/24 - d^6/720
     const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
-    *uncommon |= (softplus_wide_regime(x.u2) && magnitude_below(d, 0x3F800000u)) ? 0u : 1u;
+    // verdicts without compares, scalar registers or branches: clamp the high words into their admissible ranges and
+    // OR the bits the clamp changed into a vector accumulator (non-zero = some step left the regime; NaN, inf and
+    // negative u2 fall outside the signed range [ln 2, 700), NaN / inf angles above the magnitude bound)
+    const int hx = __double2hiint(x.u2);
+    const unsigned hd = (unsigned)__double2hiint(d) & 0x7fffffffu;
+    *uncommon |= (unsigned)(hx ^ max(0x3FE62E43, min(hx, 0x4085DFFF))) | (hd ^ min(hd, 0x3F7FFFFFu));
     a.th = th; a.c1 = c1; a.s1 = s1;
     ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
 }
@@ -181,7 +186,10 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 
     SpecRegs R;
     R.init();
-    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
+    // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
+    __shared__ double2 park[64];
+    double cum = 0.0;
     int checked_left = 0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
@@ -195,7 +203,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_spec(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
-                if (lane == slot) { S_l = S; innov_l = innov; }
+                park[slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
                 const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
@@ -203,12 +211,13 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
                 mfs.store2(x.u2, x.u3, m_off + 16u);
             }
         }
-        if (checked_left > 0 || uncommon != 0) {
-            if (uncommon != 0) { x = x0; checked_left = kCheckedChunks; }
+        const bool redo = __builtin_amdgcn_readfirstlane((int)uncommon) != 0;      // identical in every lane
+        if (checked_left > 0 || redo) {
+            if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_checked(K, readlane_f64(ychunk, slot), x, S, innov);
-                if (lane == slot) { S_l = S; innov_l = innov; }
+                park[slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
                 const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
@@ -217,7 +226,12 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
             }
             checked_left--;
         }
-        if (want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }

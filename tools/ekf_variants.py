@@ -23,8 +23,7 @@ def timed(**kw):
     return sum(ms) / len(ms)
 
 
-for name, kw in [('V1 no softplus', dict(flags=1 << 24)), ('V2 no sincos', dict(flags=2 << 24)), ('V3 no mfma', dict(flags=3 << 24)), ('V4 no rcp', dict(flags=4 << 24)), ('V5 no range checks', dict(flags=5 << 24)),
-                 ('all outputs', {}), ('no Pfs', dict(want=(True, False, True))), ('nll only', dict(want=(False, False, True))),
+for name, kw in [('all outputs', {}), ('no Pfs', dict(want=(True, False, True))), ('nll only', dict(want=(False, False, True))),
                  ('final nll only', dict(want=(False, False, True), nll_final_only=True)), ('no nll', dict(want=(True, True, False))),
                  ('dpp kernel, all outputs', dict(flags=0x80)), ('dpp kernel, final nll only', dict(flags=0x80, want=(False, False, True), nll_final_only=True)),
                  ('generic kernel', dict(flags=0x10))]:
