@@ -114,6 +114,19 @@ struct LanePoints {
     }
 };
 
+// The representative of the group a lane owns in the collapsed quadratures: xi_0..2 of its first member and the group's
+// total weight (zero for lanes without a group).
+struct CollapsedPoint {
+    double xi0, xi1, xi2, W;
+    CGP_DEV void load(const SigmaSet& sg, int lane) {
+        xi0 = xi1 = xi2 = W = 0.0;
+        if (lane < sg.groups()) {
+            const int p0 = sg.template begin<true>(lane), p1 = sg.template end<true>(lane);
+            xi0 = sg.template coord<true>(p0 * 4); xi1 = sg.template coord<true>(p0 * 4 + 1); xi2 = sg.template coord<true>(p0 * 4 + 2);
+            for (int p = p0; p < p1; p++) W += sg.template weight<true>(p);
+        }
+    }
+};
 // Shared prologue of the filter kernels: outputs, measurement chunking and NLL latch live in the kernels themselves.
 struct Coop4FilterOut {
     double* __restrict__ mfs; double* __restrict__ Pfs; double* __restrict__ nll;
@@ -136,7 +149,10 @@ struct Coop4FilterOut {
 };
 
 // ------------------------------------------------------------------------------------------------ sgp_filter, d = 4
-template <class DM>
+// COLLAPSED (CGP_SIGMA_STANDARD sets with at most 32 groups): the quadrature of cgp_steps.hpp:sgp4_prediction_collapsed
+// with one group per lane -- 9 partial sums of ONE point instead of 15 sums over the group's members; the linear
+// components' moments are closed forms evaluated from the gathered covariance.
+template <class DM, bool COLLAPSED>
 __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma) {
     static_assert(DM::D == 4, "d = 4 kernel");
     __shared__ double red[kFanLdsDoubles];
@@ -169,7 +185,17 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
     out.init(io, trial);
     const int ng = sg.groups();
     LanePoints pts;
-    pts.load(sg, lane);
+    CollapsedPoint cpt;
+    if constexpr (COLLAPSED) cpt.load(sg, lane); else pts.load(sg, lane);
+    // collapsed combine, per lane (i, j): which totals / closed forms its entry of Pp is made of
+    const bool both_nl = li < 2 && lj < 2, both_lin = li >= 2 && lj >= 2;
+    const int lo = li < lj ? li : lj, hi_ = li < lj ? lj : li;
+    const int idx_s = 2 + li + lj;                                     // s00, s10, s11 at totals 2, 3, 4
+    const int idx_x2 = 5 + (lo < 2 ? lo : 0), idx_x3 = 7 + (lo < 2 ? lo : 0);
+    const double cm0 = (!both_nl && !both_lin) ? (hi_ == 2 ? model.M[0] : model.M[2]) : 0.0;
+    const double cm1 = (!both_nl && !both_lin) ? (hi_ == 2 ? model.M[1] : model.M[3]) : 0.0;
+    const double v22c = (li == 2 && lj == 2) ? 1.0 : 0.0, v33c = (li == 3 && lj == 3) ? 1.0 : 0.0;
+    const double v32c = (both_lin && li != lj) ? 1.0 : 0.0;
 
     double cum = 0.0, S_l = 1.0, innov_l = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -183,6 +209,49 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
             coop4_gather(P, Pr);
             m.v[0] = u0; m.v[1] = u1; m.v[2] = u2; m.v[3] = u3;
             cholesky<4>(Pr, L, inv);
+            if constexpr (COLLAPSED) {
+                const double d0 = L(0, 0) * cpt.xi0;
+                const double d1 = fma(L(1, 1), cpt.xi1, L(1, 0) * cpt.xi0);
+                const double d2 = fma(L(2, 2), cpt.xi2, fma(L(2, 1), cpt.xi1, L(2, 0) * cpt.xi0));
+                const double d3 = fma(L(3, 2), cpt.xi2, fma(L(3, 1), cpt.xi1, L(3, 0) * cpt.xi0));
+                const double h0 = u0 + d0, h1 = u1 + d1;
+                typename DM::Pre pre;
+                model.precompute(u2 + d2, pre);
+                const double g0 = pre.c[0] * h0 - pre.s[0] * h1, g1 = pre.s[0] * h0 + pre.c[0] * h1;
+                const double w0 = cpt.W * g0, w1 = cpt.W * g1;
+                double* tot = red + kRedChunk * kRedLd;
+                red[0 * kRedLd + lane] = w0; red[1 * kRedLd + lane] = w1;
+                red[2 * kRedLd + lane] = w0 * g0; red[3 * kRedLd + lane] = w1 * g0; red[4 * kRedLd + lane] = w1 * g1;
+                red[5 * kRedLd + lane] = w0 * d2; red[6 * kRedLd + lane] = w1 * d2;
+                red[7 * kRedLd + lane] = w0 * d3; red[8 * kRedLd + lane] = w1 * d3;
+                wave_lds_fence();
+                {
+                    const int r = lane >> 1, h = lane & 1;
+                    const double2* row = reinterpret_cast<const double2*>(red + r * kRedLd + h * 16);
+                    double sum = 0.0;
+                    if (r < 9) sum = row_sum16(row);
+                    sum += dpp_f64<kQuadSwap1>(sum);
+                    if (h == 0 && r < 9) tot[r] = sum;
+                }
+                wave_lds_fence();
+                const double poison = L(0, 0) - L(0, 0);
+                const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
+                const double f0 = tot[0], f1 = tot[1];
+                const double f2 = fma(M0, u2, M1 * u3) + poison, f3 = fma(M2, u2, M3 * u3) + poison;
+                const double t20 = fma(M0, Pr(2, 2), M1 * Pr(3, 2)), t21 = fma(M0, Pr(3, 2), M1 * Pr(3, 3));
+                const double t30 = fma(M2, Pr(2, 2), M3 * Pr(3, 2)), t31 = fma(M2, Pr(3, 2), M3 * Pr(3, 3));
+                const double V22 = fma(t20, M0, t21 * M1), V32 = fma(t30, M0, t31 * M1), V33 = fma(t30, M2, t31 * M3);
+                const double nl = tot[idx_s] - tot[li < 2 ? li : 0] * tot[lj < 2 ? lj : 0];
+                const double mixed = fma(cm0, tot[idx_x2], cm1 * tot[idx_x3]);
+                const double lin = fma(v22c, V22, fma(v32c, V32, v33c * V33));
+                const double Pp = ((both_nl ? nl : (both_lin ? lin : mixed)) + Sig) + poison;
+                wave_lds_fence();
+                double S, innov;
+                coop4_update(meas, Pp, f0, f1, f2, f3, y, P, u0, u1, u2, u3, S, innov);
+                if (lane == slot) { S_l = S; innov_l = innov; }
+                out.store(t0 + slot, lane, P, u0, u1, u2, u3);
+                continue;
+            }
             double acc[15];
             CGP_UNROLL for (int k = 0; k < 15; k++) acc[k] = 0.0;
             if (pts.ok) {
@@ -309,17 +378,6 @@ CGP_DEV void coop4_cd_sgp_rhs(const SM& model, const SigmaSet& sg, const LanePoi
 //     E[a_j] = sum_g W_g a_j(g),   C[i][j] = sum_g W_g d_i(g) a_j(g)   (j < 2),   d = L xi restricted to xi_0..2
 // One point per lane instead of three, 10 partial sums instead of 20, no L[3][3].  A failed Cholesky poisons every
 // output with NaN like the literal sums do.
-struct CollapsedPoint {
-    double xi0, xi1, xi2, W;
-    CGP_DEV void load(const SigmaSet& sg, int lane) {
-        xi0 = xi1 = xi2 = W = 0.0;
-        if (lane < sg.groups()) {
-            const int p0 = sg.template begin<true>(lane), p1 = sg.template end<true>(lane);
-            xi0 = sg.template coord<true>(p0 * 4); xi1 = sg.template coord<true>(p0 * 4 + 1); xi2 = sg.template coord<true>(p0 * 4 + 2);
-            for (int p = p0; p < p1; p++) W += sg.template weight<true>(p);
-        }
-    }
-};
 // per-lane selectors of the combine: which closed-form column the lane's (i, j) and (j, i) entries come from
 struct CollapsedRole {
     int tij, tji;                 // indices of C[i][j], C[j][i] among the totals (valid when the column is < 2)
@@ -555,7 +613,8 @@ inline bool collapsed_ok(const ModelArgs& ma) {
 template <class DM>
 inline int launch_sgp4_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
-    hipLaunchKernelGGL((sgp4_coop_kernel<DM>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    if (collapsed_ok(ma)) hipLaunchKernelGGL((sgp4_coop_kernel<DM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((sgp4_coop_kernel<DM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 template <class SM>

@@ -6,6 +6,7 @@
 //                 redundantly (identically) by all lanes so no broadcast is ever needed.
 //   WAVE = false  one lane per trial (large batches): the fan is a serial loop, no LDS.
 #pragma once
+#include <type_traits>
 #include "cgp_math.hpp"
 #include "cgp_models.hpp"
 
@@ -118,6 +119,13 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
     constexpr int D = DM::D;
     constexpr int NS = Sym<D>::N;
     constexpr int R = 1 + D + NS + (CROSS ? D * D : 0);
+    if constexpr (!WAVE && std::is_same<DM, HarmonicLCD<1>>::value) {
+        // one lane does the whole fan: the collapsed quadrature where the set allows it (wave-uniform decision)
+        if (sgp_collapsible<DM>(sg)) {
+            sgp4_prediction_collapsed<CROSS, ST>(model, sg, mf, Pf, mp, Pp, DT);
+            return;
+        }
+    }
     Sym<D> L; Vec<D> inv;
     cholesky<D>(Pf, L, inv);
     double acc[R];
@@ -161,6 +169,76 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
         CGP_UNROLL for (int i = 0; i < D; i++)
             CGP_UNROLL for (int j = 0; j < D; j++) DT.a[j][i] = acc[1 + D + NS + i * D + j] - mf.v[i] * mp.v[j];
     }
+}
+
+// The same prediction for the d = 4 chirp / La Scala LCD model and a CGP_SIGMA_STANDARD set, with the linear structure
+// taken out of the quadrature (include/chirpgp_hip.h).  f_0, f_1 = rho Rot(theta(chi_2)) (chi_0, chi_1) depend on
+// xi_0..2 only (L is lower-triangular), f_2, f_3 = M (chi_2, chi_3) are linear, and sum w = 1, sum w xi = 0,
+// sum w xi xi^T = I, so with W_g the total weight of a group and d = L xi restricted to xi_0..2 (d_3 without L_33):
+//     mp_a = sum_g W_g f_a                                        a < 2        mp_{2,3} = M m_{2,3}
+//     Pp_ab = sum_g W_g f_a f_b - mp_a mp_b + q delta_ab          a, b < 2     Pp_{2..3,2..3} = M P_{2..3,2..3} M^T + Sigma
+//     Pp_ab = sum_c M_bc X_ac,  X_ac = sum_g W_g f_a d_{2+c}      a < 2 <= b
+//     D[i][a] = sum_g W_g d_i f_a   (= X for i >= 2)              a < 2        D[i][b] = sum_c M_bc P[i][2+c]    b >= 2
+// an exact regrouping of filters_smoothers.py:88-121 / :525 -- one evaluation per GROUP (27 for Gauss-Hermite order 3
+// instead of 81 points), 9 (13 with the cross term) partial sums instead of 15 (31).  One lane does all groups; a
+// failed Cholesky poisons every output with NaN like the literal sums do.
+template <bool CROSS, bool ST>
+CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
+                                       Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
+    Sym<4> L; Vec<4> inv;
+    cholesky<4>(Pf, L, inv);
+    double sf0 = 0.0, sf1 = 0.0, s00 = 0.0, s10 = 0.0, s11 = 0.0;
+    double x02 = 0.0, x12 = 0.0, x03 = 0.0, x13 = 0.0, c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+    const int ng = sg.groups();
+    for (int g = 0; g < ng; g++) {
+        const int p0 = sg.template begin<ST>(g), p1 = sg.template end<ST>(g);
+        double W = 0.0;
+        for (int p = p0; p < p1; p++) W += sg.template weight<ST>(p);
+        const double xi0 = sg.template coord<ST>(p0 * 4), xi1 = sg.template coord<ST>(p0 * 4 + 1), xi2 = sg.template coord<ST>(p0 * 4 + 2);
+        const double d0 = L(0, 0) * xi0;
+        const double d1 = fma(L(1, 1), xi1, L(1, 0) * xi0);
+        const double d2 = fma(L(2, 2), xi2, fma(L(2, 1), xi1, L(2, 0) * xi0));
+        const double d3 = fma(L(3, 2), xi2, fma(L(3, 1), xi1, L(3, 0) * xi0));
+        const double h0 = mf.v[0] + d0, h1 = mf.v[1] + d1;
+        HarmonicLCD<1>::Pre pre;
+        model.precompute(mf.v[2] + d2, pre);
+        const double f0 = pre.c[0] * h0 - pre.s[0] * h1, f1 = pre.s[0] * h0 + pre.c[0] * h1;
+        const double w0 = W * f0, w1 = W * f1;
+        sf0 += w0; sf1 += w1;
+        s00 = fma(w0, f0, s00); s10 = fma(w1, f0, s10); s11 = fma(w1, f1, s11);
+        x02 = fma(w0, d2, x02); x12 = fma(w1, d2, x12); x03 = fma(w0, d3, x03); x13 = fma(w1, d3, x13);
+        if (CROSS) { c00 = fma(w0, d0, c00); c01 = fma(w1, d0, c01); c10 = fma(w0, d1, c10); c11 = fma(w1, d1, c11); }
+    }
+    const double poison = L(0, 0) - L(0, 0);          // 0, or NaN when the factorisation failed
+    const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
+    mp.v[0] = sf0; mp.v[1] = sf1;
+    mp.v[2] = fma(M0, mf.v[2], M1 * mf.v[3]) + poison;
+    mp.v[3] = fma(M2, mf.v[2], M3 * mf.v[3]) + poison;
+    Pp(0, 0) = (s00 - sf0 * sf0) + model.q;
+    Pp(1, 0) = s10 - sf1 * sf0;
+    Pp(1, 1) = (s11 - sf1 * sf1) + model.q;
+    Pp(2, 0) = fma(M0, x02, M1 * x03); Pp(2, 1) = fma(M0, x12, M1 * x13);
+    Pp(3, 0) = fma(M2, x02, M3 * x03); Pp(3, 1) = fma(M2, x12, M3 * x13);
+    const double t20 = fma(M0, Pf(2, 2), M1 * Pf(3, 2)), t21 = fma(M0, Pf(3, 2), M1 * Pf(3, 3));
+    const double t30 = fma(M2, Pf(2, 2), M3 * Pf(3, 2)), t31 = fma(M2, Pf(3, 2), M3 * Pf(3, 3));
+    Pp(2, 2) = (fma(t20, M0, t21 * M1) + model.MS[0]) + poison;
+    Pp(3, 2) = (fma(t30, M0, t31 * M1) + model.MS[1]) + poison;
+    Pp(3, 3) = (fma(t30, M2, t31 * M3) + model.MS[2]) + poison;
+    if (CROSS) {
+        // DT[j][i] = D[i][j]
+        DT.a[0][0] = c00; DT.a[0][1] = c10; DT.a[0][2] = x02; DT.a[0][3] = x03;
+        DT.a[1][0] = c01; DT.a[1][1] = c11; DT.a[1][2] = x12; DT.a[1][3] = x13;
+        CGP_UNROLL for (int i = 0; i < 4; i++) {
+            const double pi2 = i >= 2 ? Pf(i, 2) : Pf(2, i), pi3 = Pf(3, i);
+            DT.a[2][i] = fma(M0, pi2, M1 * pi3) + poison;
+            DT.a[3][i] = fma(M2, pi2, M3 * pi3) + poison;
+        }
+    }
+}
+// Whether a launch may take the collapsed path: the caller's assertion, groups, and the d = 4 harmonic family.
+template <class DM> CGP_DEV bool sgp_collapsible(const SigmaSet& sg) {
+    if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) return (sg.flags & 1u /* CGP_SIGMA_STANDARD */) && sg.group_start;
+    else return false;
 }
 
 // Sigma-point moment ODE of an SDE model, filters_smoothers.py:124-137: dm = E[a], dP = C + C^T + gamma,
