@@ -86,7 +86,7 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
     S = mfma4(K.Hr, PHr, K.Xi);
     const double pred = fma(K.H3, f3, fma(K.H2, f2, fma(K.H1, f1, K.H0 * f0)));
     innov = y - pred;
-    const double rS = rcp_nr(S);
+    const double rS = rcp_nr1(S);                               // 2e-15 (one Newton step): two FMAs less on the chain
     x.P = fma(-(PHr * rS), PHq, Pp);                            // Pf = Pp - K (Pp H)^T
     const double g = rS * innov;
     x.u0 = fma(dpp_f64<kQuadBcast0>(PHq), g, f0);               // mf = mp + K innov
