@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
 
     DM model;
     model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    model.wide = true;
     SigmaSet sg = ma.sg;
     sg.stage(dyn_lds(), lane, 64, 4);
     Coop4Meas meas;
@@ -452,6 +453,7 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
 
     SM model;
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    model.wide = true;
     SigmaSet sg = ma.sg;
     sg.stage(dyn_lds(), lane, 64, 4);
     Coop4Meas meas;
@@ -527,6 +529,7 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
 
     SM model;
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    model.wide = true;
     SigmaSet sg = ma.sg;
     sg.stage(dyn_lds(), lane, 64, 4);
     Sym<4> gamma;

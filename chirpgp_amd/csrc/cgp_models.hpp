@@ -15,8 +15,50 @@
 
 namespace cgp {
 
-// softplus in the reference's naive form log(exp(x) + 1) (models.py:50) and its derivative as jax.jacfwd forms it,
-// exp(x) / (exp(x) + 1): both overflow (inf, NaN) exactly where the reference does.
+// softplus log(exp(x) + 1) (models.py:50) and its derivative exp(x) / (exp(x) + 1), per lane.
+// Common regime, ln 2 <= x < 700 (frequencies above 1.1 Hz):  x + t q(t)  and  1 / (1 + t)  with t = exp(-x) <= 1/2 and
+// q = log1p(t) / t the degree-15 polynomial of cgp_fastmath.hpp -- one exp and a polynomial instead of exp and a full
+// log (42 instead of 63 instructions, half the latency).  If ANY active lane is outside that regime (or NaN) the
+// wavefront also evaluates the reference's naive form, whose overflow behaviour (inf, NaN) is the reference's, and
+// those lanes take it: one wave-uniform branch, not taken in the common case.
+CGP_DEV double log1p_over_t(double t) {
+    const double t2 = t * t;
+    const double a0 = horner(kLog1pOverT[1], t, kLog1pOverT[0]), a1 = horner(kLog1pOverT[3], t, kLog1pOverT[2]);
+    const double a2 = horner(kLog1pOverT[5], t, kLog1pOverT[4]), a3 = horner(kLog1pOverT[7], t, kLog1pOverT[6]);
+    const double a4 = horner(kLog1pOverT[9], t, kLog1pOverT[8]), a5 = horner(kLog1pOverT[11], t, kLog1pOverT[10]);
+    const double a6 = horner(kLog1pOverT[13], t, kLog1pOverT[12]), a7 = horner(kLog1pOverT[15], t, kLog1pOverT[14]);
+    const double t4 = t2 * t2;
+    const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2), b2 = horner(a5, t2, a4), b3 = horner(a7, t2, a6);
+    const double t8 = t4 * t4;
+    return horner(horner(b3, t4, b2), t8, horner(b1, t4, b0));
+}
+CGP_DEV bool softplus_lane_common(double x) { return x >= 0.6931476593017578 && x < 700.0; }      // slightly above ln 2
+CGP_DEV void softplus_pair_wide(double x, double& sp, double& dsp) {
+    const double t = fast_exp_core(-x);
+    sp = fma(log1p_over_t(t), t, x);
+    dsp = rcp_nr(1.0 + t);
+    const bool common = softplus_lane_common(x);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!common) != 0, 0)) {
+        const double e = fast_exp(x);
+        const double z = e + 1.0;
+        const double sp_n = fast_log_ge1(z), dsp_n = e * rcp_nr(z);     // inf * NaN = NaN where the reference has inf / inf = NaN
+        sp = common ? sp : sp_n;
+        dsp = common ? dsp : dsp_n;
+    }
+}
+CGP_DEV double softplus_wide(double x) {
+    const double t = fast_exp_core(-x);
+    double sp = fma(log1p_over_t(t), t, x);
+    const bool common = softplus_lane_common(x);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!common) != 0, 0)) {
+        const double sp_n = fast_log_ge1(fast_exp(x) + 1.0);
+        sp = common ? sp : sp_n;
+    }
+    return sp;
+}
+// The naive form as is: fewer live registers than the pair above (no second path, no 16 polynomial coefficients), which
+// is what counts in the one-lane-per-trial kernels -- they live on occupancy, and the wide form costs them a wave per SIMD
+// (measured: lane-per-trial EKS 2.3 -> 4.6 ms at B = 65536).
 CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
     const double e = fast_exp(x);
     const double z = e + 1.0;
@@ -25,11 +67,14 @@ CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
 }
 CGP_DEV double softplus(double x) { return fast_log_ge1(fast_exp(x) + 1.0); }
 // `uniform` = the argument is the same in all lanes of the wavefront (a wave-per-trial kernel evaluating the model at the
-// trial's mean): one scalar branch then picks the cheap large-x form (cgp_fastmath.hpp).
-CGP_DEV void softplus_pair_sel(bool uniform, double x, double& sp, double& dsp) {
+// trial's mean): one scalar branch then picks the cheap large-x form (cgp_fastmath.hpp).  `wide` = the kernel is latency-
+// rather than occupancy-bound (one wavefront per trial, time-parallel smoother): take the wide common-regime form.
+CGP_DEV void softplus_pair_sel(bool uniform, bool wide, double x, double& sp, double& dsp) {
     if (uniform) softplus_pair_uniform(x, sp, dsp);
+    else if (wide) softplus_pair_wide(x, sp, dsp);
     else softplus_pair(x, sp, dsp);
 }
+CGP_DEV double softplus_sel(bool wide, double x) { return wide ? softplus_wide(x) : softplus(x); }
 
 // Closed-form Matern-3/2 discretisation, models.py:61-73.
 CGP_DEV void m32_solution(double ell, double sigma, double dt, double (&M)[4], double (&S)[3]) {
@@ -46,7 +91,7 @@ template <int D_> struct LinearDisc {
     static constexpr int D = D_;
     Mat<D> F;
     Sym<D> Sigma;
-    bool uniform = false;
+    bool uniform = false, wide = false;
     CGP_DEV void setup(const double* __restrict__ p, double /*dt*/, int /*model_id*/) {
         load_mat<D>(p, F);
         load_sym<D>(p + D * D, Sigma);
@@ -76,6 +121,7 @@ template <int NH> struct HarmonicLCD {
     double rho, q, fs, dt;
     double M[4], MS[3];
     bool uniform = false;      // set by wave-per-trial EKF-type callers: propagate() then sees a wave-uniform state
+    bool wide = false;         // set by latency-bound callers (wave per trial, time-parallel smoother): softplus_pair_sel
     CGP_DEV void setup(const double* __restrict__ p, double dt_, int model_id) {
         dt = dt_;
         if (model_id == 2 /* CGP_M_LASCALA_LCD */) {
@@ -105,7 +151,7 @@ template <int NH> struct HarmonicLCD {
     // sigma-point interface: the rotations depend on u_v only, so points that share chi_v share them
     static constexpr int IVC = IV;
     struct Pre { double c[NH], s[NH]; };
-    CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus(uv)) * fs, p.c, p.s); }
+    CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus_sel(wide, uv)) * fs, p.c, p.s); }
     CGP_DEV void mean_pre(const Vec<D>& u, const Pre& p, Vec<D>& f) const {
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             f.v[2 * k] = p.c[k] * u.v[2 * k] - p.s[k] * u.v[2 * k + 1];
@@ -121,7 +167,7 @@ template <int NH> struct HarmonicLCD {
     }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
         double sp, dsp;
-        softplus_pair_sel(uniform, u.v[IV], sp, dsp);
+        softplus_pair_sel(uniform, wide, u.v[IV], sp, dsp);
         const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         double c[NH], s[NH], jv[2 * NH];
         rotations(w, c, s);
@@ -174,7 +220,7 @@ template <int NH> struct HarmonicLCD {
 template <int D_> struct LinearSDE {
     static constexpr int D = D_;
     Mat<D> A;
-    bool uniform = false;
+    bool uniform = false, wide = false;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { load_mat<D>(p, A); }
     static constexpr int IVC = 0;
     struct Pre {};
@@ -194,11 +240,11 @@ template <int NH> struct HarmonicSDE {
     static constexpr int D = 2 * NH + 2;
     static constexpr int IV = D - 2;
     double lam, gam, fs;
-    bool uniform = false;
+    bool uniform = false, wide = false;
     CGP_DEV void setup(const double* __restrict__ p, int /*model_id*/) { lam = p[0]; gam = sqrt(3.0) / p[1]; fs = p[2]; }
     static constexpr int IVC = IV;
     struct Pre { double w; };
-    CGP_DEV void precompute(double uv, Pre& p) const { p.w = (kTwoPi * softplus(uv)) * fs; }
+    CGP_DEV void precompute(double uv, Pre& p) const { p.w = (kTwoPi * softplus_sel(wide, uv)) * fs; }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
         Pre p;
         precompute(u.v[IV], p);
@@ -217,7 +263,7 @@ template <int NH> struct HarmonicSDE {
     // a(u) and the non-trivial Jacobian pieces: wk[k] and the d/du_v column jv (N2)
     CGP_DEV void pieces(const Vec<D>& u, Vec<D>& a, double (&wk)[NH], double (&jv)[2 * NH]) const {
         double sp, dsp;
-        softplus_pair_sel(uniform, u.v[IV], sp, dsp);
+        softplus_pair_sel(uniform, wide, u.v[IV], sp, dsp);
         const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             wk[k] = w * (double)(k + 1);

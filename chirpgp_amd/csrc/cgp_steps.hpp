@@ -316,7 +316,7 @@ template <class DM, bool WAVE_> struct EkfPredict {
     static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
     CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> T;
         model.propagate(mf, Pf, mp, T, Pp);
@@ -328,7 +328,7 @@ template <class DM, bool WAVE_> struct SgpPredict {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = WAVE; }
     CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> unused;
         sgp_prediction<DM, WAVE, false>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
@@ -342,6 +342,7 @@ template <class SM, bool WAVE_> struct CdEkfPredict {
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.wide = WAVE;
         model.uniform = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         dt = a.dt;
@@ -363,6 +364,7 @@ template <class SM, bool WAVE_> struct CdSgpPredict {
     SM model; Sym<D> gamma; SigmaSet sg; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.wide = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         sg = a.sg; dt = a.dt;
     }
@@ -382,7 +384,7 @@ template <class DM, bool WAVE_> struct EksStep {
     static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
     CGP_DEV void step(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
         model.propagate(mf, Pf, mp, DT, Pp);          // DT = J Pf
@@ -396,7 +398,7 @@ template <class DM, bool WAVE_> struct SgpsStep {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = WAVE; }
     CGP_DEV void step(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
         sgp_prediction<DM, WAVE, true>(model, sg, lane, lds, mf, Pf, mp, Pp, DT);
@@ -422,6 +424,7 @@ template <class SM, bool WAVE_> struct CdEksStep {
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.wide = WAVE;
         model.uniform = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         dt = -a.dt;
@@ -451,6 +454,7 @@ template <class SM, bool WAVE_> struct CdSgpsStep {
     SM model; Sym<D> gamma; SigmaSet sg; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
         model.setup(a.params + trial * a.param_stride, a.model_id);
+        model.wide = WAVE;
         load_sym<D>(a.gamma + trial * a.gamma_stride, gamma);
         sg = a.sg; dt = -a.dt;
     }
@@ -651,7 +655,7 @@ template <class DM> struct EksElement {
     static constexpr bool USES_SIGMA = false;
     static constexpr int D = DM::D;
     DM model;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.wide = true; }
     CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT;
         model.propagate(mf, Pf, mp, DT, Pp);
@@ -662,7 +666,7 @@ template <class DM> struct SgpsElement {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D;
     DM model; SigmaSet sg;
-    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = true; }
     CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT;
         sgp_prediction<DM, false, true, true>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
