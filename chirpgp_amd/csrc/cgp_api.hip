@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* _
         case 1: a = fast_log_ge1(v); break;
         case 2: fast_sincos(v, a, b); break;
         case 3: a = rcp_nr(v); break;
+        case 7: softplus_pair_wide(v, a, b); break;
+        case 9: a = rcp_nr1(v); break;
         default: softplus_pair(v, a, b); break;
         }
         o0[i] = a;
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(64) debug_math_uniform_kernel(int op, const do
         const double v = x[i];
         double a, b;
         if (op == 5) softplus_pair_uniform(v, a, b);
+        else if (op == 8) { SpecRegs R; R.init(); softplus_wide(R, v, exp_neg_common(R, v), a, b); }
         else fast_sincos_uniform(v, a, b);
         if (threadIdx.x == 0) { o0[i] = a; if (o1) o1[i] = b; }
     }
@@ -237,12 +240,12 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
 
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream) {
     if (!ctx) return CGP_E_ARG;
-    if (n < 0 || op < 0 || op > 6) return fail(ctx, CGP_E_ARG, "bad op or n");
+    if (n < 0 || op < 0 || op > 9) return fail(ctx, CGP_E_ARG, "bad op or n");
     if (n == 0) return CGP_OK;
     if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
-    if (op >= 5) hipLaunchKernelGGL(debug_math_uniform_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), 0, (hipStream_t)stream, op, x, n, out0, out1);
+    if (op == 5 || op == 6 || op == 8) hipLaunchKernelGGL(debug_math_uniform_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), 0, (hipStream_t)stream, op, x, n, out0, out1);
     else hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, op, x, n, out0, out1);
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
 }

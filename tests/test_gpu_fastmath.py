@@ -88,6 +88,39 @@ def test_uniform_variants():
     assert np.all(np.isnan(sn[~f])) and np.all(np.isnan(cs[~f]))
 
 
+def test_wide_softplus_forms():
+    """The common-regime softplus x + t q(t), t = exp(-x), q = log1p(t) / t as a degree-15 polynomial: per lane with the
+    naive fallback for lanes outside [ln 2, 700) (mixed in the same wavefronts), and the speculative step's form."""
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0.6, 60, 3000), rng.uniform(-30, 0.8, 800), rng.uniform(0.69, 0.70, 200), rng.uniform(690, 712, 100),
+                        [0.6931471805599453, 0.6931476593017578, 0.69314, 699.99, 700., 710., 800., -800., np.inf, -np.inf, np.nan]])
+    rng.shuffle(x)                                  # common and uncommon lanes side by side in every wavefront
+    sp, dsp = E.debug_math(7, x)
+    with np.errstate(over='ignore', invalid='ignore'):
+        e = np.exp(x)
+        ref_sp, ref_d = np.log(e + 1.), e / (e + 1.)
+    assert np.array_equal(np.isnan(dsp), np.isnan(ref_d)) and np.array_equal(np.isnan(sp), np.isnan(ref_sp))
+    assert np.array_equal(np.isinf(sp), np.isinf(ref_sp))
+    fin = np.isfinite(ref_sp) & np.isfinite(x) & (ref_sp > 0)
+    assert np.max(np.abs(sp[fin] - ref_sp[fin]) / ref_sp[fin]) < 1e-13
+    okd = fin & np.isfinite(ref_d)
+    assert np.max(np.abs(dsp[okd] - ref_d[okd]) / ref_d[okd]) < 1e-14
+    pos = fin & (x >= 0)
+    assert _ulp_err(sp[pos], [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in x[pos]]) < 1e-15
+    assert _ulp_err(dsp[pos & okd], [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x[pos & okd]]) < 1e-15
+    # the speculative step's pair inside its regime; its derivative carries one Newton step (2.2e-15)
+    xr = np.concatenate([rng.uniform(0.6932, 60, 2000), rng.uniform(60, 699, 200), [0.6931476593017578, 699.999]])
+    sp, dsp = E.debug_math(8, xr)
+    assert _ulp_err(sp, [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in xr]) < 1e-15
+    assert _ulp_err(dsp, [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in xr]) < 5e-15
+    d = np.concatenate([10 ** rng.uniform(-8, 8, 2000) * rng.choice([-1, 1], 2000)])
+    r1, _ = E.debug_math(9, d)
+    assert np.max(np.abs(r1 * d - 1)) < 5e-15
+
+
 def test_sincos():
     import mpmath as mp
     from chirpgp_amd import _engine as E
