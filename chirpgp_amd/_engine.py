@@ -17,7 +17,7 @@ F_EKF, F_SGP, F_CD_EKF, F_CD_SGP, F_EKF_KPT = range(5)
 S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
 M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
 NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL, SIM_FIXED_X0 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
-LITERAL_SIGMA_SUM = 0x40
+LITERAL_SIGMA_SUM, DPP_KERNEL, FOUR_TRIALS_PER_WAVE, ONE_TRIAL_PER_WAVE = 0x40, 0x80, 0x200, 0x400
 SIGMA_STANDARD = 0x1
 MAX_D = 8
 

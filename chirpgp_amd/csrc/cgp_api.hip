@@ -12,10 +12,12 @@ namespace cgp {
 // carries 64 trials per wave, so it wins as soon as several wavefronts would have to share a SIMD.  Measured crossovers
 // on MI355X (tools/sweep_b.sh, EKF + EKS, d = 4, T = 2000):
 //     EKF-type filters            wave 1.87 ms vs lane 2.52 ms at B = 2048;  3.55 vs 2.53 at B = 4096   -> 2.5 waves / SIMD
+//     d = 4 chirp EKF (MFMA)      four trials per wave above B = 1024: 0.95 ms vs lane 2.64 ms at B = 4096, 1.89 vs 2.67
+//                                 at 8192, 3.53 vs 2.75 at 16384                                         -> 10 trials / SIMD
 //     sigma-point filters         the fan is spread over the lanes of the wave, which one lane per trial cannot do -> 8 / SIMD
 //     time-parallel smoothers     throughput-bound at ~2.9 TB/s for every B; the step-by-step lane-per-trial scan is
 //                                 latency-bound (T x 1.9 us) until B ~ 16K                              -> 16 / SIMD
-enum class Shape { EkfFilter, SigmaFilter, AffineSmoother, SerialSmoother };
+enum class Shape { EkfFilter, MfmaEkfFilter, SigmaFilter, AffineSmoother, SerialSmoother };
 static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, Shape shape, const cgp_sigma* sg = nullptr) {
     // the wave-per-trial shapes stage the sigma-point set in LDS; a set that does not fit runs one lane per trial
     if (sg && SigmaSet::stage_bytes(sg->s, sg->d, sg->n_groups, sg->group_start != nullptr) > (size_t)kSigLdsMaxBytes) return false;
@@ -24,6 +26,7 @@ static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, Shape sha
     const int64_t simds = (int64_t)(ctx ? ctx->num_cus : 256) * 4;
     switch (shape) {
     case Shape::EkfFilter:      return 2 * B < 5 * simds;
+    case Shape::MfmaEkfFilter:  return B < 10 * simds;
     case Shape::SigmaFilter:    return B < 8 * simds;
     case Shape::AffineSmoother: return B < 16 * simds;
     default:                    return 2 * B < 5 * simds;
@@ -162,7 +165,9 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt, flags);
-    const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : Shape::EkfFilter, sig ? sigma : nullptr);
+    const bool mfma_ekf = method == CGP_F_EKF && model->n_harm == 1 && !(flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_ONE_TRIAL_PER_WAVE)) &&
+                          (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
+    const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : (mfma_ekf ? Shape::MfmaEkfFilter : Shape::EkfFilter), sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;

@@ -237,9 +237,138 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 }
 
 
+// ---------------------------------------------------------------------------------------------- four trials per wave
+// The four blocks of the MFMA are independent, so for batches beyond one wave per SIMD each block carries its own
+// trial: lane 16 r + 4 b + q works on trial 4 * blockIdx.x + b.  The step functions above are used as they are -- they
+// are plain per-lane arithmetic, the quad broadcasts stay inside a block -- with per-lane constants; what changes is
+// the plumbing: measurements are staged in LDS (one 512-B load per trial and chunk, a broadcast ds_read per step), the
+// verdicts of the four trials are pooled with a ballot (a chunk is repeated for the whole wave), the checked step and
+// the anchor use the per-lane softplus / sincos, and the output windows span the wave's four consecutive trials.
+// One lane per trial needs T x 1.3 us whatever the batch (its step is a 500-instruction dependent chain); this
+// kernel needs T x 0.4 us per 4096 trials.
+CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
+    double sp, dsp, s1, c1;
+    softplus_pair_wide(x.u2, sp, dsp);
+    fast_sincos(K.ang * sp, s1, c1);
+    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+}
+CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
+    double sp, dsp;
+    softplus_pair_wide(u2, sp, dsp);
+    a.th = K.ang * sp;
+    fast_sincos(a.th, a.s1, a.c1);
+}
+
+__global__ void __launch_bounds__(64) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs ma) {
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, q = lane & 3, b = (lane >> 2) & 3;
+    const int64_t first = (int64_t)blockIdx.x * 4;
+    if (first >= io.B) return;
+    const int ntr = (io.B - first < 4) ? (int)(io.B - first) : 4;          // trials of this wave
+    const int64_t trial = first + (b < ntr ? b : ntr - 1);                 // blocks past the batch redo the last trial
+
+    HarmonicLCD<1> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    Ekf4MfmaConst K;
+    K.M0 = model.M[0]; K.M1 = model.M[1]; K.M2 = model.M[2]; K.M3 = model.M[3];
+    K.rho = model.rho;
+    K.ang = (model.dt * kTwoPi) * model.fs;
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    K.H0 = Hp[0]; K.H1 = Hp[1]; K.H2 = Hp[2]; K.H3 = Hp[3];
+    K.Hr = Hp[r];
+    K.Xi = io.Xi[trial * io.Xi_stride];
+    K.Sig = 0.0;
+    if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
+    else if (r + q == 5) K.Sig = model.MS[1];
+    K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
+    K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
+    K.k0 = (q == 0 && r == 2) ? 1.0 : 0.0; K.k1 = (q == 1 && r == 2) ? 1.0 : 0.0;
+    K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    Ekf4State x;
+    x.u0 = m0p[0]; x.u1 = m0p[1]; x.u2 = m0p[2]; x.u3 = m0p[3];
+    x.P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
+
+    const int64_t T = io.T;
+    // output windows over the wave's consecutive trials: a block past the batch lies beyond the window and is dropped
+    OobWindow mfs, Pfs;
+    mfs.init(io.mfs ? io.mfs + first * T * 4 : nullptr, (int64_t)ntr * T * 32);
+    Pfs.init(io.Pfs ? io.Pfs + first * T * 16 : nullptr, (int64_t)ntr * T * 128);
+    const unsigned p_base = (unsigned)b * (unsigned)T * 128u + 8u * (4 * r + q);
+    const unsigned m_base = (r == 0 && q == 0) ? (unsigned)b * (unsigned)T * 32u : kOobOffset;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    const bool want_nll = io.nll != nullptr;
+
+    SpecRegs R;
+    R.init();
+    __shared__ double ych[4][64];
+    __shared__ double2 park[4][64];
+    double cum[4] = {0.0, 0.0, 0.0, 0.0};
+    int checked_left = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        wave_lds_fence();
+        CGP_UNROLL for (int bb = 0; bb < 4; bb++) {
+            const int64_t tr = first + (bb < ntr ? bb : ntr - 1);
+            ych[bb][lane] = (t0 + lane < T) ? io.ys[tr * T + t0 + lane] : 0.0;
+        }
+        wave_lds_fence();
+        const Ekf4State x0 = x;
+        unsigned uncommon = 0;
+        if (checked_left == 0) {
+            Ekf4Anchor anchor;
+            ekf4_anchor_lane(K, x.u2, anchor);
+            for (int slot = 0; slot < nsteps; slot++) {
+                double S, innov;
+                ekf4_mfma_step_spec(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
+                park[b][slot] = make_double2(S, innov);
+                const unsigned t = (unsigned)(t0 + slot);
+                Pfs.store(x.P, p_base + t * 128u);
+                const unsigned m_off = m_base + t * 32u;      // kOobOffset + t * 32 stays out of range (windows < 2 GiB)
+                mfs.store2(x.u0, x.u1, m_off);
+                mfs.store2(x.u2, x.u3, m_off + 16u);
+            }
+        }
+        const bool redo = __builtin_amdgcn_ballot_w64(uncommon != 0) != 0;
+        if (checked_left > 0 || redo) {
+            if (redo) { x = x0; checked_left = kCheckedChunks; }
+            for (int slot = 0; slot < nsteps; slot++) {
+                double S, innov;
+                ekf4_mfma_step_checked_lane(K, ych[b][slot], x, S, innov);
+                park[b][slot] = make_double2(S, innov);
+                const unsigned t = (unsigned)(t0 + slot);
+                Pfs.store(x.P, p_base + t * 128u);
+                const unsigned m_off = m_base + t * 32u;
+                mfs.store2(x.u0, x.u1, m_off);
+                mfs.store2(x.u2, x.u3, m_off + 16u);
+            }
+            checked_left--;
+        }
+        if (want_nll) {
+            wave_lds_fence();
+            CGP_UNROLL for (int bb = 0; bb < 4; bb++) {
+                const double2 si = park[bb][lane < nsteps ? lane : 0];
+                double* out = (!nll_final && bb < ntr) ? io.nll + (first + bb) * T + t0 : nullptr;
+                cum[bb] = nll_flush_wave(si.x, si.y, lane, nsteps, cum[bb], out);
+            }
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) {
+        CGP_UNROLL for (int bb = 0; bb < 4; bb++) if (bb < ntr) io.nll[first + bb] = cum[bb];
+    }
+}
+
+// 4 T x 128 bytes of covariance rows must fit the 2 GiB window of a wave
+inline bool ekf4_mfma_x4_fits(const FilterIO& io) { return io.T * 512 <= kOobMaxBytes; }
+
 inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
-    hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    // beyond one wave per SIMD the four MFMA blocks carry four trials (CGP_ONE_TRIAL_PER_WAVE keeps one, for tests)
+    if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
+        hipLaunchKernelGGL(ekf4_mfma_x4_kernel, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+    else
+        hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

@@ -20,7 +20,8 @@ THREAD = dict(flags=0x4)
 WAVE_SEQ = dict(flags=0x2 | 0x8 | 0x10)     # wave per trial, step-by-step smoother scan, generic (non-cooperative) filter kernels
 WAVE_LITERAL = dict(flags=0x2 | 0x40)       # cooperative kernels summing over every sigma point (no collapsed quadrature)
 WAVE_DPP = dict(flags=0x2 | 0x80)           # d = 4 EKF on the DPP cooperative kernel instead of the MFMA one
-SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_DPP, id='wave_dpp_ekf'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
+WAVE_X4 = dict(flags=0x2 | 0x200)          # d = 4 matrix-core EKF with four trials per wavefront (default only above B = 1024)
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_X4, id='wave_four_trials'), pytest.param(WAVE_DPP, id='wave_dpp_ekf'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
           pytest.param(THREAD, id='lane_per_trial'), pytest.param(WAVE_LITERAL, id='wave_literal_sigma_sum')]
 
 
@@ -130,7 +131,8 @@ def test_harmonics_long_batched(kw):
     bk.compare(bk.run_pairs('hip', c, cd_T=200, hip_kw=kw), bk.run_pairs('port', c, cd_T=200), RTOL, 'harmonic2')
 
 
-@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='mfma_speculative'), pytest.param(WAVE_DPP, id='dpp'), pytest.param(THREAD, id='lane_per_trial')])
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='mfma_speculative'), pytest.param(WAVE_X4, id='mfma_four_trials'),
+                                pytest.param(WAVE_DPP, id='dpp'), pytest.param(THREAD, id='lane_per_trial')])
 def test_frequency_state_crossing_the_softplus_regimes(kw):
     """The wave-per-trial EKF runs 64-step chunks speculatively in the common regime (frequency state >= 6) and repeats a
     chunk with the reference's naive softplus when a step left it: records that start below, cross and re-cross the

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/sweep_b.jsonl
 : > $OUT
-for B in 1000 2048 4096 8192 16384; do
+for B in 1000 2048 3072 4096 6144 8192 16384; do
   for F in 2 4; do
     echo "# B=$B flags=$F" >> $OUT
     python bench.py --no-cpu-baseline --steps 3 --warmup 1 --workload ekf --batch $B --T 2000 --flags $F >> $OUT 2>/dev/null || echo '{"error": true}' >> $OUT
