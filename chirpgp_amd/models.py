@@ -23,8 +23,9 @@ M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = r
 
 
 def g(x):
-    """Positive bijection log(exp(x) + 1) (models.py:50)."""
-    return np.log(np.exp(x) + 1.)
+    """Positive bijection log(exp(x) + 1) (models.py:50), in the reference's naive form: +inf above 709.78 as there."""
+    with np.errstate(over='ignore'):
+        return np.log(np.exp(x) + 1.)
 
 
 def g_inv(x):

@@ -467,3 +467,17 @@ def test_disc_m32_matches_kf():
     for x, y in zip(a, b):
         npt.assert_allclose(x, y, rtol=1e-12, atol=1e-14)
     npt.assert_allclose(fs.eks(spec, a[0], a[1], 1e-2)[0], fs.rts(F, Sigma, b[0], b[1])[0], rtol=1e-12, atol=1e-14)
+
+
+def test_lockstep_mle_matches_per_record_fits():
+    """fit_many (R records, one launch per probe) reaches the optimum SciPy's L-BFGS-B finds record by record."""
+    from chirpgp_amd import mle, models as pm
+    T, R = 1200, 5
+    recs = np.stack([cs.chirp_case(T=T, seed=40 + i).ys for i in range(R)])
+    init = [0.1, 0.1, 0.1, 1., 1., 7.]
+    many, info = mle.fit_many('ekf', pm.build_chirp_model, init, recs, 0.1, 1e-3, maxiter=120)
+    assert many.shape == (R, 6) and info['launches'] < 400
+    for r in range(R):
+        single, res = mle.fit('ekf', pm.build_chirp_model, init, recs[r], 0.1, 1e-3, maxiter=120)
+        assert info['fun'][r] <= res.fun + 1e-3 * abs(res.fun), (r, info['fun'][r], res.fun)
+        assert abs(info['fun'][r] - res.fun) <= 2e-2 * abs(res.fun)
