@@ -325,14 +325,17 @@ struct SpecRegs {
     double ex[14], lq[16];
     double log2e, ln2hi, ln2lo;
     double s3, s5, c4, c6;       // -1/6, 1/120, 1/24, -1/720
-    CGP_DEV void init() {
+    // PIN = false leaves the values as ordinary constants the compiler may rematerialise: fewer live registers, a few
+    // more moves -- the trade for a kernel that wants two waves per SIMD rather than the shortest chain
+    template <bool PIN = true> CGP_DEV void init() {
         const double ex_[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
                                 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
-        CGP_UNROLL for (int i = 0; i < 14; i++) ex[i] = FastMathRegs::pin(ex_[i]);
-        CGP_UNROLL for (int i = 0; i < 16; i++) lq[i] = FastMathRegs::pin(kLog1pOverT[i]);
-        log2e = FastMathRegs::pin(kLog2e); ln2hi = FastMathRegs::pin(kLn2Hi); ln2lo = FastMathRegs::pin(kLn2Lo);
-        s3 = FastMathRegs::pin(-1.0 / 6.0); s5 = FastMathRegs::pin(1.0 / 120.0);
-        c4 = FastMathRegs::pin(1.0 / 24.0); c6 = FastMathRegs::pin(-1.0 / 720.0);
+        auto keep = [](double v) { return PIN ? FastMathRegs::pin(v) : v; };
+        CGP_UNROLL for (int i = 0; i < 14; i++) ex[i] = keep(ex_[i]);
+        CGP_UNROLL for (int i = 0; i < 16; i++) lq[i] = keep(kLog1pOverT[i]);
+        log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo);
+        s3 = keep(-1.0 / 6.0); s5 = keep(1.0 / 120.0);
+        c4 = keep(1.0 / 24.0); c6 = keep(-1.0 / 720.0);
     }
 };
 // ln 2 <= x < 700 (t = exp(-x) <= 1/2) as one unsigned compare on the high word of a wave-uniform x.

@@ -259,7 +259,11 @@ CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) 
     fast_sincos(a.th, a.s1, a.c1);
 }
 
-__global__ void __launch_bounds__(64) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs ma) {
+// DENSE = false: constants pinned, 297 registers, one wave per SIMD (the dispatcher then has to spread the waves over all
+// SIMDs: best up to 4096 trials).  DENSE = true: constants left to the compiler, 234 registers, two waves per SIMD
+// (beyond 4096 trials, where waves have to share SIMDs anyway: 8 - 14 % faster there, 50 % slower below).
+template <bool DENSE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENSE ? 2 : 1))) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3, b = (lane >> 2) & 3;
     const int64_t first = (int64_t)blockIdx.x * 4;
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs
     const bool want_nll = io.nll != nullptr;
 
     SpecRegs R;
-    R.init();
+    R.init<!DENSE>();
     __shared__ double ych[4][64];
     __shared__ double2 park[4][64];
     double cum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -366,7 +370,10 @@ inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     // beyond one wave per SIMD the four MFMA blocks carry four trials (CGP_ONE_TRIAL_PER_WAVE keeps one, for tests)
     if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
-        hipLaunchKernelGGL(ekf4_mfma_x4_kernel, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+    {
+        if (io.B > 4096) hipLaunchKernelGGL(ekf4_mfma_x4_kernel<true>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+        else hipLaunchKernelGGL(ekf4_mfma_x4_kernel<false>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+    }
     else
         hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());

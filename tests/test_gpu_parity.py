@@ -481,3 +481,17 @@ def test_lockstep_mle_matches_per_record_fits():
         single, res = mle.fit('ekf', pm.build_chirp_model, init, recs[r], 0.1, 1e-3, maxiter=120)
         assert info['fun'][r] <= res.fun + 1e-3 * abs(res.fun), (r, info['fun'][r], res.fun)
         assert abs(info['fun'][r] - res.fun) <= 2e-2 * abs(res.fun)
+
+
+def test_four_trials_per_wave_dense_variant_at_large_batch():
+    """Above 4096 trials the four-trials-per-wave EKF runs its two-waves-per-SIMD build: same results as one lane per
+    trial (itself checked against the oracle above), ragged last wave included."""
+    fs = _fs()
+    c = cs.chirp_case(T=8)
+    B, T = 4102, 130
+    rng = np.random.default_rng(3)
+    ys = np.sin(0.05 * np.arange(T))[None, :] * rng.uniform(0.5, 1.5, (B, 1)) + 0.3 * rng.standard_normal((B, T))
+    a = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, ys, flags=0x2)
+    b = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, ys, flags=0x4)
+    for x, y in zip(a, b):
+        npt.assert_allclose(x, y, rtol=1e-9, atol=1e-12)
