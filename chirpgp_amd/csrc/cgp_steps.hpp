@@ -78,7 +78,35 @@ CGP_DEV void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 template <int R>
-CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int /*nl*/) {
+CGP_DEV void wave_allreduce(double (&acc)[R], double* lds, int lane, int nl) {
+    if (nl <= 16) {
+        // At most 16 lanes carry partials (e.g. the 15 groups of the cubature rule in d = 8): one lane sums a whole
+        // row, so up to 64 values go through in ONE pass -- 45 for the d = 8 prediction instead of three passes of 16.
+        // Rows of 16 entries at a pitch of 18 doubles, totals behind them (64 * 18 + 64 doubles < the buffer).
+        constexpr int kLd = 18;
+        double* tot = lds + 64 * kLd;
+        CGP_UNROLL for (int base = 0; base < R; base += 64) {
+            if (lane < 16) {
+                CGP_UNROLL for (int k = 0; k < 64; k++)
+                    if (base + k < R) lds[k * kLd + lane] = acc[base + k];
+            }
+            wave_lds_fence();
+            if (base + lane < R) {
+                const double2* row = reinterpret_cast<const double2*>(lds + lane * kLd);
+                double2 a = row[0], b = row[1], c = row[2], d = row[3];
+                const double2 e = row[4], f = row[5], g = row[6], h = row[7];
+                a.x += e.x; a.y += e.y; b.x += f.x; b.y += f.y; c.x += g.x; c.y += g.y; d.x += h.x; d.y += h.y;
+                a.x += c.x; a.y += c.y; b.x += d.x; b.y += d.y;
+                a.x += b.x; a.y += b.y;
+                tot[lane] = a.x + a.y;
+            }
+            wave_lds_fence();
+            CGP_UNROLL for (int k = 0; k < 64; k++)
+                if (base + k < R) acc[base + k] = tot[k];
+            wave_lds_fence();
+        }
+        return;
+    }
     double* tot = lds + kRedChunk * kRedLd;
     const int r = lane >> 2, q = lane & 3;
     CGP_UNROLL for (int base = 0; base < R; base += kRedPass) {
