@@ -2,14 +2,36 @@
 
 The point sets are tiny host constants (81 x 4 doubles for Gauss-Hermite order 3 in d = 4) built once in NumPy
 and uploaded; everything that uses them per step -- chi = m + chol(P) xi, the model evaluations, the weighted
-sums, the RK4 stages -- runs inside the HIP kernels (csrc/cgp_sigma.hpp).  ``gaussian_expectation`` is the
+sums, the RK4 stages -- runs inside the HIP kernels (csrc/cgp_steps.hpp).  ``gaussian_expectation`` is the
 post-smoother step of every driver (demos/ekfs_mle.py:73-75) and runs on the device as well.
 """
 import math
 from typing import NamedTuple, Optional
 import numpy as np
 
-__all__ = ['SigmaPoints', 'gaussian_expectation']
+__all__ = ['rk4_m_cov', 'rk4_m_cov_backward', 'SigmaPoints', 'gaussian_expectation']
+
+
+def _rk4_pair(rhs, m, P, dt):
+    """Classic fourth-order Runge-Kutta step of size dt for the coupled pair (m, P); rhs(m, P) -> (dm, dP)."""
+    am, aP = rhs(m, P)
+    bm, bP = rhs(m + 0.5 * dt * am, P + 0.5 * dt * aP)
+    cm, cP = rhs(m + 0.5 * dt * bm, P + 0.5 * dt * bP)
+    em, eP = rhs(m + dt * cm, P + dt * cP)
+    return m + dt * (am + 2 * bm + 2 * cm + em) / 6, P + dt * (aP + 2 * bP + 2 * cP + eP) / 6
+
+
+def rk4_m_cov(m_cov_ode, m, P, dt):
+    """One RK4 step of the moment ODEs (quadratures.py:34-54), host side, for user code that integrates its own
+    ``m_cov_ode(m, P) -> (dm, dP)``.  The continuous-discrete filters run their RK4 inside the HIP kernels
+    (csrc/cgp_steps.hpp) and do not call this."""
+    return _rk4_pair(m_cov_ode, np.asarray(m, dtype=np.float64), np.asarray(P, dtype=np.float64), dt)
+
+
+def rk4_m_cov_backward(m_cov_ode, m, P, mf, Pf, dt):
+    """The smoother's variant (quadratures.py:57-81): the ODE also sees the filtering result (mf, Pf), held fixed over
+    the four stages."""
+    return _rk4_pair(lambda a, b: m_cov_ode(a, b, mf, Pf), np.asarray(m, dtype=np.float64), np.asarray(P, dtype=np.float64), dt)
 
 
 def _hermite_physicists(order):

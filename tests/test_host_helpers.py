@@ -64,3 +64,24 @@ def test_toymodels_and_tools_match_the_oracle():
     for x, y in zip(tools.lti_sde_to_disc(A, np.array([0., 2.]), 0.1), ot.lti_sde_to_disc(A, np.array([0., 2.]), 0.1)):
         npt.assert_allclose(x, y, rtol=1e-13)
     npt.assert_allclose(tools.rmse(np.ones((4, 2)), np.zeros((4, 2))), 2.0)
+
+
+def test_rk4_pair_helpers_match_the_oracle():
+    """quadratures.rk4_m_cov / rk4_m_cov_backward (reference names) against the oracle's restatement on a linear ODE, and
+    against the exact solution of dm = A m, dP = A P + P A^T + Q to fourth order."""
+    from chirpgp_amd.quadratures import rk4_m_cov, rk4_m_cov_backward
+    A = np.array([[0., 1.], [-2., -0.3]])
+    Q = np.array([[0., 0.], [0., 0.5]])
+    ode = lambda m, P: (A @ m, A @ P + P @ A.T + Q)
+    m, P = np.array([1., -1.]), np.array([[0.3, 0.1], [0.1, 0.2]])
+    a = rk4_m_cov(ode, m, P, 0.01)
+    b = oq.rk4_m_cov(ode, m, P, 0.01)
+    npt.assert_allclose(a[0], b[0], rtol=1e-15)
+    npt.assert_allclose(a[1], b[1], rtol=1e-15)
+    import scipy.linalg
+    npt.assert_allclose(a[0], scipy.linalg.expm(A * 0.01) @ m, rtol=1e-9)
+    back = lambda m_, P_, mf, Pf: (A @ m_ + 0.1 * (m_ - mf), A @ P_ + P_ @ A.T - 0.2 * Pf)
+    a = rk4_m_cov_backward(back, m, P, m * 0.9, P * 1.1, -0.01)
+    b = oq.rk4_m_cov_backward(back, m, P, m * 0.9, P * 1.1, -0.01)
+    npt.assert_allclose(a[0], b[0], rtol=1e-15)
+    npt.assert_allclose(a[1], b[1], rtol=1e-15)
