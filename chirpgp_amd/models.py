@@ -220,6 +220,31 @@ def disc_chirp_lcd(lam, b, ell, sigma):
     return disc_harmonic_chirp_lcd(lam, b, ell, sigma, 1, 1.)
 
 
+def disc_chirp_lcd_cond_v(lam, b):
+    """Chirp block conditioned on a given frequency-state value v (models.py:313-330): host-side NumPy closure
+    ``m_and_cov(u (2,), v, dt) -> (rho Rot(dt 2 pi g(v)) u, q I)``.  Only the covariance-function utilities of the
+    reference use it (cov_funcs.py:202); it is not a filter model and never reaches the kernels."""
+    def m_and_cov(u, v, dt):
+        th = dt * 2 * math.pi * g(v)
+        rho = math.exp(-lam * dt)
+        c, s_ = math.cos(th) * rho, math.sin(th) * rho
+        q = b ** 2 * dt if lam == 0 else b ** 2 / (2 * lam) * (1 - math.exp(-2 * lam * dt))
+        u = np.asarray(u, dtype=np.float64)
+        return np.array([c * u[0] - s_ * u[1], s_ * u[0] + c * u[1]]), np.eye(2) * q
+    return m_and_cov
+
+
+def disc_chirp_euler_maruyama():
+    """As in the reference (models.py:389-392): not provided, the chirp SDE is too stiff for Euler-Maruyama."""
+    return NotImplemented
+
+
+def disc_chirp_tme(*args, **kwargs):
+    """The reference's Taylor-moment-expansion discretisation (models.py:395-416) needs the third-party ``tme`` package,
+    which is neither vendored in the reference nor available here: out of scope."""
+    raise NotImplementedError('disc_chirp_tme needs the un-vendored `tme` package of the reference; use disc_chirp_lcd')
+
+
 def disc_model_lascala_lcd(ell, sigma):
     """models.py:419-434."""
     return DiscreteModel(M_LASCALA_LCD, 4, 1, _stack(ell, sigma))

@@ -85,3 +85,17 @@ def test_rk4_pair_helpers_match_the_oracle():
     b = oq.rk4_m_cov_backward(back, m, P, m * 0.9, P * 1.1, -0.01)
     npt.assert_allclose(a[0], b[0], rtol=1e-15)
     npt.assert_allclose(a[1], b[1], rtol=1e-15)
+
+
+def test_remaining_reference_model_names():
+    """models.disc_chirp_lcd_cond_v (host utility, models.py:313-330), disc_chirp_euler_maruyama, disc_chirp_tme."""
+    import pytest
+    u = np.array([0.3, -0.2])
+    for lam in (0.2, 0.0):
+        a = pm.disc_chirp_lcd_cond_v(lam, 0.4)(u, 1.7, 1e-2)
+        b = om.disc_chirp_lcd_cond_v(lam, 0.4)(u, 1.7, 1e-2)
+        npt.assert_allclose(a[0], b[0], rtol=1e-14)
+        npt.assert_allclose(a[1], b[1], rtol=1e-14)
+    assert pm.disc_chirp_euler_maruyama() is NotImplemented
+    with pytest.raises(NotImplementedError):
+        pm.disc_chirp_tme(0.1, 0.1, 1., 1.)
