@@ -6,7 +6,7 @@ frequency law past its (0, pi) domain for the long records of BASELINE.json (SUR
 import math
 import numpy as np
 
-__all__ = ['gen_chirp', 'gen_harmonic_chirp', 'constant_mag', 'damped_exp_mag', 'random_ou_mag', 'affine_freq',
+__all__ = ['gen_chirp', 'gen_harmonic_chirp', 'gen_chirp_envelope', 'constant_mag', 'damped_exp_mag', 'random_ou_mag', 'affine_freq',
            'polynomial_freq', 'meow_freq', 'tiled_meow', 'noisy_copies']
 
 
@@ -19,6 +19,11 @@ def gen_harmonic_chirp(ts, magnitude_funcs, fundamental_phase_func, base_phase=0
     """sum_i alpha_i(t) sin(phi_0 + i 2 pi phi(t))  (toymodels.py:73-104)."""
     ph = fundamental_phase_func(ts)
     return sum(mag(ts) * np.sin(base_phase + (i + 1) * 2 * math.pi * ph) for i, mag in enumerate(magnitude_funcs))
+
+
+def gen_chirp_envelope(ts, magnitude_func, phase_func, base_phase=0.):
+    """Complex chirp alpha(t) exp(i (phi_0 + 2 pi phi(t)))  (toymodels.py:107-120)."""
+    return magnitude_func(ts) * np.exp(1j * (base_phase + 2 * math.pi * phase_func(ts)))
 
 
 def constant_mag(b):
