@@ -118,12 +118,13 @@ CGP_DEV double fast_log_ge1(double z) {
 }
 
 // sin(x), cos(x): 3-term Cody-Waite reduction by pi/2 for |x| < 1e5 (n < 2^16: n * kPio2_1, n * kPio2_2 exact),
-// Taylor to r^17 / r^16 on |r| <= pi/4 (truncation 5e-17).  Larger |x|, inf and NaN take the library path.
+// Taylor to r^17 / r^16 on |r| <= pi/4 (truncation 5e-17).  Larger |x|, inf and NaN take the library's values.
+// The reduced-range evaluation runs unconditionally; only if some active lane is outside the range does the wavefront
+// also call the library and those lanes take its result -- one wave-uniform branch at the END (a branch in front would
+// cut the caller's dependent chain into basic blocks that cannot be interleaved; see cgp_mfma4.hpp).  Signs are flipped
+// on the high word instead of negate-and-select.
 CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
-    if (!(fabs(x) < 1.0e5)) {
-        sincos(x, &sn, &cs);
-        return;
-    }
+    const bool common = fabs(x) < 1.0e5;               // false for inf and NaN
     const double n = __builtin_rint(x * kTwoOverPi);
     double r = fma(-n, kPio2_1, x);
     r = fma(-n, kPio2_2, r);
@@ -148,10 +149,15 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0)); // 1 - r^2/2 + r^4 (1/4! - ...)
     const int q = (int)n;
     const bool swap = (q & 1) != 0;
-    double a = swap ? c0 : s0;
-    double b = swap ? s0 : c0;
-    sn = (q & 2) ? -a : a;
-    cs = ((q + 1) & 2) ? -b : b;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    sn = __hiloint2double(__double2hiint(a) ^ ((q & 2) << 30), __double2loint(a));
+    cs = __hiloint2double(__double2hiint(b) ^ (((q + 1) & 2) << 30), __double2loint(b));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!common) != 0, 0)) {
+        double sl, cl;
+        sincos(x, &sl, &cl);
+        sn = common ? sn : sl;
+        cs = common ? cs : cl;
+    }
 }
 
 // exp(x) without the overflow / underflow / NaN handling, for arguments known to lie in (-700, 700).
