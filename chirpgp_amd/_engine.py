@@ -140,6 +140,11 @@ def dev(x, device=None):
 
 _const_cache = {}
 
+
+def torch_index(idx, like):
+    """NumPy integer index -> int64 tensor on `like`'s device."""
+    return _torch().as_tensor(np.asarray(idx, dtype=np.int64), device=like.device)
+
 # Optional timing hook used by bench.py: when set to a list, every kernel launch appends
 # (name, start_event, end_event), the events recorded on the launch stream immediately around the C-ABI call.
 kernel_events = None

@@ -25,8 +25,11 @@ def batched_nll(method, build, thetas, ys, Xi, dt, sgps=None, **build_kw):
     thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
     G = thetas.shape[0]
     drift, disp, disc, m0, P0, H = build(M.g(thetas), **build_kw)
-    ys = np.asarray(ys, dtype=np.float64)
-    ysb = np.broadcast_to(ys, (G, ys.shape[-1])) if ys.ndim == 1 else ys      # one record for all rows, or one per row
+    if type(ys).__module__.startswith('torch'):                               # records already in HBM (fit_many)
+        ysb = ys if ys.ndim == 2 else ys[None, :].expand(G, -1)
+    else:
+        ys = np.asarray(ys, dtype=np.float64)
+        ysb = np.broadcast_to(ys, (G, ys.shape[-1])) if ys.ndim == 1 else ys  # one record for all rows, or one per row
     if ysb.shape[0] != G:
         raise ValueError(f'ys has {ysb.shape[0]} records for {G} parameter vectors')
     kw = dict(nll_final_only=True, want=(False, False, True))
@@ -40,7 +43,8 @@ def batched_nll(method, build, thetas, ys, Xi, dt, sgps=None, **build_kw):
         out = fs.cd_sgp_filter(drift, disp, sgps, H, Xi, m0, P0, dt, ysb, **kw)
     else:
         raise ValueError(method)
-    return np.asarray(out[2])
+    nll = out[2]
+    return nll.cpu().numpy() if type(nll).__module__.startswith('torch') else np.asarray(nll)
 
 
 def make_objective(method, build, ys, Xi, dt, sgps=None, rel_step=1e-6, **build_kw):
@@ -80,7 +84,8 @@ def _value_and_grad_many(method, build, thetas, yss, Xi, dt, sgps, rel_step, bui
     idx = np.arange(P)
     batch[:, 1 + 2 * idx, idx] += h
     batch[:, 2 + 2 * idx, idx] -= h
-    ys_rep = np.repeat(yss, 2 * P + 1, axis=0)                              # record r serves its 2P+1 rows
+    # record r serves its 2P+1 rows; the records live in HBM, so the replication is a device-side copy
+    ys_rep = yss.repeat_interleave(2 * P + 1, dim=0) if type(yss).__module__.startswith('torch') else np.repeat(yss, 2 * P + 1, axis=0)
     nll = batched_nll(method, build, batch.reshape(-1, P), ys_rep, Xi, dt, sgps, **build_kw).reshape(R, 2 * P + 1)
     f = nll[:, 0].copy()
     grad = (nll[:, 1::2] - nll[:, 2::2]) / (2 * h)
@@ -97,7 +102,10 @@ def fit_many(method, build, init_params, yss, Xi, dt, sgps=None, maxiter=200, hi
     run one L-BFGS-B per record.  Same objective, same unconstrained parametrisation g() as :func:`fit`.
 
     yss (R, T);  init_params (P,) or (R, P) positive model parameters  ->  (opt_params (R, P), info dict)."""
-    yss = np.atleast_2d(np.asarray(yss, dtype=np.float64))
+    from chirpgp_amd import _engine as E
+    yss = E.dev(yss)                                  # uploaded once; every probe replicates rows on the device
+    if yss.ndim == 1:
+        yss = yss[None, :]
     R = yss.shape[0]
     x = np.array(np.broadcast_to(M.g_inv(np.asarray(init_params, dtype=np.float64)), (R, np.shape(init_params)[-1])))
     P = x.shape[1]
@@ -136,7 +144,7 @@ def fit_many(method, build, init_params, yss, Xi, dt, sgps=None, maxiter=200, hi
                 break
             idx = np.flatnonzero(searching)
             xt = x[idx] + step[idx, None] * d[idx]
-            ft, gt = _value_and_grad_many(method, build, xt, yss[idx], Xi, dt, sgps, rel_step, build_kw)
+            ft, gt = _value_and_grad_many(method, build, xt, yss[E.torch_index(idx, yss)], Xi, dt, sgps, rel_step, build_kw)
             launches += 1
             ok = ft <= f[idx] + 1e-4 * step[idx] * gd[idx]
             acc = idx[ok]
