@@ -275,11 +275,10 @@ CGP_DEV void fast_sincos_uniform(const FastMathImm&, double x, double& sn, doubl
 //     consumed by a rarely-taken forward branch at the bottom (the fix-up recomputes in the reference's naive form);
 //   * every polynomial is in Estrin form (3-4 dependent levels instead of 6-13);
 //   * the sin / cos quadrant logic stays on the vector ALU, off the critical path, instead of a round trip through
-//     the scalar unit;
-//   * CHECK = false drops the fix-up branches altogether and only ORs the verdict into *uncommon: a branch inside the
-//     step splits it into basic blocks that the instruction scheduler cannot interleave (measured: 167 cycles per step
-//     for the two never-taken branches), so the EKF kernel runs whole 64-step chunks speculatively and repeats a
-//     chunk with CHECK = true if any of its steps left the common regime (cgp_mfma4.hpp).
+//     the scalar unit.
+// Even a never-taken branch splits a step into basic blocks that the instruction scheduler cannot interleave (measured:
+// 167 cycles per step for these two), which is why the matrix-core EKF goes one step further and runs whole 64-step
+// chunks with no checks at all (SpecRegs below, cgp_mfma4.hpp); the versions here serve the DPP cooperative kernels.
 // exp(-x) for |x| < 700 (no overflow / underflow / NaN handling): x = -(k ln2 + r), Estrin on r, v_ldexp_f64.
 template <class Regs>
 CGP_DEV double exp_neg_common(const Regs& R, double x) {
@@ -311,10 +310,6 @@ CGP_DEV void softplus_from_exp_neg(const FastMathRegs& R, double x, double t, do
 CGP_DEV bool softplus_common_regime(double x) {
     const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
     return (hx - 0x40180000u) < (0x4085E000u - 0x40180000u);
-}
-// |x| < bound for a wave-uniform x, bound = 2^n given by the high word of its double (false for NaN).
-CGP_DEV bool magnitude_below(double x, unsigned bound_hi) {
-    return ((unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffffu) < bound_hi;
 }
 
 // log1p(t) / t on [0, 1/2] as a polynomial of degree 15 (Chebyshev-node interpolant, tools/gen_math_constants.py;
@@ -363,20 +358,17 @@ CGP_DEV void softplus_wide(const SpecRegs& R, double x, double t, double& sp, do
     dsp = rcp_nr1(1.0 + t);
 }
 
-template <bool CHECK = true>
-CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp, unsigned* uncommon = nullptr) {
+CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp) {
     const bool common = softplus_common_regime(x);
     softplus_from_exp_neg(R, x, exp_neg_common(R, x), sp, dsp);
-    if (!CHECK) *uncommon |= common ? 0u : 1u;     // speculative callers collect the verdict and redo the work if it is set
-    if (CHECK && __builtin_expect(!common, 0)) {            // elsewhere, and for inf / NaN: the naive form of models.py:50 as is
+    if (__builtin_expect(!common, 0)) {            // elsewhere, and for inf / NaN: the naive form of models.py:50 as is
         const double e = fast_exp(x);
         const double z = e + 1.0;
         sp = fast_log_ge1(z);
         dsp = e * rcp_nr(z);
     }
 }
-template <bool CHECK = true>
-CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, double& cs, unsigned* uncommon = nullptr) {
+CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, double& cs) {
     const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x)) & 0x7fffffffu;
     const bool common = hx < 0x40F86A00u;                                          // |x| < 1e5 (not inf, not NaN)
     const double n = __builtin_rint(x * R.two_over_pi);
@@ -403,8 +395,7 @@ CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, do
     const double a = swap ? c0 : s0, b = swap ? s0 : c0;
     sn = __hiloint2double(__double2hiint(a) ^ sa, __double2loint(a));
     cs = __hiloint2double(__double2hiint(b) ^ sb, __double2loint(b));
-    if (!CHECK) *uncommon |= common ? 0u : 1u;
-    if (CHECK && __builtin_expect(!common, 0)) sincos(x, &sn, &cs);                 // out of line: rare
+    if (__builtin_expect(!common, 0)) sincos(x, &sn, &cs);                          // out of line: rare
 }
 
 // Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of
