@@ -214,7 +214,12 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
                 pred.predict(lane, lds, mf, Pf, mp, Pp);
                 Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
                 if (lane == slot) { S_l = S; innov_l = innov; }
-                if (mfs || Pfs) wave_store_step<D>(rowpark, lane, mf, Pf, mfs ? mfs + t * D : nullptr, Pfs ? Pfs + t * D * D : nullptr);
+                if constexpr (D >= 6) {
+                    if (mfs || Pfs) wave_store_step<D>(rowpark, lane, mf, Pf, mfs ? mfs + t * D : nullptr, Pfs ? Pfs + t * D * D : nullptr);
+                } else if (writer) {      // few enough pieces that the LDS round trip costs more than it saves
+                    if (mfs) store_vec<D>(mfs + t * D, mf);
+                    if (Pfs) store_sym_full<D>(Pfs + t * D * D, Pf);
+                }
             }
             if (want_nll) {
                 double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
@@ -312,8 +317,8 @@ __global__ void __launch_bounds__(64) smoother_kernel(SmootherIO io, ModelArgs m
             load_vec<D>(mfs + t * D, mf);
             load_sym<D>(Pfs + t * D * D, Pf);
             step.step(lane, lds, mf, Pf, ms, Ps);
-            if constexpr (WAVE) wave_store_step<D>(rowpark, lane, ms, Ps, mss + t * D, Pss + t * D * D);
-            else {
+            if constexpr (WAVE && D >= 6) wave_store_step<D>(rowpark, lane, ms, Ps, mss + t * D, Pss + t * D * D);
+            else if (writer) {
                 store_vec<D>(mss + t * D, ms);
                 store_sym_full<D>(Pss + t * D * D, Ps);
             }
