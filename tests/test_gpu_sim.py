@@ -147,3 +147,34 @@ def test_simulate_rejects_bad_arguments():
         E.run_simulate(c.drift, c.H, c.Xi, c.m0, c.P0, c.dt, 10, 0, 4)
     with pytest.raises(ValueError):
         E.run_simulate(c.disc, c.H[:3], c.Xi, c.m0, c.P0, c.dt, 10, 0, 4)
+
+
+def test_reference_crlb_monte_carlo_statement():
+    """test/test_crlb.py:19-73 end to end on the device: 10^6 trajectories of the Matern-3/2 LGSSM (T = 10, dt = 0.1), the
+    batched kf on all of them; Pfs identical across trials, E[(mf - x)(mf - x)^T] ~= Pf (atol 1e-1 as there), and Pf
+    equal to the Riccati recursion.  The draws are the engine's Philox streams instead of jax.random's."""
+    import math
+    import torch
+    from chirpgp_amd import filters_smoothers as fs, tools
+    from chirpgp_amd import models as pm
+    ell, sigma, dt, T, B = 1., 1., 0.1, 10, 1000000
+    A = np.array([[0., 1.], [-3 / ell ** 2, -2 * math.sqrt(3) / ell]])
+    Bv = np.array([0., 2 * sigma * (math.sqrt(3) / ell) ** 1.5])
+    F, Sigma = tools.lti_sde_to_disc(A, Bv, dt)
+    Xi, H, m0 = 1., np.array([1., 0.]), np.zeros(2)
+    P0 = np.diag([sigma ** 2, 3 / ell ** 2 * sigma ** 2])
+    xss, yss = tools.simulate_measurements(pm.linear_cond_m_cov(F, Sigma), H, Xi, m0, P0, dt, T, 666, batch=B)
+    mfs, Pfs, _ = fs.kf(F, Sigma, H, Xi, m0, P0, yss)
+    assert torch.equal(Pfs[123456], Pfs[7]) and torch.equal(Pfs[0], Pfs[B - 1])
+    res = mfs - xss
+    E = torch.einsum('bti,btj->tij', res, res).cpu().numpy() / B
+    Pf = Pfs[0].cpu().numpy()
+    npt.assert_allclose(E, Pf, atol=1e-1)
+    npt.assert_allclose(E, Pf, rtol=1e-2, atol=5e-3)      # what 10^6 draws actually give (sd of an entry ~ 1.4e-3 P)
+    P, want = P0, []
+    for _ in range(T):
+        Pp = F @ P @ F.T + Sigma
+        K = Pp @ H / (H @ Pp @ H + Xi)
+        P = Pp - np.outer(K, K) * (H @ Pp @ H + Xi)
+        want.append(P)
+    npt.assert_allclose(Pf, np.array(want), rtol=1e-12, atol=1e-14)
