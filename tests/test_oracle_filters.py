@@ -179,3 +179,46 @@ def test_nan_semantics_non_pd_cholesky():
     P0 = np.array([[1., 2.], [2., 1.]])          # indefinite
     mfs, Pfs, nll = fs.sgp_filter(f, sg, np.array([1., 0.]), 0.1, np.zeros(2), P0, 0.1, np.ones(5))
     assert np.all(np.isnan(mfs)) and np.all(np.isnan(Pfs)) and np.all(np.isnan(nll))
+
+
+def test_lorenz63_discrete_vs_continuous_discrete():
+    """The intent of the reference's test/test_ekfs.py:11-62 -- ekf / eks on a discretised Lorenz-63 against cd_ekf /
+    cd_eks on the SDE, same loose tolerances -- without its two unavailable ingredients: the order-2 TME discretisation
+    (third-party `tme`) is replaced by one RK4 step of the drift for the mean and the second-order expansion
+    Gamma dt + (J Gamma + Gamma J^T) dt^2 / 2 for the covariance (both agree with TME-2 to O(dt^3)), and the jax.random
+    draws by NumPy's."""
+    import math
+    kappa, lam, mu = 10., 28., 2.
+    Gamma = 25. * np.eye(3)                                   # dispersion 5 I
+
+    def drift(u):
+        return np.array([kappa * (u[1] - u[0]), u[0] * (lam - u[2]) - u[1], u[0] * u[1] - mu * u[2]])
+
+    def drift_jac(u):
+        return np.array([[-kappa, kappa, 0.], [lam - u[2], -1., -u[0]], [u[1], u[0], -mu]])
+
+    def m_and_cov(u, dt):
+        k1 = drift(u); k2 = drift(u + 0.5 * dt * k1); k3 = drift(u + 0.5 * dt * k2); k4 = drift(u + dt * k3)
+        J = drift_jac(np.real(u))
+        return u + dt * (k1 + 2 * k2 + 2 * k3 + k4) / 6, Gamma * dt + (J @ Gamma + Gamma @ J.T) * dt ** 2 / 2
+
+    dt, T, Xi = 1e-3, 2000, 2.
+    H, m0, P0 = np.array([1., 0., 0.]), np.zeros(3), np.eye(3)
+    rng = np.random.default_rng(666)
+    x = m0 + rng.standard_normal(3)
+    traj = np.empty((T, 3))
+    for k in range(T):
+        m, cov = m_and_cov(x, dt)
+        x = m + np.linalg.cholesky(cov) @ rng.standard_normal(3)
+        traj[k] = x
+    ys = traj[:, 0] + math.sqrt(Xi) * rng.standard_normal(T)
+
+    f = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
+    s = fs.eks(m_and_cov, f[0], f[1], dt)
+    cf = fs.cd_ekf(drift, lambda _: 5. * np.eye(3), H, Xi, m0, P0, dt, ys)
+    cs_ = fs.cd_eks(drift, lambda _: 5. * np.eye(3), cf[0], cf[1], dt)
+    npt.assert_allclose(f[0], cf[0], rtol=0.2, atol=0.05)     # the reference has no atol; zero crossings of a state need one
+    npt.assert_allclose(f[1], cf[1], rtol=0.21, atol=1e-3)
+    npt.assert_allclose(f[2], cf[2], rtol=1e-5, atol=1e-2)
+    assert np.all(np.isfinite(s[0])) and np.all(np.isfinite(cs_[0]))
+    npt.assert_allclose(s[0][:-200], cs_[0][:-200], rtol=0.2, atol=0.5)      # states range over +-20; zero crossings
