@@ -64,19 +64,29 @@ constexpr int kCheckedChunks = 16;
 
 struct Ekf4MfmaConst {
     double M0, M1, M2, M3, rho, ang;           // M32 block, exp(-lam dt), dt 2 pi fs
-    double H0, H1, H2, H3, Hr, Xi, Sig;
-    double kc, ks, k0, k1, kk;                 // J[q][r] = kc c + ks s + k0 jv0 + k1 jv1 + kk
+    double Hr, Xi, Sig;
+    double kc, ks, kj, kk;                     // J[q][r] = kc c + ks s + kk + kj dth f[q ^ 1]  (kj = -1 at (0, 2), +1 at (1, 2))
 };
-struct Ekf4State { double P, u0, u1, u2, u3; };
+// The mean is distributed like the covariance: ur = u[r] (row layout) and uq = u[q] (column layout) at lane (r, q); the
+// frequency state u[2] every lane needs is one quad broadcast of uq.
+struct Ekf4State {
+    double P, ur, uq;
+    CGP_DEV double u2() const { return dpp_f64<kQuadBcast2>(uq); }
+};
 
-// Everything of a step after the rotation (c1, s1) = (cos, sin)(theta) and the softplus derivative dsp are known.
+// Everything of a step after the rotation (c1, s1) = (cos, sin)(theta) and the softplus derivative dsp are known -- the
+// mean on the matrix cores as well.  With J0 = blockdiag(rho Rot(theta), M32) held as J0[q][r] (one register, like RJT):
+//     f = J0 u        by row:    mfma(A = J0,   B = u[r])        by column:  mfma(A = u[r], B = J0)
+//     H . f           everywhere: mfma(A = H[r], B = f by row)
+//     mf = f + PH g   one FMA per layout with PH by row / by column (which the covariance update needs anyway)
+// so the per-lane scalar copies of u0..u3 and f0..f3, the quad broadcasts of PH and the FMA chains for f and H . f are
+// gone; the Jacobian column d f / d u2 = dth (-f1, f0) is a quad swap of f by column times a per-lane sign.
 CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
     const double c = c1 * K.rho, s = s1 * K.rho;
-    const double f0 = fma(c, x.u0, -s * x.u1), f1 = fma(s, x.u0, c * x.u1);
-    const double f2 = fma(K.M0, x.u2, K.M1 * x.u3), f3 = fma(K.M2, x.u2, K.M3 * x.u3);
-    const double dth = K.ang * dsp;
-    const double jv0 = -dth * f1, jv1 = dth * f0;
-    const double RJT = fma(K.k0, jv0, fma(K.k1, jv1, fma(K.kc, c, fma(K.ks, s, K.kk))));
+    const double J0T = fma(K.kc, c, fma(K.ks, s, K.kk));
+    const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
+    const double kjd = K.kj * (K.ang * dsp);
+    const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
     // ---- predict: Pp = J P J^T + Sigma
     const double Q = mfma4(x.P, RJT, 0.0);
     const double Pp = mfma4(RJT, Q, K.Sig);
@@ -84,21 +94,18 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
     const double PHr = mfma4(Pp, K.Hr, 0.0);
     const double PHq = mfma4(K.Hr, Pp, 0.0);
     S = mfma4(K.Hr, PHr, K.Xi);
-    const double pred = fma(K.H3, f3, fma(K.H2, f2, fma(K.H1, f1, K.H0 * f0)));
-    innov = y - pred;
+    innov = y - mfma4(K.Hr, f_r, 0.0);
     const double rS = rcp_nr1(S);                               // 2e-15 (one Newton step): two FMAs less on the chain
     x.P = fma(-(PHr * rS), PHq, Pp);                            // Pf = Pp - K (Pp H)^T
     const double g = rS * innov;
-    x.u0 = fma(dpp_f64<kQuadBcast0>(PHq), g, f0);               // mf = mp + K innov
-    x.u1 = fma(dpp_f64<kQuadBcast1>(PHq), g, f1);
-    x.u2 = fma(dpp_f64<kQuadBcast2>(PHq), g, f2);
-    x.u3 = fma(dpp_f64<kQuadBcast3>(PHq), g, f3);
+    x.ur = fma(PHr, g, f_r);                                    // mf = mp + K innov, in both layouts
+    x.uq = fma(PHq, g, f_q);
 }
 
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
 CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
-    softplus_pair_uniform(x.u2, sp, dsp);
+    softplus_pair_uniform(x.u2(), sp, dsp);
     // theta = dt 2 pi g(u2) fs as ONE multiply by the constant dt 2 pi fs (the reference rounds three times,
     // models.py:296-297: a relative 1e-16 on an angle of ~0.05 rad)
     fast_sincos_uniform(K.ang * sp, s1, c1);
@@ -124,8 +131,9 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 
 CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                  double& innov, unsigned* uncommon) {
+    const double u2 = x.u2();
     double sp, dsp;
-    softplus_wide(R, x.u2, exp_neg_common(R, x.u2), sp, dsp);
+    softplus_wide(R, u2, exp_neg_common(R, u2), sp, dsp);
     const double th = K.ang * sp;
     const double d = th - a.th;
     const double d2 = d * d, d4 = d2 * d2;
@@ -135,7 +143,7 @@ CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, doub
     // verdicts without compares, scalar registers or branches: clamp the high words into their admissible ranges and
     // OR the bits the clamp changed into a vector accumulator (non-zero = some step left the regime; NaN, inf and
     // negative u2 fall outside the signed range [ln 2, 700), NaN / inf angles above the magnitude bound)
-    const int hx = __double2hiint(x.u2);
+    const int hx = __double2hiint(u2);
     const unsigned hd = (unsigned)__double2hiint(d) & 0x7fffffffu;
     *uncommon |= (unsigned)(hx ^ max(0x3FE62E43, min(hx, 0x4085DFFF))) | (hd ^ min(hd, 0x3F7FFFFFu));
     a.th = th; a.c1 = c1; a.s1 = s1;
@@ -155,7 +163,6 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     K.rho = model.rho;
     K.ang = (model.dt * kTwoPi) * model.fs;
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
-    K.H0 = Hp[0]; K.H1 = Hp[1]; K.H2 = Hp[2]; K.H3 = Hp[3];
     K.Hr = Hp[r];
     K.Xi = io.Xi[trial * io.Xi_stride];
     // Sigma[r][q] (models.py:302-308)
@@ -165,12 +172,12 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     // J = [c -s jv0 0; s c jv1 0; 0 0 M0 M1; 0 0 M2 M3], this lane holds J[q][r]
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
-    K.k0 = (q == 0 && r == 2) ? 1.0 : 0.0; K.k1 = (q == 1 && r == 2) ? 1.0 : 0.0;
+    K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
     K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     Ekf4State x;
-    x.u0 = m0p[0]; x.u1 = m0p[1]; x.u2 = m0p[2]; x.u3 = m0p[3];
+    x.ur = m0p[r]; x.uq = m0p[q];
     x.P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
 
     const int64_t T = io.T;
@@ -199,16 +206,14 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
         unsigned uncommon = 0;
         if (checked_left == 0) {
             Ekf4Anchor anchor;
-            ekf4_anchor(K, x.u2, anchor);
+            ekf4_anchor(K, x.u2(), anchor);
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_spec(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
                 park[slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
-                const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
-                mfs.store2(x.u0, x.u1, m_off);
-                mfs.store2(x.u2, x.u3, m_off + 16u);
+                mfs.store(x.uq, lane < 4 ? t * 32u + 8u * lane : kOobOffset);
             }
         }
         const bool redo = __builtin_amdgcn_readfirstlane((int)uncommon) != 0;      // identical in every lane
@@ -220,9 +225,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
                 park[slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
-                const unsigned m_off = lane == 0 ? t * 32u : kOobOffset;
-                mfs.store2(x.u0, x.u1, m_off);
-                mfs.store2(x.u2, x.u3, m_off + 16u);
+                mfs.store(x.uq, lane < 4 ? t * 32u + 8u * lane : kOobOffset);
             }
             checked_left--;
         }
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 // kernel needs T x 0.4 us per 4096 trials.
 CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
-    softplus_pair_wide(x.u2, sp, dsp);
+    softplus_pair_wide(x.u2(), sp, dsp);
     fast_sincos(K.ang * sp, s1, c1);
     ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
 }
@@ -278,7 +281,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     K.rho = model.rho;
     K.ang = (model.dt * kTwoPi) * model.fs;
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
-    K.H0 = Hp[0]; K.H1 = Hp[1]; K.H2 = Hp[2]; K.H3 = Hp[3];
     K.Hr = Hp[r];
     K.Xi = io.Xi[trial * io.Xi_stride];
     K.Sig = 0.0;
@@ -286,12 +288,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     else if (r + q == 5) K.Sig = model.MS[1];
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
-    K.k0 = (q == 0 && r == 2) ? 1.0 : 0.0; K.k1 = (q == 1 && r == 2) ? 1.0 : 0.0;
+    K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
     K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     Ekf4State x;
-    x.u0 = m0p[0]; x.u1 = m0p[1]; x.u2 = m0p[2]; x.u3 = m0p[3];
+    x.ur = m0p[r]; x.uq = m0p[q];
     x.P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
 
     const int64_t T = io.T;
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     mfs.init(io.mfs ? io.mfs + first * T * 4 : nullptr, (int64_t)ntr * T * 32);
     Pfs.init(io.Pfs ? io.Pfs + first * T * 16 : nullptr, (int64_t)ntr * T * 128);
     const unsigned p_base = (unsigned)b * (unsigned)T * 128u + 8u * (4 * r + q);
-    const unsigned m_base = (r == 0 && q == 0) ? (unsigned)b * (unsigned)T * 32u : kOobOffset;
+    const unsigned m_base = (r == 0) ? (unsigned)b * (unsigned)T * 32u + 8u * q : kOobOffset;
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     const bool want_nll = io.nll != nullptr;
 
@@ -322,16 +324,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
         unsigned uncommon = 0;
         if (checked_left == 0) {
             Ekf4Anchor anchor;
-            ekf4_anchor_lane(K, x.u2, anchor);
+            ekf4_anchor_lane(K, x.u2(), anchor);
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_spec(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_base + t * 128u);
-                const unsigned m_off = m_base + t * 32u;      // kOobOffset + t * 32 stays out of range (windows < 2 GiB)
-                mfs.store2(x.u0, x.u1, m_off);
-                mfs.store2(x.u2, x.u3, m_off + 16u);
+                mfs.store(x.uq, m_base + t * 32u);               // kOobOffset + t * 32 stays out of range (windows < 2 GiB)
             }
         }
         const bool redo = __builtin_amdgcn_ballot_w64(uncommon != 0) != 0;
@@ -343,9 +343,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store(x.P, p_base + t * 128u);
-                const unsigned m_off = m_base + t * 32u;
-                mfs.store2(x.u0, x.u1, m_off);
-                mfs.store2(x.u2, x.u3, m_off + 16u);
+                mfs.store(x.uq, m_base + t * 32u);
             }
             checked_left--;
         }
