@@ -70,9 +70,9 @@ def bytes_per_trial_step(d):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
-    (profiles/r01_v16_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
+    (profiles/r01_v17_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
     FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v16_ekf_eks_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_v17_ekf_eks_pmc.json')
     try:
         prof = json.load(open(path))
     except OSError:
