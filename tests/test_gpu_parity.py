@@ -495,3 +495,26 @@ def test_four_trials_per_wave_dense_variant_at_large_batch():
     b = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, ys, flags=0x4)
     for x, y in zip(a, b):
         npt.assert_allclose(x, y, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='one_trial_per_wave'), pytest.param(WAVE_X4, id='four_trials_per_wave'),
+                                pytest.param(THREAD, id='lane_per_trial')])
+def test_nan_in_one_trial_of_the_chirp_ekf(kw):
+    """A NaN measurement in the middle of one record, and an indefinite P0 in another: those trials turn NaN exactly where
+    the oracle's do; their neighbours -- which share a wavefront with them in the four-trials-per-wave kernel, so their
+    chunks are repeated on the checked step -- are unaffected."""
+    c = _batch_case(cs.chirp_case, 6, T=700)
+    c.ys = c.ys.copy()
+    c.ys[1, 333] = np.nan
+    P0 = np.repeat(np.asarray(c.P0)[None], 6, axis=0)
+    P0[4] = np.array([[1., 2., 0, 0], [2., 1., 0, 0], [0, 0, 1., 0], [0, 0, 0, 1.]])
+    c.P0 = P0
+    from oracle import port
+    want = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys)
+    got = _fs().ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys, **kw)
+    for g, w in zip(got, want):
+        assert np.array_equal(np.isnan(g), np.isnan(w))
+        ok = ~np.isnan(w)
+        npt.assert_allclose(g[ok], w[ok], rtol=RTOL, atol=1e-12)
+    assert np.isnan(got[0][1, 333:]).all() and not np.isnan(got[0][1, :333]).any()
+    assert not np.isnan(got[0][[0, 2, 3, 5]]).any()
