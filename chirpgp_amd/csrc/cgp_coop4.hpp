@@ -1,4 +1,7 @@
-// cgp_coop4.hpp -- lane-cooperative EKF step for the d = 4 chirp model (BASELINE config C2's filter).
+// cgp_coop4.hpp -- lane-cooperative (DPP) layout for the d = 4 chirp model: the helpers every cooperative kernel shares
+// (DPP moves, the scalar-measurement update, the NLL flush) and the DPP EKF kernel.  That kernel was BASELINE config C2's
+// filter until the matrix-core version (cgp_mfma4.hpp) replaced it; it remains for records too long for the MFMA
+// kernel's 2 GiB output windows and behind CGP_DPP_KERNEL, and its update is what the sigma-point kernels call.
 //
 // Why: with one trial per wavefront the generic filter kernel executes every float64 instruction of a step on 64
 // identical lanes: 303 VALU + 42 SALU instructions and 1917 cycles per step (profiles/r01_v4_ekf_eks_pmc.json), i.e. the

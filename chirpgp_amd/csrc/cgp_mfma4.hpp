@@ -16,8 +16,8 @@
 //     S = H . PH + Xi       mfma(A = H[r],          B = PH[r], C = Xi)       lands in every lane
 //
 // Five matrix instructions replace the 85 DPP moves and FMAs of the cooperative kernel's covariance algebra
-// (cgp_coop4.hpp); what stays on the vector ALU is the scalar chain softplus -> sincos -> mean and the rank-one
-// update.  This is not a GEMM-shaped workload being forced onto MFMA: the products ARE 4 x 4 x 4, and the instruction
+// (cgp_coop4.hpp), three more carry the mean (ekf4_mfma_finish); what stays on the vector ALU is the scalar chain
+// softplus -> rotation and the rank-one update.  This is not a GEMM-shaped workload being forced onto MFMA: the products ARE 4 x 4 x 4, and the instruction
 // is used for its latency (one issue slot, 4 passes) on a T-serial chain.
 //
 // Speculation.  The step is one dependent chain, and a branch anywhere in it costs far more than its own cycles: it
