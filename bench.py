@@ -134,6 +134,8 @@ def main():
     ap.add_argument('--T', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--flags', type=int, default=0, help='CGP_* flag bits forwarded to the engine (e.g. 2 = wave per trial)')
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: the batch is the TOTAL over all ranks and is sharded (default: weak, --batch trials per rank)')
     ap.add_argument('--rehearse', action='store_true',
                     help='multi-process dry run on fewer GPUs than ranks: ranks share devices and the collectives go over '
                          'gloo on host copies (RCCL refuses two ranks on one device); timings are then meaningless')
@@ -164,6 +166,12 @@ def main():
 
     defaults = {'ekf': (1000, 10000), 'sgp': (1000, 10000), 'cd_sgp': (512, 50000), 'cd_ekf': (1000, 10000), 'harmonic': (1000, 10000)}
     B = args.batch or defaults[args.workload][0]
+    if args.strong and world > 1:                     # contiguous shard of the total batch
+        from chirpgp_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(B, rank, world)
+        B_total, B = B, hi - lo
+    else:
+        B_total = B * world
     T = args.T or defaults[args.workload][1]
     wl = make_workload(B, T, seed=1000003 * rank, kind=args.workload)
     d = wl['d']
@@ -197,6 +205,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Allocator priming (untimed, before the W warm-up steps): the timed loop keeps one result alive while the next step
+    # allocates its outputs, so it alternates between two sets of output buffers; two passes whose results are held
+    # together make PyTorch's caching allocator own both sets, and no hipMalloc of GB-sized buffers lands in the timed
+    # region whatever --warmup is.  Device memory management is not part of the path being measured.
+    prime = [step(), step()]
+    torch.cuda.synchronize()
+    del prime
     for _ in range(args.warmup):
         step()
     sync()
@@ -220,10 +235,10 @@ def main():
         last = coll(f[2][:, -1].contiguous())
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        out = parallel.all_gather_trials(last, world * B)
+        out = parallel.all_gather_trials(last, B_total)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert out.shape[0] == world * B
+        assert out.shape[0] == B_total
 
     if rank == 0:
         filt_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
@@ -232,19 +247,20 @@ def main():
         units = B * T
         dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)
         achieved = dom[2] * units / (dom[1] * 1e-3) / 1e9
-        total_gbs = (bf + bs) * units * world / (elapsed / args.steps) / 1e9
+        total_units = B_total * T                       # all ranks (rank 0's own share is `units`)
+        total_gbs = (bf + bs) * total_units / (elapsed / args.steps) / 1e9
         result = {
             "metric": "filter+smoother trial-steps/s (batch x T / wall)",
-            "value": units * world * args.steps / elapsed,
+            "value": total_units * args.steps / elapsed,
             "unit": "trial-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"ekf": "C2: discrete EKF+EKS (demos/ekfs_mle.py model)", "sgp": "C3: Gauss-Hermite order-3 sgp_filter+sgp_smoother",
                                     "cd_sgp": "C4: cd_sgp_filter+cd_sgp_smoother RK4", "cd_ekf": "cd_ekf+cd_eks RK4",
                                     "harmonic": "C5: 3-harmonic chirp, cubature sgp_filter+sgp_smoother"}[args.workload],
-                       "d": d, "T": T, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"trials sharded x{world}",
+                       "d": d, "T": T, "batch_per_gpu": B, "global_batch": B_total, "parallelism": f"trials sharded x{world}",
                        "sigma_points": int(wl['sgps'].n_points) if args.workload != 'ekf' and args.workload != 'cd_ekf' else None},
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
