@@ -83,6 +83,21 @@ def pmc_traffic(kernel_key):
     return None
 
 
+def pmc_issue(kernel_key, units):
+    """Instructions and cycles per trial-step of the dominant kernel from the same committed profile (SQ_INSTS_VALU,
+    SQ_INSTS_SALU, SQ_WAVE_CYCLES x 4): why a T-serial kernel sits far below the HBM roof at B = 1000."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_v17_ekf_eks_pmc.json')))
+    except OSError:
+        return None
+    for name, c in prof.items():
+        if kernel_key in name and all(k in c for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES')):
+            return {"valu_per_step": c['SQ_INSTS_VALU']['mean'] / units, "salu_per_step": c['SQ_INSTS_SALU']['mean'] / units,
+                    "cycles_per_step": 4 * c['SQ_WAVE_CYCLES']['mean'] / units, "waves": c['SQ_WAVES']['mean'],
+                    "source": "profiles/r01_v17_ekf_eks_pmc.json"}
+    return None
+
+
 def cpu_baseline(wl, target_seconds=12.0):
     """The oracle's C port (oracle/c/port.c, OpenMP over trials) timed on the host cores on a bounded sample of the
     SAME workload: as many trials (full T) as fit ~target_seconds, at least one per thread."""
@@ -272,6 +287,8 @@ def main():
                         "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9, "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9},
             "gather_ms": gather_ms,
         }
+        if args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags:
+            result["issue_profile"] = pmc_issue('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother', units)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
             if result["cpu_baseline"]:
