@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
                 const double d3 = fma(L(3, 2), cpt.xi2, fma(L(3, 1), cpt.xi1, L(3, 0) * cpt.xi0));
                 const double h0 = u0 + d0, h1 = u1 + d1;
                 typename DM::Pre pre;
-                model.precompute(u2 + d2, pre);
+                model.precompute(u2 + d2, pre);      // one group per lane: an anchored rotation would only add the anchor to the chain
                 const double g0 = pre.c[0] * h0 - pre.s[0] * h1, g1 = pre.s[0] * h0 + pre.c[0] * h1;
                 const double w0 = cpt.W * g0, w1 = cpt.W * g1;
                 double* tot = red + kRedChunk * kRedLd;

@@ -99,7 +99,10 @@ template <int D_> struct LinearDisc {
     // sigma-point interface: nothing to share between the points of a group
     static constexpr int IVC = 0;
     struct Pre {};
+    struct Anchor {};
+    CGP_DEV void anchor(double, Anchor&) const {}
     CGP_DEV void precompute(double, Pre&) const {}
+    CGP_DEV void precompute(double, const Anchor&, Pre&) const {}
     CGP_DEV void mean_pre(const Vec<D>& u, const Pre&, Vec<D>& f) const { matvec<D>(F, u, f); }
     CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const { matvec<D>(F, u, f); }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
@@ -152,6 +155,38 @@ template <int NH> struct HarmonicLCD {
     static constexpr int IVC = IV;
     struct Pre { double c[NH], s[NH]; };
     CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus_sel(wide, uv)) * fs, p.c, p.s); }
+    // The sigma points of one prediction spread around the mean, so their rotation angles differ from the mean's by a
+    // small d = dt (w - w0): the fan anchors (cos, sin) at the mean once and every point takes the small-angle rotation
+    // by d (sin to d^9, cos to d^8: remainders < 3e-19 for |d| <= 2^-4) instead of a full sincos -- 14 instead of ~45
+    // instructions per group of points.  If any lane's d is larger (or NaN) the wavefront also evaluates the full
+    // sincos and those lanes take it.
+    struct Anchor { double w0, c1, s1; };
+    CGP_DEV void anchor(double uv0, Anchor& a) const {
+        a.w0 = (kTwoPi * softplus_sel(wide, uv0)) * fs;
+        fast_sincos(dt * a.w0, a.s1, a.c1);
+    }
+    CGP_DEV void precompute(double uv, const Anchor& a, Pre& p) const {
+        const double w = (kTwoPi * softplus_sel(wide, uv)) * fs;
+        const double d = dt * (w - a.w0), d2 = d * d;
+        const double ps = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        const double cd = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+        const double sd = d * ps;
+        double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
+        const bool small = fabs(d) <= 0.0625;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!small) != 0, 0)) {
+            double sf, cf;
+            fast_sincos(dt * w, sf, cf);
+            c1 = small ? c1 : cf;
+            s1 = small ? s1 : sf;
+        }
+        double ck = c1, sk = s1;
+        p.c[0] = c1 * rho; p.s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            p.c[k] = ck * rho; p.s[k] = sk * rho;
+        }
+    }
     CGP_DEV void mean_pre(const Vec<D>& u, const Pre& p, Vec<D>& f) const {
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             f.v[2 * k] = p.c[k] * u.v[2 * k] - p.s[k] * u.v[2 * k + 1];

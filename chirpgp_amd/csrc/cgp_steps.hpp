@@ -161,13 +161,18 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
     // Fan over groups of points that share chi_v (the coordinate the model is nonlinear in): one lane per group in the
     // wave shape, a serial loop otherwise; the model's transcendental part runs once per group.
     const int step = WAVE ? 64 : 1, ng = sg.groups();
+    // one lane walking all groups anchors the rotation at the mean (cgp_models.hpp); with one group per lane the anchor
+    // would only lengthen the chain
+    typename DM::Anchor anchor;
+    if (!WAVE) model.anchor(mf.v[DM::IVC], anchor);
     for (int g = WAVE ? lane : 0; g < ng; g += step) {
         int p = sg.template begin<ST>(g);
         const int pe = sg.template end<ST>(g);
         Vec<D> chi, f;
         sigma_point<D, ST>(mf, L, sg, p, chi);
         typename DM::Pre pre;
-        model.precompute(chi.v[DM::IVC], pre);
+        if (WAVE) model.precompute(chi.v[DM::IVC], pre);
+        else model.precompute(chi.v[DM::IVC], anchor, pre);
         for (;;) {
             model.mean_pre(chi, pre, f);
             const double w = sg.template weight<ST>(p);
@@ -218,6 +223,8 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
     double sf0 = 0.0, sf1 = 0.0, s00 = 0.0, s10 = 0.0, s11 = 0.0;
     double x02 = 0.0, x12 = 0.0, x03 = 0.0, x13 = 0.0, c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
     const int ng = sg.groups();
+    HarmonicLCD<1>::Anchor anchor;
+    model.anchor(mf.v[2], anchor);
     for (int g = 0; g < ng; g++) {
         const int p0 = sg.template begin<ST>(g), p1 = sg.template end<ST>(g);
         double W = 0.0;
@@ -229,7 +236,7 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
         const double d3 = fma(L(3, 2), xi2, fma(L(3, 1), xi1, L(3, 0) * xi0));
         const double h0 = mf.v[0] + d0, h1 = mf.v[1] + d1;
         HarmonicLCD<1>::Pre pre;
-        model.precompute(mf.v[2] + d2, pre);
+        model.precompute(mf.v[2] + d2, anchor, pre);
         const double f0 = pre.c[0] * h0 - pre.s[0] * h1, f1 = pre.s[0] * h0 + pre.c[0] * h1;
         const double w0 = W * f0, w1 = W * f1;
         sf0 += w0; sf1 += w1;
