@@ -7,9 +7,12 @@ discrete EKF + EKS of the demos' chirp model (demos/ekfs_mle.py), d = 4, T = 10 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ekf|sgp|cd_sgp|cd_ekf|harmonic] [--batch B] [--T T]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU over RCCL); trials shard across ranks with no data-path
-collective (weak scaling: every rank runs B trials); one all_gather of the per-trial final NLL happens after the
-timed region and is reported as gather_ms.  Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run as a child
+process, one rank per GPU over RCCL; the parent never touches the GPU); under an external torchrun it checks that
+WORLD_SIZE == N.  Trials shard across ranks with no data-path collective; one all_gather of the per-trial final NLL
+happens after the timed region and is reported as gather_ms.  Scaling: C2 (`ekf`) is weak by default (B = 1000 per
+rank) and also reports the strong figure (B = 1000 in total) under "strong"; C3 / C5 (`sgp`, `harmonic`) are strong
+by default ("batch=1000 sharded 8 GPUs", BASELINE.json); `--scaling weak|strong` overrides.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
+PMC_PROFILE = 'profiles/r01_v17_ekf_eks_pmc.json'
 
 
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0):
@@ -72,7 +77,7 @@ def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
     (profiles/r01_v17_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
     FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v17_ekf_eks_pmc.json')
+    path = os.path.join(ROOT, PMC_PROFILE)
     try:
         prof = json.load(open(path))
     except OSError:
@@ -87,14 +92,14 @@ def pmc_issue(kernel_key, units):
     """Instructions and cycles per trial-step of the dominant kernel from the same committed profile (SQ_INSTS_VALU,
     SQ_INSTS_SALU, SQ_WAVE_CYCLES x 4): why a T-serial kernel sits far below the HBM roof at B = 1000."""
     try:
-        prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_v17_ekf_eks_pmc.json')))
+        prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
     except OSError:
         return None
     for name, c in prof.items():
         if kernel_key in name and all(k in c for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES')):
             return {"valu_per_step": c['SQ_INSTS_VALU']['mean'] / units, "salu_per_step": c['SQ_INSTS_SALU']['mean'] / units,
                     "cycles_per_step": 4 * c['SQ_WAVE_CYCLES']['mean'] / units, "waves": c['SQ_WAVES']['mean'],
-                    "source": "profiles/r01_v17_ekf_eks_pmc.json"}
+                    "source": PMC_PROFILE}
     return None
 
 
@@ -139,28 +144,89 @@ def cpu_baseline(wl, target_seconds=12.0):
             "sample": f"{n2} of {ys.shape[0]} trials x T={T} ({label}, oracle/c/port.c, OpenMP, best of 2, {best:.2f} s)"}
 
 
-def main():
+WORKLOADS = {
+    # kind: (label, default trials, default T, default scaling, which roof bounds it in the large-batch limit)
+    'ekf': ("C2: discrete EKF+EKS (demos/ekfs_mle.py model)", 1000, 10000, 'weak', 'hbm'),
+    'sgp': ("C3: Gauss-Hermite order-3 sgp_filter+sgp_smoother", 1000, 10000, 'strong', 'valu_f64'),
+    'cd_sgp': ("C4: cd_sgp_filter+cd_sgp_smoother RK4", 512, 50000, 'weak', 'valu_f64'),
+    'cd_ekf': ("cd_ekf+cd_eks RK4", 1000, 10000, 'weak', 'valu_f64'),
+    'harmonic': ("C5: 3-harmonic chirp, cubature sgp_filter+sgp_smoother", 1000, 10000, 'strong', 'valu_f64'),
+}
+# float64 vector peak: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2 flop x 2.4 GHz (a wave64 v_fma_f64 occupies its SIMD for
+# 4 cycles: measured 4.0 cycles per independent instruction, one wave per SIMD, tools/ubench/f64_issue.hip)
+F64_VALU_PEAK_TFLOPS = 78.6
+N_SIMDS = 1024
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='ekf', choices=['ekf', 'sgp', 'cd_sgp', 'cd_ekf', 'harmonic'])
-    ap.add_argument('--batch', type=int, default=None, help='trials per GPU (default: BASELINE config)')
+    ap.add_argument('--workload', default='ekf', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None,
+                    help='trials: per GPU under weak scaling, in total under strong scaling (default: BASELINE config)')
     ap.add_argument('--T', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--flags', type=int, default=0, help='CGP_* flag bits forwarded to the engine (e.g. 2 = wave per trial)')
-    ap.add_argument('--strong', action='store_true',
-                    help='strong scaling: the batch is the TOTAL over all ranks and is sharded (default: weak, --batch trials per rank)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None,
+                    help='weak: --batch trials per rank; strong: --batch trials in total, sharded (default per workload: '
+                         'ekf / cd_* weak, sgp / harmonic strong as BASELINE.json words them)')
+    ap.add_argument('--strong', action='store_true', help='same as --scaling strong')
     ap.add_argument('--rehearse', action='store_true',
                     help='multi-process dry run on fewer GPUs than ranks: ranks share devices and the collectives go over '
                          'gloo on host copies (RCCL refuses two ranks on one device); timings are then meaningless')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+def launcher_command(gpus, argv, port):
+    """The child process that runs this script on `gpus` ranks of one node (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(gpus)}',
+            '--master-addr', '127.0.0.1', '--master-port', str(int(port)), os.path.abspath(__file__), *argv]
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def valu_issue(workload, kernel, units, ms):
+    """Executed float64 vector work of one launch from the committed PMC profile of this workload
+    (profiles/r02_issue_table.json, written by tools/issue_table.py from rocprofv3 --pmc passes): wave-instructions by
+    class per trial-step, hence executed FLOP (all 64 lanes counted, FMA = 2) and the share of VALU issue slots used."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_issue_table.json')))[workload][kernel]
+    except (OSError, KeyError):
+        return None
+    flop_per_step = 64 * (2 * tab['fma_f64'] + tab['mul_f64'] + tab['add_f64']) + 2 * 256 * tab.get('mfma_f64', 0)
+    return {"executed_tflops": flop_per_step * units / (ms * 1e-3) / 1e12, "valu_per_step": tab['valu'],
+            "f64_per_step": tab['fma_f64'] + tab['mul_f64'] + tab['add_f64'], "cycles_per_step": tab.get('cycles'),
+            "source": tab.get('source', 'profiles/r02_issue_table.json')}
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Start the ranks as a child process BEFORE anything here imports torch or touches the GPU; never exec.
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        sys.exit(subprocess.run(launcher_command(args.gpus, sys.argv[1:], free_port()), env=env).returncode)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it as '
+                         f'`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` '
+                         f'or let `python bench.py --gpus {args.gpus}` start the ranks itself')
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU')
     if args.rehearse:
@@ -172,122 +238,155 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     def coll(t):
         """Tensor as the process group wants it: HBM for RCCL, a host copy for the gloo rehearsal."""
         return t.cpu() if args.rehearse else t
 
     from chirpgp_amd import filters_smoothers as fs
-
-    defaults = {'ekf': (1000, 10000), 'sgp': (1000, 10000), 'cd_sgp': (512, 50000), 'cd_ekf': (1000, 10000), 'harmonic': (1000, 10000)}
-    B = args.batch or defaults[args.workload][0]
-    if args.strong and world > 1:                     # contiguous shard of the total batch (SURVEY.md 8e)
-        from chirpgp_amd.parallel import shard_bounds
-        lo, hi = shard_bounds(B, rank, world)
-        B_total, B = B, hi - lo
-    else:
-        B_total = B * world
-    T = args.T or defaults[args.workload][1]
-    wl = make_workload(B, T, seed=1000003 * rank, kind=args.workload)
-    d = wl['d']
-    ys_dev = torch.from_numpy(wl['ys']).cuda()
-    kw = dict(flags=args.flags) if args.flags else {}
-
     from chirpgp_amd import _engine
+    from chirpgp_amd.parallel import shard_bounds
 
-    def step(record=None):
-        k = wl['kind']
-        if k == 'ekf':
-            f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
-        elif k in ('sgp', 'harmonic'):
-            f = fs.sgp_filter(wl['disc'], wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
-        elif k == 'cd_sgp':
-            f = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
-        else:
-            f = fs.cd_ekf(wl['drift'], wl['disp'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
-        if k == 'ekf':
-            s = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
-        elif k in ('sgp', 'harmonic'):
-            s = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'], **kw)
-        elif k == 'cd_sgp':
-            s = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], f[0], f[1], wl['dt'], **kw)
-        else:
-            s = fs.cd_eks(wl['drift'], wl['disp'], f[0], f[1], wl['dt'], **kw)
-        return f, s
+    label, B_default, T_default, scaling_default, bound = WORKLOADS[args.workload]
+    scaling = 'strong' if args.strong else (args.scaling or scaling_default)
+    batch = args.batch or B_default
+    T = args.T or T_default
+    kw = dict(flags=args.flags) if args.flags else {}
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Allocator priming (untimed, before the W warm-up steps): the timed loop keeps one result alive while the next step
-    # allocates its outputs, so it alternates between two sets of output buffers; two passes whose results are held
-    # together make PyTorch's caching allocator own both sets, and no hipMalloc of GB-sized buffers lands in the timed
-    # region whatever --warmup is.  Device memory management is not part of the path being measured.
-    prime = [step(), step()]
-    torch.cuda.synchronize()
-    del prime
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # HIP events on the launch stream, recorded immediately around each C-ABI call (kernel duration, not host time)
-    events = _engine.kernel_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        f, s = step(events)
-    sync()
-    elapsed = time.perf_counter() - t0
-    _engine.kernel_events = None
-    tmax = coll(torch.tensor([elapsed], dtype=torch.float64, device='cuda'))
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    def measure(mode):
+        """W warm-up and K timed passes of the workload under `mode` scaling -> measurements of this rank (times are the
+        maximum over ranks)."""
+        if mode == 'strong':                          # contiguous shard of the total batch (SURVEY.md 8e)
+            lo, hi = shard_bounds(batch, rank, world)
+            B, B_total = hi - lo, batch
+        else:
+            B, B_total = batch, batch * world
+        wl = make_workload(max(B, 1), T, seed=1000003 * rank, kind=args.workload)
+        if B == 0:                                    # more ranks than trials: this rank idles through the barriers
+            wl['ys'] = wl['ys'][:0]
+        ys_dev = torch.from_numpy(wl['ys']).cuda()
 
-    # the single collective of the path: gather the per-trial final NLL (B doubles per rank) -- after the timed region
-    gather_ms = None
-    if world > 1:
-        from chirpgp_amd import parallel
-        last = coll(f[2][:, -1].contiguous())
+        def step():
+            k = wl['kind']
+            if k == 'ekf':
+                f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
+                s = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
+            elif k in ('sgp', 'harmonic'):
+                f = fs.sgp_filter(wl['disc'], wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
+                s = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'], **kw)
+            elif k == 'cd_sgp':
+                f = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
+                s = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], f[0], f[1], wl['dt'], **kw)
+            else:
+                f = fs.cd_ekf(wl['drift'], wl['disp'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
+                s = fs.cd_eks(wl['drift'], wl['disp'], f[0], f[1], wl['dt'], **kw)
+            return f, s
+
+        # Allocator priming (untimed, before the W warm-up steps): the timed loop keeps one result alive while the next
+        # step allocates its outputs, so it alternates between two sets of output buffers; two passes whose results are
+        # held together make PyTorch's caching allocator own both sets, and no hipMalloc of GB-sized buffers lands in the
+        # timed region whatever --warmup is.  Device memory management is not part of the path being measured.
+        prime = [step(), step()]
         torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        out = parallel.all_gather_trials(last, B_total)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert out.shape[0] == B_total
+        del prime
+        for _ in range(args.warmup):
+            step()
+        sync()
+        # HIP events on the launch stream, recorded immediately around each C-ABI call (kernel duration, not host time)
+        events = _engine.kernel_events = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            f, s = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        _engine.kernel_events = None
+        tmax = coll(torch.tensor([elapsed], dtype=torch.float64, device='cuda'))
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+        # the single collective of the path: gather the per-trial final NLL -- after the timed region
+        gather_ms = None
+        if world > 1:
+            from chirpgp_amd import parallel
+            last = coll(f[2][:, -1].contiguous())
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            out = parallel.all_gather_trials(last, B_total) if mode == 'strong' else parallel.all_gather_trials(last, B * world)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            assert out.shape[0] == B_total
+        filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
+        smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
+        return dict(wl=wl, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
+                    filt_ms=float(np.mean(filt)) if filt else 0.0, smooth_ms=float(np.mean(smooth)) if smooth else 0.0)
+
+    m = measure(scaling)
+    # C2's north star also asks for the strong figure (1000 trials in total): measured right after, reported beside
+    other = measure('strong') if (world > 1 and scaling == 'weak' and args.workload == 'ekf') else None
 
     if rank == 0:
-        filt_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
-        smooth_ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'smoother']))
+        wl, B, B_total, elapsed = m['wl'], m['B'], m['B_total'], m['elapsed']
+        d = wl['d']
+        filt_ms, smooth_ms = m['filt_ms'], m['smooth_ms']
         bf, bs = bytes_per_trial_step(d)
-        units = B * T
+        units = B * T                                   # rank 0's own share (kernel figures are rank 0's)
         dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)
         achieved = dom[2] * units / (dom[1] * 1e-3) / 1e9
-        total_units = B_total * T                       # all ranks (rank 0's own share is `units`)
+        total_units = B_total * T                       # all ranks
         total_gbs = (bf + bs) * total_units / (elapsed / args.steps) / 1e9
+        bench_shape = args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags
+        traffic = pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother') if bench_shape else None
+        hbm = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+               "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "committed; not re-measured by this run)") if traffic is not None else None,
+               "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1],
+               # one wavefront per trial below ~2.5 trials per SIMD (cgp_api.hip:choose_wave): occupancy of the 1024 SIMDs
+               "waves_per_simd": round(B / N_SIMDS, 3) if B < 2560 else None}
+        roofline = hbm
+        if bound == 'valu_f64':
+            # sigma-point / RK4 workloads: 80-220 flop per byte against a machine balance of ~10 (SURVEY.md 8d), so the
+            # float64 vector pipe is the roof; the HBM fraction stays beside it
+            iss = valu_issue(args.workload, dom[0], units, dom[1])
+            roofline = {"bound": "valu_f64", "kernel": dom[0],
+                        "achieved": iss["executed_tflops"] if iss else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": iss["executed_tflops"] / F64_VALU_PEAK_TFLOPS if iss else None,
+                        "executed_flop_source": iss["source"] if iss else None,
+                        "valu_per_step": iss["valu_per_step"] if iss else None, "f64_per_step": iss["f64_per_step"] if iss else None,
+                        "cycles_per_step": iss["cycles_per_step"] if iss else None,
+                        "waves_per_simd": hbm["waves_per_simd"], "avg_launch_ms": dom[1], "traffic": None, "traffic_source": None,
+                        "hbm": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}}
         result = {
             "metric": "filter+smoother trial-steps/s (batch x T / wall)",
             "value": total_units * args.steps / elapsed,
             "unit": "trial-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"ekf": "C2: discrete EKF+EKS (demos/ekfs_mle.py model)", "sgp": "C3: Gauss-Hermite order-3 sgp_filter+sgp_smoother",
-                                    "cd_sgp": "C4: cd_sgp_filter+cd_sgp_smoother RK4", "cd_ekf": "cd_ekf+cd_eks RK4",
-                                    "harmonic": "C5: 3-harmonic chirp, cubature sgp_filter+sgp_smoother"}[args.workload],
-                       "d": d, "T": T, "batch_per_gpu": B, "global_batch": B_total, "parallelism": f"trials sharded x{world}",
-                       "sigma_points": int(wl['sgps'].n_points) if args.workload != 'ekf' and args.workload != 'cd_ekf' else None},
+            "config": {"workload": label, "d": d, "T": T, "batch_per_gpu": B, "global_batch": B_total,
+                       "parallelism": f"trials sharded x{world}",
+                       "sigma_points": int(wl['sgps'].n_points) if args.workload not in ('ekf', 'cd_ekf') else None},
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother')
-                                     if (args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags) else None),
-                         "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1]},
+            "roofline": roofline,
             "kernels": {"filter_ms": filt_ms, "smoother_ms": smooth_ms,
-                        "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9, "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9},
-            "gather_ms": gather_ms,
+                        "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
+                        "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9 if smooth_ms else None},
+            "gather_ms": m['gather_ms'],
         }
-        if args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags:
+        if other is not None:
+            result["strong"] = {"value": other['B_total'] * T * args.steps / other['elapsed'], "unit": "trial-steps/s",
+                                "global_batch": other['B_total'], "batch_per_gpu": other['B'],
+                                "ms_per_step": other['elapsed'] / args.steps * 1e3, "gather_ms": other['gather_ms'],
+                                "filter_ms": other['filt_ms'], "smoother_ms": other['smooth_ms']}
+        if bench_shape:
             result["issue_profile"] = pmc_issue('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother', units)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
