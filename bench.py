@@ -66,6 +66,19 @@ def make_workload(B, T, seed=0, kind='ekf'):
     return wl
 
 
+def frozen_frequency_linear_model(params, dt):
+    """BASELINE config C1's linear model: the chirp LCD discretisation with the frequency frozen at its initial value,
+    F = blockdiag(exp(-lam dt) Rot(2 pi g(m0_v) dt), M32_F) (models.py:296-301), Sigma = blockdiag(q, q, M32_Sigma)
+    (models.py:302-308) -- what `kf` / `rts` run on in the plumbing configuration."""
+    from chirpgp_amd import models as pm
+    lam, b, delta, ell, sigma, m0_v = (float(x) for x in params)
+    th = dt * 2 * math.pi * float(pm.g(m0_v))
+    rot = math.exp(-lam * dt) * np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+    Fm, Sm = pm._m32(ell, sigma, dt)
+    q = b ** 2 * dt if lam == 0. else b ** 2 / (2 * lam) * (1 - math.exp(-2 * lam * dt))
+    return pm._blkdiag([rot, Fm]), pm._blkdiag([q, q, Sm])
+
+
 def bytes_per_trial_step(d):
     """filter reads y (8 B), writes mf, Pf, nll (8d + 8d^2 + 8); smoother reads and writes 8d + 8d^2."""
     filt = 8 + 8 * d + 8 * d * d + 8

@@ -292,21 +292,23 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     d = int(spec.d)
     if d > MAX_D:
         raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
-    ctx = context(ys_d.device.index)
-    keep = [ys_d]
-    model = _model_struct(spec, gamma, B, keep)
-    sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
-    init = _init_struct(H, Xi, m0, P0, d, B, keep)
-    opts = dict(dtype=torch.float64, device=ys_d.device)
-    mfs = torch.empty((B, T, d), **opts) if want[0] else None
-    Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
-    nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
-    fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
-    lib, st = load_library(), _stream()
-    rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                                 C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
-    _check(ctx, rc, 'cgp_filter')
-    return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
+    # constants, stream, outputs and the launch all belong to the device the data lives on, whatever the current one is
+    with torch.cuda.device(ys_d.device):
+        ctx = context(ys_d.device.index)
+        keep = [ys_d]
+        model = _model_struct(spec, gamma, B, keep)
+        sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
+        init = _init_struct(H, Xi, m0, P0, d, B, keep)
+        opts = dict(dtype=torch.float64, device=ys_d.device)
+        mfs = torch.empty((B, T, d), **opts) if want[0] else None
+        Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
+        nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
+        fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
+        lib, st = load_library(), _stream()
+        rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                     C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
+        _check(ctx, rc, 'cgp_filter')
+        return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
 
 
 def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
@@ -324,16 +326,17 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
         raise ValueError(f'model dimension {spec.d} != data dimension {d}')
     if d > MAX_D:
         raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
-    ctx = context(m.device.index)
-    keep = [m, P]
-    model = _model_struct(spec, gamma, B, keep)
-    sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
-    mss, Pss = torch.empty_like(m), torch.empty_like(P)
-    lib, st = load_library(), _stream()
-    rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                                     float(dt), _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), st))
-    _check(ctx, rc, 'cgp_smoother')
-    return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
+    with torch.cuda.device(m.device):
+        ctx = context(m.device.index)
+        keep = [m, P]
+        model = _model_struct(spec, gamma, B, keep)
+        sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
+        mss, Pss = torch.empty_like(m), torch.empty_like(P)
+        lib, st = load_library(), _stream()
+        rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                         float(dt), _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), st))
+        _check(ctx, rc, 'cgp_smoother')
+        return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
 
 
 def gaussian_expectation(ms, chol_Ps, xi, w):
@@ -343,25 +346,27 @@ def gaussian_expectation(ms, chol_Ps, xi, w):
     m, s = dev(ms).reshape(-1), dev(chol_Ps).reshape(-1)
     if m.shape != s.shape:
         raise ValueError('ms and chol_Ps must have the same number of entries')
-    ctx = context(m.device.index)
-    xi_d, w_d = dev(xi).reshape(-1), dev(w).reshape(-1)
-    out = torch.empty_like(m)
-    rc = load_library().cgp_gaussian_expectation(ctx, _ptr(m), _ptr(s), m.numel(), 1, _ptr(xi_d), _ptr(w_d), xi_d.numel(),
-                                                 _ptr(out), _stream())
-    _check(ctx, rc, 'cgp_gaussian_expectation')
-    out = out.reshape(-1, 1)
-    return out.cpu().numpy() if like_numpy else out
+    with torch.cuda.device(m.device):
+        ctx = context(m.device.index)
+        xi_d, w_d = dev(xi).reshape(-1), dev(w).reshape(-1)
+        out = torch.empty_like(m)
+        rc = load_library().cgp_gaussian_expectation(ctx, _ptr(m), _ptr(s), m.numel(), 1, _ptr(xi_d), _ptr(w_d), xi_d.numel(),
+                                                     _ptr(out), _stream())
+        _check(ctx, rc, 'cgp_gaussian_expectation')
+        out = out.reshape(-1, 1)
+        return out.cpu().numpy() if like_numpy else out
 
 
 def debug_math(op, x):
     """In-kernel elementary functions on the device (test hook): returns (out0, out1) as NumPy arrays."""
     torch = _torch()
     xd = dev(x).reshape(-1)
-    ctx = context(xd.device.index)
-    o0, o1 = torch.empty_like(xd), torch.empty_like(xd)
-    rc = load_library().cgp_debug_math(ctx, int(op), _ptr(xd), xd.numel(), _ptr(o0), _ptr(o1), _stream())
-    _check(ctx, rc, 'cgp_debug_math')
-    return o0.cpu().numpy(), o1.cpu().numpy()
+    with torch.cuda.device(xd.device):
+        ctx = context(xd.device.index)
+        o0, o1 = torch.empty_like(xd), torch.empty_like(xd)
+        rc = load_library().cgp_debug_math(ctx, int(op), _ptr(xd), xd.numel(), _ptr(o0), _ptr(o1), _stream())
+        _check(ctx, rc, 'cgp_debug_math')
+        return o0.cpu().numpy(), o1.cpu().numpy()
 
 
 def _init_struct(H, Xi, m0, P0, d, B, keep):
@@ -399,19 +404,20 @@ def run_simulate(spec, H, Xi, m0, P0, dt, T, seed, B, trial0=0, want=(True, True
     if d > MAX_D:
         raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
     B, T = int(B), int(T)
-    ctx = context(device)
-    keep = []
-    model = _model_struct(spec, None, B, keep)
-    init = _init_struct(H if want[1] else None, Xi if want[1] else None, m0, P0, d, B, keep)
-    opts = dict(dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device() if device is None else device))
-    xs = torch.empty((B, T, d), **opts) if want[0] else None
-    ys = torch.empty((B, T), **opts) if want[1] else None
-    lib, st = load_library(), _stream()
-    fl = int(flags) | (SIM_FIXED_X0 if P0 is None else 0)
-    rc = _timed('simulate', lambda: lib.cgp_simulate(ctx, C.byref(model), C.byref(init), float(dt), int(seed) & (2 ** 64 - 1),
-                                                     int(trial0), B, T, _ptr(xs), _ptr(ys), fl, st))
-    _check(ctx, rc, 'cgp_simulate')
-    return xs, ys
+    with torch.cuda.device(torch.cuda.current_device() if device is None else device):
+        ctx = context(device)
+        keep = []
+        model = _model_struct(spec, None, B, keep)
+        init = _init_struct(H if want[1] else None, Xi if want[1] else None, m0, P0, d, B, keep)
+        opts = dict(dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device() if device is None else device))
+        xs = torch.empty((B, T, d), **opts) if want[0] else None
+        ys = torch.empty((B, T), **opts) if want[1] else None
+        lib, st = load_library(), _stream()
+        fl = int(flags) | (SIM_FIXED_X0 if P0 is None else 0)
+        rc = _timed('simulate', lambda: lib.cgp_simulate(ctx, C.byref(model), C.byref(init), float(dt), int(seed) & (2 ** 64 - 1),
+                                                         int(trial0), B, T, _ptr(xs), _ptr(ys), fl, st))
+        _check(ctx, rc, 'cgp_simulate')
+        return xs, ys
 
 
 def add_noise(clean, Xi, seed, B, trial0=0):
@@ -424,15 +430,16 @@ def add_noise(clean, Xi, seed, B, trial0=0):
         stride, T = int(c.shape[1]), int(c.shape[1])
     else:
         raise ValueError(f'clean must be (T,) or ({B}, T), got {tuple(c.shape)}')
-    Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
-    if Xit.numel() not in (1, B):
-        raise ValueError('Xi must be a scalar or have one entry per trial')
-    ctx = context(c.device.index)
-    ys = torch.empty((int(B), T), dtype=torch.float64, device=c.device)
-    rc = _timed('add_noise', lambda: load_library().cgp_add_noise(ctx, _ptr(c), stride, _ptr(Xit), 1 if Xit.numel() > 1 else 0,
-                                                                  int(seed) & (2 ** 64 - 1), int(trial0), int(B), T, _ptr(ys), _stream()))
-    _check(ctx, rc, 'cgp_add_noise')
-    return ys
+    with torch.cuda.device(c.device):
+        Xit = dev_const(np.asarray(Xi, dtype=np.float64).reshape(-1)) if not _is_torch(Xi) else dev(Xi.reshape(-1))
+        if Xit.numel() not in (1, B):
+            raise ValueError('Xi must be a scalar or have one entry per trial')
+        ctx = context(c.device.index)
+        ys = torch.empty((int(B), T), dtype=torch.float64, device=c.device)
+        rc = _timed('add_noise', lambda: load_library().cgp_add_noise(ctx, _ptr(c), stride, _ptr(Xit), 1 if Xit.numel() > 1 else 0,
+                                                                      int(seed) & (2 ** 64 - 1), int(trial0), int(B), T, _ptr(ys), _stream()))
+        _check(ctx, rc, 'cgp_add_noise')
+        return ys
 
 
 def debug_philox(ctr, key):

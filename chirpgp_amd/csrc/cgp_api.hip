@@ -139,7 +139,11 @@ int cgp_create(cgp_ctx** out, int device) {
 
 void cgp_destroy(cgp_ctx* ctx) { delete ctx; }
 
-const char* cgp_last_error(const cgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* cgp_last_error(const cgp_ctx* ctx) {
+    if (!ctx) return "null context";
+    const ThreadError& e = thread_error();
+    return e.ctx == ctx ? e.msg.c_str() : "";
+}
 
 int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
                double dt, const double* ys, int64_t B, int64_t T, double* mfs, double* Pfs, double* nll,
@@ -156,7 +160,8 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     int rc = check_model(ctx, model, sde, sig, sigma);
     if (rc != CGP_OK) return rc;
     if ((method == CGP_F_EKF_KPT) != (model->model_id == CGP_M_KPT)) return fail(ctx, CGP_E_ARG, "CGP_F_EKF_KPT goes with CGP_M_KPT only");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
 
     FilterIO io;
     io.H = init->H; io.H_stride = init->H_stride;
@@ -205,7 +210,8 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     int rc = check_model(ctx, model, sde, sig, sigma);
     if (rc != CGP_OK) return rc;
     if (model->model_id == CGP_M_KPT) return fail(ctx, CGP_E_ARG, "the KPT model has no smoother in the reference");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
 
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
@@ -236,7 +242,8 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
     if (n < 0 || order < 1) return fail(ctx, CGP_E_ARG, "bad n or order");
     if (n == 0) return CGP_OK;
     if (!ms || !sd || !xi || !w || !out) return fail(ctx, CGP_E_ARG, "NULL pointer");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
     hipLaunchKernelGGL(gaussian_expectation_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ms, sd, n, in_stride, xi, w, order, out);
@@ -248,7 +255,8 @@ int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out
     if (n < 0 || op < 0 || op > 9) return fail(ctx, CGP_E_ARG, "bad op or n");
     if (n == 0) return CGP_OK;
     if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
     if (op == 5 || op == 6 || op == 8) hipLaunchKernelGGL(debug_math_uniform_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), 0, (hipStream_t)stream, op, x, n, out0, out1);
     else hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, op, x, n, out0, out1);

@@ -1,4 +1,4 @@
-// Discrete linear model (kf / rts, and ekf / sgp on a linear cond_m_cov): d = 1..6, 8.
+// Discrete linear model (kf / rts, and ekf / sgp on a linear cond_m_cov): d = 1..8.
 #include "cgp_dispatch.hpp"
 namespace cgp {
 int dispatch_filter_disc_linear(int method, int key, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
@@ -9,6 +9,7 @@ int dispatch_filter_disc_linear(int method, int key, bool wave, const FilterIO& 
     case 4: return filter_disc<LinearDisc<4>>(method, wave, io, ma, st);
     case 5: return filter_disc<LinearDisc<5>>(method, wave, io, ma, st);
     case 6: return filter_disc<LinearDisc<6>>(method, wave, io, ma, st);
+    case 7: return filter_disc<LinearDisc<7>>(method, wave, io, ma, st);
     case 8: return filter_disc<LinearDisc<8>>(method, wave, io, ma, st);
     default: return CGP_E_UNSUPPORTED;
     }
@@ -21,6 +22,7 @@ int dispatch_smoother_disc_linear(int method, int key, bool wave, const Smoother
     case 4: return smoother_disc<LinearDisc<4>>(method, wave, io, ma, st);
     case 5: return smoother_disc<LinearDisc<5>>(method, wave, io, ma, st);
     case 6: return smoother_disc<LinearDisc<6>>(method, wave, io, ma, st);
+    case 7: return smoother_disc<LinearDisc<7>>(method, wave, io, ma, st);
     case 8: return smoother_disc<LinearDisc<8>>(method, wave, io, ma, st);
     default: return CGP_E_UNSUPPORTED;
     }

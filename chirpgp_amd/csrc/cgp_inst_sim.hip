@@ -50,7 +50,8 @@ int cgp_simulate(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init, dou
     if (model->param_stride != 0 && model->param_stride < model->n_params) return fail(ctx, CGP_E_ARG, "model.param_stride < n_params");
     // counter word 2 holds step * ceil(d / 2) + pair
     if ((uint64_t)T * (uint64_t)((model->d + 1) / 2) > 0xFFFFFFFFull) return fail(ctx, CGP_E_ARG, "T too long for the 32-bit step counter");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
 
     SimIO io;
     io.H = init->H; io.H_stride = init->H_stride;
@@ -87,7 +88,8 @@ int cgp_add_noise(cgp_ctx* ctx, const double* clean, int64_t clean_stride, const
     if (!clean || !Xi || !ys) return fail(ctx, CGP_E_ARG, "NULL pointer");
     if (clean_stride != 0 && clean_stride < T) return fail(ctx, CGP_E_ARG, "clean_stride < T");
     if ((uint64_t)T > 0x1FFFFFFFEull) return fail(ctx, CGP_E_ARG, "T too long for the 32-bit step counter");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t total = B * ((T + 1) / 2), blocks = (total + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
     hipLaunchKernelGGL(add_noise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, clean, clean_stride, Xi, Xi_stride, seed, trial0, B, T, ys);
@@ -99,7 +101,8 @@ int cgp_debug_philox(cgp_ctx* ctx, const uint32_t* ctr, const uint32_t* key, int
     if (n < 0) return fail(ctx, CGP_E_ARG, "negative n");
     if (n == 0) return CGP_OK;
     if (!ctr || !key || !out) return fail(ctx, CGP_E_ARG, "NULL pointer");
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(debug_philox_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, ctr, key, n, out);
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");

@@ -366,6 +366,9 @@ inline bool ekf4_mfma_x4_fits(const FilterIO& io) { return io.T * 512 <= kOobMax
 
 inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    // the kernels address a trial's covariance rows through a 32-bit byte offset into a 2 GiB buffer window: a record too
+    // long for it is refused HERE, next to the kernels that need it (the dispatcher routes such records to the DPP kernel)
+    if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
     // beyond one wave per SIMD the four MFMA blocks carry four trials (CGP_ONE_TRIAL_PER_WAVE keeps one, for tests)
     if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
     {

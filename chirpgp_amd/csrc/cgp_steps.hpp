@@ -139,6 +139,12 @@ template <int D, bool ST> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>
     }
 }
 
+template <int NH> struct HarmonicLCD;
+template <class DM> CGP_DEV bool sgp_collapsible(const SigmaSet& sg);
+template <bool CROSS, bool ST>
+CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
+                                       Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT);
+
 // Sigma-point prediction of a discrete model, filters_smoothers.py:88-121, plus (CROSS) the smoother's
 // D^T = (sum_i w_i chi_i f_i^T - mf mp^T)^T, filters_smoothers.py:525.
 template <class DM, bool WAVE, bool CROSS, bool ST = WAVE>

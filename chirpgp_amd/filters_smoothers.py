@@ -43,9 +43,7 @@ def _gamma_from_callable(b):
 def _gamma_from_matrix(b):
     if isinstance(b, M.Dispersion):
         return b.outer()
-    if E._is_torch(b):
-        return b @ b.transpose(-1, -2)
-    b = np.asarray(b, dtype=np.float64)
+    b = _np(b)                                      # a (d, dw) constant: formed on the host, no torch op on the path
     return b @ np.swapaxes(b, -1, -2)
 
 

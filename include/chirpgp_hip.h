@@ -152,6 +152,9 @@ typedef struct cgp_init {
 int         cgp_version(void);
 int         cgp_create(cgp_ctx** out, int device);
 void        cgp_destroy(cgp_ctx* ctx);
+/* Message of the CALLING THREAD's most recent failed call on `ctx` ("" if none): kept per thread, so host threads that
+ * share a context do not race; valid until that thread's next failing call.  Every entry point runs on the context's
+ * device and restores the calling thread's current device before it returns. */
 const char* cgp_last_error(const cgp_ctx* ctx);
 
 /* Filters: reads ys, writes mfs / Pfs / nll (any of the three may be NULL = not wanted). */

@@ -1,0 +1,69 @@
+"""SURVEY.md 8f row 1 (batched NLL objective + MLE driver) against the ORACLE: the engine's objective, its gradient and
+the optimum it reaches are compared with the same quantities of oracle/c/port.c (tests/mle_oracle.py), from the same
+start, on seeded records -- the reference's drivers do exactly this optimisation before every filter / smoother run
+(demos/ekfs_mle.py:39-51, demos/ghfs_mle.py:56-60, demos/cd_ghfs_mle.py:47-50)."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from tests import mle_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+INIT = np.array([0.1, 0.1, 0.1, 1., 1., 7.])           # demos/ekfs_mle.py:39
+
+
+def _record(T, seed, dt=1e-3, Xi=0.1):
+    from chirpgp_amd.toymodels import gen_chirp, meow_freq, constant_mag
+    ts = np.linspace(dt, dt * T, T)
+    _, phase = meow_freq(offset=8.)
+    return gen_chirp(ts, constant_mag(1.), phase) + np.sqrt(Xi) * np.random.default_rng(seed).standard_normal(T)
+
+
+CASES = [pytest.param('ekf', 3141, 555, id='ekf_T3141'), pytest.param('sgp_filter', 1500, 556, id='sgp_filter_T1500'),
+         pytest.param('cd_sgp_filter', 600, 556, id='cd_sgp_filter_T600'), pytest.param('cd_ekf', 1000, 556, id='cd_ekf_T1000')]
+
+
+@pytest.mark.parametrize('method,T,seed', CASES)
+def test_objective_and_gradient_against_the_oracle(method, T, seed):
+    """NLL to 1e-9 relative, gradient to 1e-4 relative of its norm-scale, at the start point and at a second point."""
+    from chirpgp_amd import mle, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    sg = SigmaPoints.gauss_hermite(4, 3)
+    ys = _record(T, seed)
+    fun = mle.make_objective(method, pm.build_chirp_model, ys, 0.1, 1e-3, sgps=sg)
+    for theta in (mo.g_inv(INIT), mo.g_inv(INIT * np.array([1.3, 2.0, 0.7, 1.5, 3.0, 1.2]))):
+        f, grad = fun(theta)
+        f_o, grad_o = mo.value_and_grad(method, pm.build_chirp_model, theta, ys, 0.1, 1e-3, sgps=sg)
+        npt.assert_allclose(f, f_o, rtol=1e-9)
+        npt.assert_allclose(grad, grad_o, rtol=1e-4, atol=1e-4 * np.abs(grad_o).max())
+
+
+@pytest.mark.parametrize('method,T,seed', CASES)
+def test_fit_reaches_the_oracle_optimum(method, T, seed):
+    """chirpgp_amd.mle.fit against SciPy L-BFGS-B on the port objective, same start: NLL within 1e-6 relative; parameters
+    within 1e-3 relative (absolute 1e-4 for `b`, which the likelihood of these records drives to zero -- a flat
+    direction in the unconstrained parametrisation)."""
+    from chirpgp_amd import mle, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    sg = SigmaPoints.gauss_hermite(4, 3)
+    ys = _record(T, seed)
+    opt, res = mle.fit(method, pm.build_chirp_model, INIT, ys, 0.1, 1e-3, sgps=sg, maxiter=300)
+    opt_o, res_o = mo.fit(method, pm.build_chirp_model, INIT, ys, 0.1, 1e-3, sgps=sg)
+    assert res.fun < mo.nll(method, pm.build_chirp_model, mo.g_inv(INIT), ys, 0.1, 1e-3, sg)[0] - 1.0
+    npt.assert_allclose(res.fun, res_o.fun, rtol=1e-6)
+    npt.assert_allclose(opt, opt_o, rtol=1e-3, atol=1e-4)
+    # and the oracle agrees that the engine's optimum is one: its own NLL there equals the engine's
+    npt.assert_allclose(mo.nll(method, pm.build_chirp_model, pm.g_inv(opt), ys, 0.1, 1e-3, sg)[0], res.fun, rtol=1e-9)
+
+
+def test_lockstep_fit_many_reaches_the_oracle_optima():
+    """mle.fit_many (all records in lock step) against the oracle-side L-BFGS-B, record by record."""
+    from chirpgp_amd import mle, models as pm
+    T, R = 1200, 3
+    recs = np.stack([_record(T, 700 + r) for r in range(R)])
+    many, info = mle.fit_many('ekf', pm.build_chirp_model, INIT, recs, 0.1, 1e-3, maxiter=200)
+    for r in range(R):
+        _, res_o = mo.fit('ekf', pm.build_chirp_model, INIT, recs[r], 0.1, 1e-3)
+        assert info['fun'][r] <= res_o.fun + 1e-4 * abs(res_o.fun), (r, info['fun'][r], res_o.fun)
+        npt.assert_allclose(mo.nll('ekf', pm.build_chirp_model, pm.g_inv(many[r]), recs[r], 0.1, 1e-3)[0], info['fun'][r], rtol=1e-9)

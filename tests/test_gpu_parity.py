@@ -322,7 +322,7 @@ def test_mle_through_the_filter():
     assert rmse(freq(ts), est) < 3.0, rmse(freq(ts), est)
 
 
-@pytest.mark.parametrize('d', [1, 2, 5, 6, 8])
+@pytest.mark.parametrize('d', [1, 2, 3, 4, 5, 6, 7, 8])
 def test_linear_models_all_dims(d):
     """kf / rts / sgp / cd_* on random stable linear models of every compiled dimension, against the C port."""
     from chirpgp_amd import models as pm
@@ -397,8 +397,7 @@ def test_c_abi_argument_errors():
     assert lib.cgp_filter(ctx, E.F_EKF, C.byref(bad), None, *args) == -1
     lin9 = E.CgpModel(E.M_LINEAR, 9, 0, 162, params.data_ptr(), 0, None, 0)
     assert lib.cgp_filter(ctx, E.F_EKF, C.byref(lin9), None, *args) == -2                # not compiled in
-    lin7 = E.CgpModel(E.M_LINEAR, 7, 0, 98, params.data_ptr(), 0, None, 0)
-    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(lin7), None, *args) == -2
+    assert b'dimension' in lib.cgp_last_error(ctx)
     assert lib.cgp_filter(ctx, E.F_EKF, C.byref(model), None, C.byref(init), 0.1, buf.data_ptr(), 0, 4, None, None, None, 0, None) == 0   # B = 0
     from chirpgp_amd import filters_smoothers as fs
     with pytest.raises(NotImplementedError):
@@ -518,3 +517,107 @@ def test_nan_in_one_trial_of_the_chirp_ekf(kw):
         npt.assert_allclose(g[ok], w[ok], rtol=RTOL, atol=1e-12)
     assert np.isnan(got[0][1, 333:]).all() and not np.isnan(got[0][1, :333]).any()
     assert not np.isnan(got[0][[0, 2, 3, 5]]).any()
+
+
+# ------------------------------------------------------------------ BASELINE config C1
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
+                                pytest.param(THREAD, id='lane_per_trial'), pytest.param({}, id='default_shape')])
+def test_config_c1_linear_kf_rts_on_the_toy_chirp(kw):
+    """BASELINE configs[0]: linear KF + RTS, d = 4, T = 1000, batch = 1 on the toy chirp -- the chirp LCD model with its
+    frequency frozen at the initial value (filters_smoothers.py:145-219; F from models.py:296-301, Sigma from :302-308),
+    against the NumPy oracle's kf / rts at 1e-9 in every launch shape, and against the C port."""
+    import bench
+    from oracle import np_filters as nf
+    from oracle import port
+    fs = _fs()
+    params, dt, T = [0.1, 0.1, 0.1, 1., 1., 7.], 1e-3, 1000
+    F, Sigma = bench.frozen_frequency_linear_model(params, dt)
+    c = cs.chirp_case(T=T, seed=71, params=tuple(params), dt=dt)
+    # the frozen-frequency F is the EKF's mean map at the initial state: F m0 == cond mean(m0)
+    npt.assert_allclose(F @ c.m0, c.o_disc(c.m0, dt)[0], rtol=1e-14, atol=1e-15)
+    npt.assert_allclose(Sigma, c.o_disc(c.m0, dt)[1], rtol=1e-14, atol=0)
+    want_f = nf.kf(F, Sigma, c.H, c.Xi, c.m0, c.P0, c.ys)
+    want_s = nf.rts(F, Sigma, want_f[0], want_f[1])
+    got_f = fs.kf(F, Sigma, c.H, c.Xi, c.m0, c.P0, c.ys, **kw)
+    got_s = fs.rts(F, Sigma, got_f[0], got_f[1], **kw)
+    assert got_f[0].shape == (T, 4) and got_f[1].shape == (T, 4, 4) and got_f[2].shape == (T,) and got_s[1].shape == (T, 4, 4)
+    worst = bk.compare({'kf': got_f, 'rts': got_s}, {'kf': want_f, 'rts': want_s}, 1e-9, 'C1')
+    print({k: f'{v:.1e}' for k, v in worst.items()})
+    npt.assert_array_equal(got_s[0][-1], got_f[0][-1])
+    npt.assert_array_equal(got_s[1][-1], got_f[1][-1])
+    # smoother on the oracle's filtering results (identical inputs), and the second checker
+    on_oracle = fs.rts(F, Sigma, want_f[0], want_f[1], **kw)
+    bk.compare({'rts': on_oracle}, {'rts': want_s}, 1e-9, 'C1/rts_on_oracle_inputs')
+    from chirpgp_amd import models as pm
+    pf = port.filter(port.F_EKF, pm.linear_cond_m_cov(F, Sigma), None, c.H, c.Xi, c.m0, c.P0, dt, c.ys)
+    bk.compare({'kf': got_f}, {'kf': pf}, 1e-9, 'C1/port')
+
+
+def test_last_error_is_per_thread():
+    """Host threads sharing one context: each sees the message of ITS last failed call (include/chirpgp_hip.h)."""
+    import ctypes as C
+    import threading
+    import torch
+    from chirpgp_amd import _engine as E
+    lib, ctx = E.load_library(), E.context()
+    params = torch.zeros(200, dtype=torch.float64, device='cuda')
+    buf = torch.zeros(64, dtype=torch.float64, device='cuda')
+    init = E.CgpInit(buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0)
+    args = (C.byref(init), 0.1, buf.data_ptr(), 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
+    lcd = E.CgpModel(E.M_HARMONIC_LCD, 4, 1, 5, params.data_ptr(), 0, None, 0)
+    lin9 = E.CgpModel(E.M_LINEAR, 9, 0, 162, params.data_ptr(), 0, None, 0)
+    seen, barrier = {}, threading.Barrier(2)
+
+    def worker(name, method, model, needle):
+        ok = True
+        for _ in range(200):
+            rc = lib.cgp_filter(ctx, method, C.byref(model), None, *args)
+            barrier.wait()
+            msg = lib.cgp_last_error(ctx)
+            ok = ok and rc < 0 and needle in msg
+            barrier.wait()
+        seen[name] = ok
+    t1 = threading.Thread(target=worker, args=('a', E.F_CD_EKF, lcd, b'SDE model'))
+    t2 = threading.Thread(target=worker, args=('b', E.F_EKF, lin9, b'dimension'))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert seen == {'a': True, 'b': True}
+    assert torch.cuda.current_device() == 0
+
+
+@pytest.mark.parametrize('kw', [pytest.param(THREAD, id='lane_per_trial'), pytest.param(WAVE, id='wave_per_trial')])
+def test_wide_sigma_fans_take_the_full_sincos_fallback(kw):
+    """The lane-per-trial and time-parallel sigma-point paths anchor the rotation at the mean and rotate each group of
+    points by the small angle d = dt (w - w0), falling back to a full sincos where |d| > 1/16 (cgp_models.hpp).  A batch
+    that mixes narrow fans with wide ones (large P0[2][2], freq_scale 1e3 as in the reference's real_applications) makes
+    some lanes take the fallback and others not; one trial carries a NaN measurement."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    B, T, dt = 6, 400, 1e-3
+    rng = np.random.default_rng(77)
+    base = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
+    for nh, sg, fscale in ((1, SigmaPoints.gauss_hermite(4, 3), 1.0), (1, SigmaPoints.cubature(4), 1.0), (2, SigmaPoints.cubature(6), 1e3)):
+        params = base * rng.uniform(0.9, 1.1, size=(B, 6))
+        if fscale == 1.0:
+            drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+        else:
+            params[:, 5] = pm.g_inv(np.array([0.004, 0.006, 0.008, 0.01, 0.012, 0.02]))     # kHz-scale frequencies
+            drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, nh, fscale)
+        P0 = np.array(P0)
+        wide = np.array([1., 400., 1., 2500., 1., 30.])                     # P0[2][2] scale per trial: narrow and wide fans
+        if fscale == 1.0:
+            P0[:, -2, -2] *= wide
+        ys = np.stack([cs.chirp_measurements(T, 900 + i, dt=dt, num_harmonics=0 if nh == 1 else nh)[2] for i in range(B)])
+        ys[3, 250] = np.nan
+        # the fans really are wide: dt * 2 pi fs * (g(m + 3 sd) - g(m)) beyond 1/16 for some trials, inside for others
+        sd = np.sqrt(P0[:, -2, -2])
+        spread = dt * 2 * np.pi * fscale * (pm.g(m0[:, -2] + np.sqrt(3.) * sd) - pm.g(m0[:, -2]))
+        assert (spread > 0.0625).any() and (spread < 0.0625).any(), spread
+        want_f = port.filter(port.F_SGP, disc, sg, H, 0.1, m0, P0, dt, ys)
+        want_s = port.smoother(port.S_SGP, disc, sg, dt, want_f[0], want_f[1])
+        got_f = fs.sgp_filter(disc, sg, H, 0.1, m0, P0, dt, ys, **kw)
+        got_s = fs.sgp_smoother(disc, sg, want_f[0], want_f[1], dt, **kw)      # on the oracle's filtering results
+        for g_, w_, n in zip(got_f + got_s, want_f + want_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
+            cs.assert_close(g_, w_, RTOL, f'wide fan nh={nh} fs={fscale}: {n}')
+        assert np.isnan(got_f[0][3, 250:]).all() and not np.isnan(got_f[0][[0, 1, 2, 4, 5]]).any()

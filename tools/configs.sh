@@ -21,10 +21,7 @@ for l in open('gpurun_out/configs.jsonl'):
     print(f"{d['value']:.3e} steps/s  filter {k['filter_ms']:.2f} ms ({k['filter_GBs']:.0f} GB/s)  smoother {k['smoother_ms']:.2f} ms ({k['smoother_GBs']:.0f} GB/s)")
 # C1: linear KF + RTS, d = 4, T = 1000, B = 1 (frozen-frequency chirp LCD)
 wl = bench.make_workload(1, 1000)
-disc = wl['disc']
-F = np.stack([disc(np.eye(4)[j] * 0 + np.array([0, 0, 7., 0]) + np.eye(4)[j] * (0 if j == 2 else 1), 1e-3)[0] - disc(np.array([0, 0, 7., 0]), 1e-3)[0] for j in range(4)], axis=1)
-F[:, 2] = disc(np.array([0, 0, 8., 0]), 1e-3)[0] - disc(np.array([0, 0, 7., 0]), 1e-3)[0]
-Sigma = disc(np.array([0, 0, 7., 0]), 1e-3)[1]
+F, Sigma = bench.frozen_frequency_linear_model([0.1, 0.1, 0.1, 1., 1., 7.], 1e-3)
 ys = torch.from_numpy(wl['ys'][0]).cuda()
 for _ in range(3):
     r = fs.kf(F, Sigma, wl['H'], wl['Xi'], wl['m0'], wl['P0'], ys); s = fs.rts(F, Sigma, r[0], r[1])
