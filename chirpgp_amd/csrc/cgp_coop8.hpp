@@ -1,0 +1,251 @@
+// cgp_coop8.hpp -- lane-cooperative kernels for the harmonic chirp models of state dimension 6 and 8 (BASELINE config C5:
+// three harmonics, d = 8, cubature rule; demos/ghfs_harmonics_mle.py:25-27).
+//
+// TILE LAYOUT.  A d x d matrix (d <= 8, padded to 8 x 8 with zeros) lives one entry per lane as 2 x 2 blocks of 4 x 4:
+//
+//     lane = 16 r + 4 b + q,   b = 2 I + J     holds   X[4 I + r][4 J + q]
+//
+// i.e. every 16-lane DPP row r carries row r of all four blocks, a DPP bank (4 lanes) is one block row, and the four
+// blocks are exactly the four independent products of v_mfma_f64_4x4x4_4b_f64, which computes per block
+//     out[r][q] = C[r][q] + sum_k A[k][r] B[k][q]        ("A^T B" in this register indexing; tools/ubench/dpp_layout.hip)
+// Blocks move inside a DPP row with row rotations (b <- b - 1: row_ror:4, b <- b ^ 2: row_ror:8) and bank masks.  With
+// that, a matrix-vector product of the 8 x 8 covariance is ONE matrix instruction plus one cross-block add, the rank-one
+// Kalman update is one FMA per lane, and a step's d^2 covariance entries leave in one coalesced 512-byte store.
+//
+// sgp8_coop_kernel: sgp_filter (filters_smoothers.py:446-490) for sigma-point sets the host has flagged
+// CGP_SIGMA_STANDARD with at most 16 groups (every cubature rule up to d = 8: 2 (d - 1) + 1 groups), in the collapsed
+// form of cgp_steps.hpp:sgp4_prediction_collapsed generalised to n harmonics:
+//   * the last two state components are linear, f_lin = M chi_lin, and the sigma points of a group differ in the last
+//     coordinate only, so each GROUP is evaluated once, at weight W_g, with displacement d = L xi restricted to
+//     xi_0..d-2 (L = chol(Pf), lower);
+//   * the rows of the "moment matrix" G are g_i = f_i(chi) for the rotating components and e = M (d_v, d_v+1) for the
+//     linear pair (the propagated displacement); then with sum W = 1, sum W xi = 0, sum W xi xi^T = I
+//         mp  = (sum_p W g_i ; M m_lin)
+//         Pp  = sum_p W G G^T - mp_rot mp_rot^T  +  L[d-1][d-1]^2 M[:,1] M[:,1]^T (lin-lin block)  +  Sigma
+//     -- an exact regrouping of filters_smoothers.py:88-121.  The sums over the points ARE small matrix products
+//     (G W G^T, 8 x 16 x 8): point p = 4 b + r is evaluated by the four lanes q of (r, b), each keeps the rows 4 X + q of
+//     G, and tile (X, Y) of the product is one 4x4x4 matrix instruction per block of four points plus a cross-block
+//     all-reduce (two DPP adds);
+//   * chol(Pf) is needed by every point, so it is computed redundantly by all lanes from an LDS gather of the
+//     distributed covariance -- as L D L^T, which keeps square roots off the pivot-to-pivot dependency chain (the
+//     reciprocal of a pivot is 3 dependent instructions, a square root 7); a non-positive pivot poisons the step with
+//     NaN like the reference's Cholesky does.
+#pragma once
+#include "cgp_coop4.hpp"
+
+namespace cgp {
+
+CGP_DEV double mfma4x4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <int CTRL, int BANKS> CGP_DEV double dpp_banks_f64(double old, double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xF, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xF, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+// value held by block b ^ 2 (same r, q)
+CGP_DEV double blk_xor2(double x) { return dpp_f64<kRowRor8>(x); }
+// value held by block b ^ 1: odd blocks read b - 1 (row_ror:4), even blocks read b + 1 (row_ror:12)
+CGP_DEV double blk_xor1(double x) { return dpp_banks_f64<kRowRor12, 0x5>(dpp_banks_f64<kRowRor4, 0xA>(x, x), x); }
+// blocks (0,1) and (1,0) exchanged: the block-transposed arrangement of a symmetric matrix in tile layout
+CGP_DEV double blk_swap12(double x) { return dpp_banks_f64<kRowRor4, 0x4>(dpp_banks_f64<kRowRor12, 0x2>(x, x), x); }
+// sum over the four blocks, result in all of them
+CGP_DEV double blk_allreduce(double x) {
+    x += blk_xor2(x);
+    return x + dpp_f64<kRowRor4>(x);
+}
+
+// sqrt(s) by v_rsq_f64, one coupled Newton (Goldschmidt) step and one residual correction: 7 instructions, ~1e-16.
+CGP_DEV double sqrt_fast(double s) {
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y, h = 0.5 * y;
+    const double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    return fma(fma(-g, g, s), h, g);
+}
+
+// P = L D L^T with unit lower L (strict lower triangle in l) and pivots dv.  Right-looking, fully unrolled; the chain
+// from pivot to pivot is reciprocal (3) + scale (1) + update (1).  bad = some pivot <= 0 or NaN.
+template <int D> CGP_DEV void ldl_lower(const Sym<D>& P, Sym<D>& l, double (&dv)[D], bool& bad) {
+    Sym<D> a = P;
+    bad = false;
+    CGP_UNROLL for (int j = 0; j < D; j++) {
+        const double dj = a(j, j);
+        dv[j] = dj;
+        bad = bad || !(dj > 0.0);
+        if (j < D - 1) {
+            const double inv = rcp_nr1(dj);
+            double c[D];
+            CGP_UNROLL for (int i = j + 1; i < D; i++) { c[i] = a(i, j); l(i, j) = c[i] * inv; }
+            CGP_UNROLL for (int i = j + 1; i < D; i++)
+                CGP_UNROLL for (int k = j + 1; k <= i; k++) a(i, k) = fma(-l(i, j), c[k], a(i, k));
+        }
+    }
+}
+
+template <int NH>
+__global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma) {
+    constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
+    static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
+    __shared__ __attribute__((aligned(16))) double pbuf[64 + 8];       // the covariance row-major (pitch 8) and the mean
+    __shared__ double2 park[64];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int I = b >> 1, J = b & 1;
+    const int i = 4 * I + r, j = 4 * J + q;                              // this lane's covariance entry
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicLCD<NH> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    model.wide = true;
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, D);
+
+    // ---- the group this lane evaluates: p = 4 b + r (the four lanes q share it); xi_0..D-2 of its first member, total weight
+    double xi[D - 1], W = 0.0;
+    CGP_UNROLL for (int c = 0; c < D - 1; c++) xi[c] = 0.0;
+    {
+        const int p = 4 * b + r;
+        if (p < sg.groups()) {
+            const int p0 = sg.template begin<true>(p), p1 = sg.template end<true>(p);
+            CGP_UNROLL for (int c = 0; c < D - 1; c++) xi[c] = sg.template coord<true>(p0 * D + c);
+            for (int k = p0; k < p1; k++) W += sg.template weight<true>(k);
+        }
+    }
+
+    // ---- per-lane constants
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double HR = (i < D) ? Hp[i] : 0.0;                             // H[4 I + r]
+    const double HC = (4 * J + r < D) ? Hp[4 * J + r] : 0.0;             // H[4 J + r]
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    const double XiC = (I == 0) ? Xi : 0.0;                              // added once in the cross-block sum of S
+    double Sig = 0.0;                                                    // Sigma[i][j] (models.py:370-386)
+    if (i == j && i < NL) Sig = model.q;
+    else if (i == V && j == V) Sig = model.MS[0];
+    else if ((i == V + 1 && j == V) || (i == V && j == V + 1)) Sig = model.MS[1];
+    else if (i == V + 1 && j == V + 1) Sig = model.MS[2];
+    const bool lin_i = (i == V || i == V + 1), lin_j = (j == V || j == V + 1);
+    const double K1 = (lin_i && lin_j) ? model.M[2 * (i - V) + 1] * model.M[2 * (j - V) + 1] : 0.0;
+    const double Ma = lin_i ? model.M[2 * (i - V)] : 0.0, Mb = lin_i ? model.M[2 * (i - V) + 1] : 0.0;
+    const bool entry = i < D && j < D;
+    const bool mean_lane = (J == 0 && q == 0 && i < D);
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
+    double mrow = (i < D) ? m0p[i] : 0.0;                                // mean in row form: m[4 I + r]
+    double P = entry ? ((i >= j) ? P0p[i * D + j] : P0p[j * D + i]) : 0.0;
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
+    double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+    const double ONE = 1.0;
+
+    double cum = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const int64_t t = t0 + slot;
+            const double y = readlane_f64(ychunk, slot);
+            // ---- distributed (Pf, mf) -> every lane: through LDS, read back as broadcasts
+            pbuf[i * 8 + j] = P;
+            if (mean_lane) pbuf[64 + i] = mrow;
+            wave_lds_fence();
+            Sym<D> Pr; Vec<D> m;
+            CGP_UNROLL for (int a = 0; a < D; a++) {
+                CGP_UNROLL for (int c = 0; c <= a; c += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(pbuf + a * 8 + c);
+                    Pr(a, c) = v.x;
+                    if (c + 1 <= a) Pr(a, c + 1) = v.y;
+                }
+            }
+            CGP_UNROLL for (int a = 0; a < D; a += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(pbuf + 64 + a);
+                m.v[a] = v.x; m.v[a + 1] = v.y;
+            }
+            wave_lds_fence();
+            // ---- chol(Pf) = L sqrt(D'), replicated
+            Sym<D> l; double dv[D]; bool bad;
+            ldl_lower<D>(Pr, l, dv, bad);
+            const double poison = bad ? __builtin_nan("") : 0.0;
+            // ---- this lane's point: displacement d = L xi (xi_0..D-2), rotating pairs, propagated linear pair
+            double xs[D - 1];
+            CGP_UNROLL for (int c = 0; c < D - 1; c++) xs[c] = fma(xi[c], sqrt_fast(dv[c]), poison);
+            double dd[D];
+            CGP_UNROLL for (int a = 0; a < D; a++) {
+                double s = (a <= D - 2) ? xs[a] : 0.0;                   // unit diagonal; xi_{D-1} does not take part
+                CGP_UNROLL for (int c = 0; c < (a <= D - 2 ? a : D - 1); c++) s = fma(l(a, c), xs[c], s);
+                dd[a] = s;
+            }
+            typename HarmonicLCD<NH>::Pre pre;
+            model.precompute(m.v[V] + dd[V], pre);                      // rho cos / sin of k theta(chi_v), k = 1..NH
+            double gg[NL];
+            CGP_UNROLL for (int k = 0; k < NH; k++) {
+                const double h0 = m.v[2 * k] + dd[2 * k], h1 = m.v[2 * k + 1] + dd[2 * k + 1];
+                gg[2 * k] = pre.c[k] * h0 - pre.s[k] * h1;
+                gg[2 * k + 1] = pre.s[k] * h0 + pre.c[k] * h1;
+            }
+            const double e0 = fma(model.M[0], dd[V], model.M[1] * dd[V + 1]);
+            const double e1 = fma(model.M[2], dd[V], model.M[3] * dd[V + 1]);
+            // rows 4 X + q of G kept by this lane
+            const double A0 = (q == 0) ? gg[0] : (q == 1) ? gg[1] : (q == 2) ? gg[2] : gg[3];
+            double A1;
+            if constexpr (NH == 3) A1 = (q == 0) ? gg[4] : (q == 1) ? gg[5] : (q == 2) ? e0 : e1;
+            else A1 = (q == 0) ? e0 : (q == 1) ? e1 : 0.0;
+            const double B0 = W * A0, B1 = W * A1;
+            // ---- G W G^T by tiles, row sums in row and column form
+            const double T00 = blk_allreduce(mfma4x4(A0, B0, 0.0)), T01 = blk_allreduce(mfma4x4(A0, B1, 0.0));
+            const double T10 = blk_allreduce(mfma4x4(A1, B0, 0.0)), T11 = blk_allreduce(mfma4x4(A1, B1, 0.0));
+            const double R0 = blk_allreduce(mfma4x4(A0, W, 0.0)), R1 = blk_allreduce(mfma4x4(A1, W, 0.0));        // sum W G[4 X + r]
+            const double C0 = blk_allreduce(mfma4x4(ONE, B0, 0.0)), C1 = blk_allreduce(mfma4x4(ONE, B1, 0.0));    // sum W G[4 Y + q]
+            const double Tt = (b == 0) ? T00 : (b == 1) ? T01 : (b == 2) ? T10 : T11;
+            const double S1r = I ? R1 : R0, S1c = J ? C1 : C0;
+            // ---- predicted moments in tile layout / row form
+            const double Pp = fma(-S1r, S1c, Tt) + fma(dv[D - 1], K1, Sig);
+            const double mp = S1r + (fma(Ma, m.v[V], Mb * m.v[V + 1]) + poison);
+            // ---- update (filters_smoothers.py:55-68)
+            double PHc = mfma4x4(HR, Pp, 0.0);                           // sum_k H[4 I + k] Pp[4 I + k][4 J + q]
+            PHc += blk_xor2(PHc);                                        // PH[4 J + q]
+            double PHr = mfma4x4(blk_swap12(Pp), HC, 0.0);               // sum_k Pp[4 I + r][4 J + k] H[4 J + k]
+            PHr += blk_xor1(PHr);                                        // PH[4 I + r]
+            double S = mfma4x4(HR, PHr, XiC);                            // sum_k H[4 I + k] PH[4 I + k]
+            S += blk_xor2(S);
+            double pred = mfma4x4(HR, mp, 0.0);
+            pred += blk_xor2(pred);
+            const double innov = y - pred;
+            const double rS = rcp_nr1(S);
+            P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
+            mrow = fma(PHr, rS * innov, mp);
+            park[slot] = make_double2(S, innov);
+            if (Pfs && entry) Pfs[t * (D * D) + i * D + j] = P;
+            if (mfs && mean_lane) mfs[t * D + i] = mrow;
+        }
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+// The collapsed quadrature of the kernel above needs the caller's CGP_SIGMA_STANDARD assertion, groups, and at most one
+// group per (DPP row, block) pair.
+inline bool coop8_sigma_ok(const ModelArgs& ma) {
+    return (ma.sg.flags & CGP_SIGMA_STANDARD) && ma.sg.group_start && ma.sg.n_groups >= 1 && ma.sg.n_groups <= 16;
+}
+
+template <int NH>
+inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL((sgp8_coop_kernel<NH>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace cgp

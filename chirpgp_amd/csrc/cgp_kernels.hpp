@@ -450,6 +450,9 @@ int dispatch_filter_mfma4(const FilterIO&, const ModelArgs&, hipStream_t);
 // the matrix-core EKF addresses a trial's outputs through 2 GiB buffer windows (cgp_mfma4.hpp)
 inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00ll; }
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
+// d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
+bool coop8_filter_sgp_ok(int n_harm, const ModelArgs&);
+int dispatch_filter_coop8_sgp(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop4_cdsgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_coop4_cdsgp(const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop4_cdekf(const FilterIO&, const ModelArgs&, hipStream_t);

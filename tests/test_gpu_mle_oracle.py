@@ -42,8 +42,8 @@ def test_objective_and_gradient_against_the_oracle(method, T, seed):
 @pytest.mark.parametrize('method,T,seed', CASES)
 def test_fit_reaches_the_oracle_optimum(method, T, seed):
     """chirpgp_amd.mle.fit against SciPy L-BFGS-B on the port objective, same start: NLL within 1e-6 relative; parameters
-    within 1e-3 relative (absolute 1e-4 for `b`, which the likelihood of these records drives to zero -- a flat
-    direction in the unconstrained parametrisation)."""
+    within 1e-3 relative -- except `b`, which the likelihood of these records drives to zero (1e-6 .. 1e-4: a flat direction
+    of the unconstrained parametrisation, where the optimisers stop at different points): absolute 1e-3 there."""
     from chirpgp_amd import mle, models as pm
     from chirpgp_amd.quadratures import SigmaPoints
     sg = SigmaPoints.gauss_hermite(4, 3)
@@ -52,7 +52,9 @@ def test_fit_reaches_the_oracle_optimum(method, T, seed):
     opt_o, res_o = mo.fit(method, pm.build_chirp_model, INIT, ys, 0.1, 1e-3, sgps=sg)
     assert res.fun < mo.nll(method, pm.build_chirp_model, mo.g_inv(INIT), ys, 0.1, 1e-3, sg)[0] - 1.0
     npt.assert_allclose(res.fun, res_o.fun, rtol=1e-6)
-    npt.assert_allclose(opt, opt_o, rtol=1e-3, atol=1e-4)
+    keep = np.array([0, 2, 3, 4, 5])
+    npt.assert_allclose(opt[keep], opt_o[keep], rtol=1e-3)
+    assert opt_o[1] < 1e-3 and abs(opt[1] - opt_o[1]) < 1e-3, (opt[1], opt_o[1])
     # and the oracle agrees that the engine's optimum is one: its own NLL there equals the engine's
     npt.assert_allclose(mo.nll(method, pm.build_chirp_model, pm.g_inv(opt), ys, 0.1, 1e-3, sg)[0], res.fun, rtol=1e-9)
 

@@ -606,8 +606,7 @@ def test_wide_sigma_fans_take_the_full_sincos_fallback(kw):
             drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, nh, fscale)
         P0 = np.array(P0)
         wide = np.array([1., 400., 1., 2500., 1., 30.])                     # P0[2][2] scale per trial: narrow and wide fans
-        if fscale == 1.0:
-            P0[:, -2, -2] *= wide
+        P0[:, -2, -2] *= wide if fscale == 1.0 else np.array([0.01, 1., 0.01, 1., 0.01, 1.])
         ys = np.stack([cs.chirp_measurements(T, 900 + i, dt=dt, num_harmonics=0 if nh == 1 else nh)[2] for i in range(B)])
         ys[3, 250] = np.nan
         # the fans really are wide: dt * 2 pi fs * (g(m + 3 sd) - g(m)) beyond 1/16 for some trials, inside for others
