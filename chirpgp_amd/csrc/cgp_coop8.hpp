@@ -248,4 +248,131 @@ inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
     return hip_rc(hipGetLastError());
 }
 
+// ====================================================================================================================
+// Discrete smoothers (rts / eks / sgp_smoother, filters_smoothers.py:187-219, 317-349, 493-531) for 5 <= d <= 8.
+//
+// The time-parallel smoother of cgp_kernels.hpp composes the affine maps of 64 steps with a six-round suffix scan in
+// which EVERY lane multiplies 8 x 8 matrices every round: 10 000 of its 25 000 wave-instructions per tile at d = 8, with
+// two maps live per lane (register spills).  Here the lanes still build the maps of their own steps in parallel -- that
+// part is 64 independent chains and wants one step per lane -- but the composition is replaced by what it stands for:
+// the 64 maps go to LDS, and the wavefront walks the tile backwards COOPERATIVELY, carrying (ms, Ps) in the tile layout
+// and applying one map per step on the matrix cores,
+//     W = Ps G^T,   Ps <- G W + C,   ms <- G ms + c        (G, c, C of cgp_steps.hpp: "TIME-PARALLEL SMOOTHER")
+// two 8 x 8 x 8 products = four v_mfma_f64_4x4x4 (the G operands come from LDS already arranged per block, the carry is
+// re-arranged between blocks with bank-masked DPP moves).  A step of the walk is a ~150-cycle dependent chain instead of a
+// share of 1400 multiply-adds per lane and scan round; the next map's operands are fetched while the current one is applied.
+constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | C (packed lower, 36) | c (8) | one zero; odd: conflict-free lane stride
+constexpr int kElemC = 64, kElemc = 100, kElemZero = 108;
+
+// block (I, J) <- block (K, I): the A operand "X[4 I + r][4 K + k]" of a symmetric X held in tile layout
+CGP_DEV double blk_rows_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0x8>(dpp_banks_f64<kRowRor4, 0x6>(x, x), x); }
+CGP_DEV double blk_rows_of_k1(double x) { return dpp_banks_f64<kRowRor12, 0x6>(dpp_banks_f64<kRowRor8, 0x1>(x, x), x); }
+// block (I, J) <- block (K, J): the B operand "W[4 K + k][4 J + q]"
+CGP_DEV double blk_cols_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0xC>(x, x); }
+CGP_DEV double blk_cols_of_k1(double x) { return dpp_banks_f64<kRowRor8, 0x3>(x, x); }
+
+struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Cv, cv; };
+
+template <class Elem>
+__global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {
+    constexpr int D = Elem::D;
+    static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
+    __shared__ double elems[32 * kElemDoubles];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int I = b >> 1, J = b & 1;
+    const int i = 4 * I + r, j = 4 * J + q;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    Elem elem;
+    elem.setup(ma, trial);
+    for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / C and the zero slot stay zero
+    if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * D;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
+    double* __restrict__ mss = io.mss + trial * T * D;
+    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+    const bool entry = i < D && j < D;
+    const bool mean_lane = (J == 0 && q == 0 && i < D);
+
+    // per-lane element offsets (doubles) of the operands of one map
+    const int oA = (4 * I + q) * 8 + r;              // G[4 I + q'][4 K + r'] at + 4 K
+    const int oB = (4 * J + q) * 8 + r;              // G[4 J + q'][4 K + r'] at + 4 K
+    const int oM = (4 * I + q) * 8 + 4 * J + r;      // G[4 I + q'][4 J + r']
+    const int oC = entry ? kElemC + Sym<8>::idx(i, j) : kElemZero;
+    const int oc = (i < D) ? kElemc + i : kElemZero;
+
+    // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
+    double Ps = entry ? ((i >= j) ? Pfs[(T - 1) * D * D + i * D + j] : Pfs[(T - 1) * D * D + j * D + i]) : 0.0;
+    double xc = (4 * J + r < D) ? mfs[(T - 1) * D + 4 * J + r] : 0.0;
+    if (entry) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
+    if (mean_lane) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+
+    for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+        const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
+        // ---- every lane: the affine map of its own step -> LDS
+        {
+            const int64_t step = base + lane;
+            Affine<D> e;
+            affine_identity<D>(e);
+            if (step >= 0) {
+                Vec<D> mf; Sym<D> Pf;
+                load_vec<D>(mfs + step * D, mf);
+                load_sym<D>(Pfs + step * D * D, Pf);
+                elem.element(mf, Pf, e);
+            }
+            // The maps go to LDS in two halves of 32 (27.9 KB: four workgroups -- one per SIMD -- fit a CU; all 64 at once
+            // would be 55.8 KB, two workgroups per CU, and a batch of 1000 trials would run in two rounds): lanes 32..63,
+            // the later steps, first; lanes 0..31 keep theirs in registers until the first half has been walked.
+            const int s_first = base < 0 ? (int)(-base) : 0;
+            CGP_UNROLL for (int half = 1; half >= 0; half--) {
+                if ((lane >> 5) == half) {
+                    double* mine = elems + (lane & 31) * kElemDoubles;
+                    CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c < D; c++) mine[a * 8 + c] = e.G.a[a][c];
+                    CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[kElemC + Sym<8>::idx(a, c)] = e.C(a, c);
+                    CGP_UNROLL for (int a = 0; a < D; a++) mine[kElemc + a] = e.c.v[a];
+                }
+                wave_lds_fence();
+                // ---- the wavefront walks the half from its last step to its first
+                const int s_hi = 32 * half + 31, s_lo = s_first > 32 * half ? s_first : 32 * half;
+                if (s_lo <= s_hi) {
+                    auto fetch = [&](int s, Elem8Operands& o) {
+                        const double* p = elems + (s & 31) * kElemDoubles;
+                        o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Cv = p[oC]; o.cv = p[oc];
+                    };
+                    Elem8Operands cur, nxt;
+                    fetch(s_hi, cur);
+                    for (int s = s_hi; s >= s_lo; s--) {
+                        nxt = cur;
+                        if (s > s_lo) fetch(s - 1, nxt);
+                        // W = Ps G^T
+                        const double W = mfma4x4(blk_rows_of_k1(Ps), cur.gB1, mfma4x4(blk_rows_of_k0(Ps), cur.gB0, 0.0));
+                        // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] ms[4 J + k] + c
+                        double ym = mfma4x4(cur.gM, xc, 0.0);
+                        ym = (ym + blk_xor1(ym)) + cur.cv;
+                        // Ps <- G W + C
+                        Ps = mfma4x4(cur.gA1, blk_cols_of_k1(W), mfma4x4(cur.gA0, blk_cols_of_k0(W), cur.Cv));
+                        xc = blk_swap12(ym);
+                        const int64_t step = base + s;
+                        if (entry) Pss[step * D * D + i * D + j] = Ps;
+                        if (mean_lane) mss[step * D + i] = ym;
+                        cur = nxt;
+                    }
+                }
+                wave_lds_fence();
+            }
+        }
+    }
+}
+
+template <class Elem>
+inline hipError_t launch_coop8_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
+    hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
+    return hipGetLastError();
+}
+
 }  // namespace cgp

@@ -10,4 +10,34 @@ int dispatch_filter_coop8_sgp(int n_harm, const FilterIO& io, const ModelArgs& m
     default: return CGP_E_UNSUPPORTED;
     }
 }
+// The cooperative smoother keeps 32 affine maps in 27.9 KB of static LDS; with the staged sigma-point set beside it a
+// workgroup must stay within 40 KB so that four of them (one per SIMD) share a CU's 160 KB (every cubature rule fits;
+// larger sets take the lane-scan kernel).
+bool coop8_smoother_ok(int d, const ModelArgs& ma) {
+    return d >= 5 && d <= 8 && sigma_lds_bytes(ma, d) + sizeof(double) * 32 * kElemDoubles + 64 <= 40 * 1024;
+}
+int dispatch_smoother_coop8_linear(int method, int d, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    if (method != CGP_S_EKS && method != CGP_S_SGP) return CGP_E_UNSUPPORTED;
+    const bool sg = method == CGP_S_SGP;
+    switch (d) {
+    case 5: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<LinearDisc<5>>>(io, ma, st) : launch_coop8_smoother<EksElement<LinearDisc<5>>>(io, ma, st));
+    case 6: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<LinearDisc<6>>>(io, ma, st) : launch_coop8_smoother<EksElement<LinearDisc<6>>>(io, ma, st));
+    case 7: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<LinearDisc<7>>>(io, ma, st) : launch_coop8_smoother<EksElement<LinearDisc<7>>>(io, ma, st));
+    case 8: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<LinearDisc<8>>>(io, ma, st) : launch_coop8_smoother<EksElement<LinearDisc<8>>>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+// the sigma-point elements of the harmonic models are compiled in their collapsed form only: other sets take the lane-scan kernel
+bool coop8_smoother_harm_ok(int method, const ModelArgs& ma) {
+    return method == CGP_S_EKS || (method == CGP_S_SGP && (ma.sg.flags & CGP_SIGMA_STANDARD) && ma.sg.group_start);
+}
+int dispatch_smoother_coop8_harm(int method, int n_harm, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    if (method != CGP_S_EKS && method != CGP_S_SGP) return CGP_E_UNSUPPORTED;
+    const bool sg = method == CGP_S_SGP;
+    switch (n_harm) {
+    case 2: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<HarmonicLCD<2>, true>>(io, ma, st) : launch_coop8_smoother<EksElement<HarmonicLCD<2>>>(io, ma, st));
+    case 3: return hip_rc(sg ? launch_coop8_smoother<SgpsElement<HarmonicLCD<3>, true>>(io, ma, st) : launch_coop8_smoother<EksElement<HarmonicLCD<3>>>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
 }  // namespace cgp

@@ -141,13 +141,18 @@ template <int D, bool ST> CGP_DEV void sigma_point(const Vec<D>& m, const Sym<D>
 
 template <int NH> struct HarmonicLCD;
 template <class DM> CGP_DEV bool sgp_collapsible(const SigmaSet& sg);
+template <int NH, bool CROSS, bool ST>
+CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const SigmaSet& sg, const Vec<2 * NH + 2>& mf, const Sym<2 * NH + 2>& Pf,
+                                       Vec<2 * NH + 2>& mp, Sym<2 * NH + 2>& Pp, Mat<2 * NH + 2>& DT);
 template <bool CROSS, bool ST>
 CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
                                        Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT);
 
 // Sigma-point prediction of a discrete model, filters_smoothers.py:88-121, plus (CROSS) the smoother's
 // D^T = (sum_i w_i chi_i f_i^T - mf mp^T)^T, filters_smoothers.py:525.
-template <class DM, bool WAVE, bool CROSS, bool ST = WAVE>
+// COLL (d >= 6 harmonic models, one lane doing the whole fan): the launch has checked on the host that the set may take the
+// collapsed quadrature, so the kernel contains that path ONLY (both in one kernel cost registers: spills at d = 8).
+template <class DM, bool WAVE, bool CROSS, bool ST = WAVE, bool COLL = false>
 CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, double* lds,
                             const Vec<DM::D>& mf, const Sym<DM::D>& Pf, Vec<DM::D>& mp, Sym<DM::D>& Pp, Mat<DM::D>& DT) {
     constexpr int D = DM::D;
@@ -159,6 +164,9 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
             sgp4_prediction_collapsed<CROSS, ST>(model, sg, mf, Pf, mp, Pp, DT);
             return;
         }
+    } else if constexpr (!WAVE && COLL && (std::is_same<DM, HarmonicLCD<2>>::value || std::is_same<DM, HarmonicLCD<3>>::value)) {
+        sgpn_prediction_collapsed<(DM::D - 2) / 2, CROSS, ST>(model, sg, mf, Pf, mp, Pp, DT);
+        return;
     }
     Sym<D> L; Vec<D> inv;
     cholesky<D>(Pf, L, inv);
@@ -276,7 +284,86 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
         }
     }
 }
-// Whether a launch may take the collapsed path: the caller's assertion, groups, and the d = 4 harmonic family.
+// The same regrouping for n harmonics (d = 2 n + 2; rotating components a < 2 n, linear pair v = 2 n, v + 1), one lane doing
+// all groups: with d = L xi restricted to xi_0..d-2 and g_a = f_a(m + d) of a group's representative,
+//     mp_a = sum W g_a,   Pp_ab = sum W g_a g_b - mp_a mp_b + q delta_ab,   Pp_{a, v+b} = sum_c M_bc (sum W g_a d_{v+c}),
+//     mp_lin = M m_lin,   Pp_lin,lin = M P_lin,lin M^T + Sigma_lin,
+//     D[i][a] = sum W d_i g_a   (cross covariance, smoother),   D[i][v+b] = sum_c M_bc P[i][v+c]
+// -- 15 evaluations and 39 (75 with the cross term) partial sums for the cubature rule in d = 8, instead of 16 and 45 (109).
+template <int NH, bool CROSS, bool ST>
+CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const SigmaSet& sg, const Vec<2 * NH + 2>& mf, const Sym<2 * NH + 2>& Pf,
+                                       Vec<2 * NH + 2>& mp, Sym<2 * NH + 2>& Pp, Mat<2 * NH + 2>& DT) {
+    constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pf, L, inv);                       // L[D-1][D-1] is never used: its square root is dead code
+    double sf[NL], sab[NL * (NL + 1) / 2], x[NL][2], cr[CROSS ? NL : 1][NL];
+    CGP_UNROLL for (int a = 0; a < NL; a++) { sf[a] = 0.0; x[a][0] = 0.0; x[a][1] = 0.0; }
+    CGP_UNROLL for (int a = 0; a < NL * (NL + 1) / 2; a++) sab[a] = 0.0;
+    if (CROSS) { CGP_UNROLL for (int a = 0; a < NL; a++) CGP_UNROLL for (int c = 0; c < NL; c++) cr[a][c] = 0.0; }
+    const int ng = sg.groups();
+    typename HarmonicLCD<NH>::Anchor anchor;
+    model.anchor(mf.v[V], anchor);
+    for (int g = 0; g < ng; g++) {
+        const int p0 = sg.template begin<ST>(g), p1 = sg.template end<ST>(g);
+        double W = 0.0;
+        for (int p = p0; p < p1; p++) W += sg.template weight<ST>(p);
+        double xi[D - 1], dd[D];
+        CGP_UNROLL for (int c = 0; c < D - 1; c++) xi[c] = sg.template coord<ST>(p0 * D + c);
+        CGP_UNROLL for (int a = 0; a < D; a++) {
+            double t = L(a, 0) * xi[0];
+            CGP_UNROLL for (int c = 1; c <= (a < D - 1 ? a : D - 2); c++) t = fma(L(a, c), xi[c], t);
+            dd[a] = t;
+        }
+        typename HarmonicLCD<NH>::Pre pre;
+        model.precompute(mf.v[V] + dd[V], anchor, pre);
+        double wg[NL], gg[NL];
+        CGP_UNROLL for (int k = 0; k < NH; k++) {
+            const double h0 = mf.v[2 * k] + dd[2 * k], h1 = mf.v[2 * k + 1] + dd[2 * k + 1];
+            gg[2 * k] = pre.c[k] * h0 - pre.s[k] * h1;
+            gg[2 * k + 1] = pre.s[k] * h0 + pre.c[k] * h1;
+        }
+        CGP_UNROLL for (int a = 0; a < NL; a++) {
+            wg[a] = W * gg[a];
+            sf[a] += wg[a];
+            CGP_UNROLL for (int c = 0; c <= a; c++) sab[a * (a + 1) / 2 + c] = fma(wg[a], gg[c], sab[a * (a + 1) / 2 + c]);
+            x[a][0] = fma(wg[a], dd[V], x[a][0]);
+            x[a][1] = fma(wg[a], dd[V + 1], x[a][1]);
+            if (CROSS) { CGP_UNROLL for (int c = 0; c < NL; c++) cr[c][a] = fma(wg[a], dd[c], cr[c][a]); }
+        }
+    }
+    const double poison = L(0, 0) - L(0, 0);          // 0, or NaN when the factorisation failed
+    const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
+    CGP_UNROLL for (int a = 0; a < NL; a++) mp.v[a] = sf[a];
+    mp.v[V] = fma(M0, mf.v[V], M1 * mf.v[V + 1]) + poison;
+    mp.v[V + 1] = fma(M2, mf.v[V], M3 * mf.v[V + 1]) + poison;
+    CGP_UNROLL for (int a = 0; a < NL; a++) {
+        CGP_UNROLL for (int c = 0; c <= a; c++) {
+            const double v = sab[a * (a + 1) / 2 + c] - sf[a] * sf[c];
+            Pp(a, c) = (a == c) ? v + model.q : v;
+        }
+        Pp(V, a) = fma(M0, x[a][0], M1 * x[a][1]);
+        Pp(V + 1, a) = fma(M2, x[a][0], M3 * x[a][1]);
+    }
+    const double t20 = fma(M0, Pf(V, V), M1 * Pf(V + 1, V)), t21 = fma(M0, Pf(V + 1, V), M1 * Pf(V + 1, V + 1));
+    const double t30 = fma(M2, Pf(V, V), M3 * Pf(V + 1, V)), t31 = fma(M2, Pf(V + 1, V), M3 * Pf(V + 1, V + 1));
+    Pp(V, V) = (fma(t20, M0, t21 * M1) + model.MS[0]) + poison;
+    Pp(V + 1, V) = (fma(t30, M0, t31 * M1) + model.MS[1]) + poison;
+    Pp(V + 1, V + 1) = (fma(t30, M2, t31 * M3) + model.MS[2]) + poison;
+    if (CROSS) {
+        // DT[j][i] = D[i][j]
+        CGP_UNROLL for (int a = 0; a < NL; a++) {
+            CGP_UNROLL for (int c = 0; c < NL; c++) DT.a[a][c] = cr[c][a];
+            DT.a[a][V] = x[a][0]; DT.a[a][V + 1] = x[a][1];
+        }
+        CGP_UNROLL for (int c = 0; c < D; c++) {
+            const double pv = Pf(c, V), pw = Pf(c, V + 1);          // Sym::operator() is symmetric in its arguments
+            DT.a[V][c] = fma(M0, pv, M1 * pw) + poison;
+            DT.a[V + 1][c] = fma(M2, pv, M3 * pw) + poison;
+        }
+    }
+}
+// Whether a launch may take the collapsed path: the caller's assertion, groups, and the d = 4 harmonic family (run-time
+// check inside the kernel; the d >= 6 kernels are compiled per path, see COLL above and sgp_collapsible_host).
 template <class DM> CGP_DEV bool sgp_collapsible(const SigmaSet& sg) {
     if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) return (sg.flags & 1u /* CGP_SIGMA_STANDARD */) && sg.group_start;
     else return false;
@@ -365,14 +452,14 @@ template <class DM, bool WAVE_> struct EkfPredict {
 };
 
 // sgp_filter (filters_smoothers.py:480-487)
-template <class DM, bool WAVE_> struct SgpPredict {
+template <class DM, bool WAVE_, bool COLL = false> struct SgpPredict {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = WAVE; }
     CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> unused;
-        sgp_prediction<DM, WAVE, false>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
+        sgp_prediction<DM, WAVE, false, WAVE, COLL>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
     }
 };
 
@@ -435,14 +522,14 @@ template <class DM, bool WAVE_> struct EksStep {
 };
 
 // sgp_smoother (filters_smoothers.py:520-528)
-template <class DM, bool WAVE_> struct SgpsStep {
+template <class DM, bool WAVE_, bool COLL = false> struct SgpsStep {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = WAVE; }
     CGP_DEV void step(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
-        sgp_prediction<DM, WAVE, true>(model, sg, lane, lds, mf, Pf, mp, Pp, DT);
+        sgp_prediction<DM, WAVE, true, WAVE, COLL>(model, sg, lane, lds, mf, Pf, mp, Pp, DT);
         smoother_gain<D>(DT, Pp, G);
         smoother_apply<D>(G, mf, Pf, mp, Pp, ms, Ps);
     }
@@ -703,14 +790,14 @@ template <class DM> struct EksElement {
         affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
     }
 };
-template <class DM> struct SgpsElement {
+template <class DM, bool COLL = false> struct SgpsElement {
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = true; }
     CGP_DEV void element(const Vec<D>& mf, const Sym<D>& Pf, Affine<D>& e) const {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT;
-        sgp_prediction<DM, false, true, true>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
+        sgp_prediction<DM, false, true, true, COLL>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
         affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
     }
 };

@@ -136,7 +136,8 @@ typedef struct cgp_init {
 #define CGP_WAVE_PER_TRIAL    0x2u   /* force one 64-lane wavefront per trial (small batches; default below a threshold)  */
 #define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
 #define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
-#define CGP_GENERIC_KERNEL    0x10u  /* filters: force the generic kernel where a lane-cooperative specialisation exists   */
+#define CGP_GENERIC_KERNEL    0x10u  /* force the generic kernel where a lane-cooperative specialisation exists (filters; d >= 5
+                                        time-parallel smoothers: the lane-scan kernel instead of the cooperative walk)      */
 #define CGP_LITERAL_SIGMA_SUM  0x40u  /* sigma-point methods: sum over every point even when the set is CGP_SIGMA_STANDARD     */
 #define CGP_DPP_KERNEL        0x80u  /* d = 4 EKF: the DPP cooperative kernel instead of the matrix-core (MFMA) one             */
 #define CGP_FOUR_TRIALS_PER_WAVE 0x200u /* d = 4 matrix-core EKF: four trials per wavefront whatever the batch (default above 1024) */

@@ -18,10 +18,11 @@ RTOL = 1e-5
 WAVE = dict(flags=0x2)
 THREAD = dict(flags=0x4)
 WAVE_SEQ = dict(flags=0x2 | 0x8 | 0x10)     # wave per trial, step-by-step smoother scan, generic (non-cooperative) filter kernels
+WAVE_GENERIC = dict(flags=0x2 | 0x10)       # wave per trial, generic filter kernels, lane-scan time-parallel smoothers (no tile-layout kernels)
 WAVE_LITERAL = dict(flags=0x2 | 0x40)       # cooperative kernels summing over every sigma point (no collapsed quadrature)
 WAVE_DPP = dict(flags=0x2 | 0x80)           # d = 4 EKF on the DPP cooperative kernel instead of the MFMA one
 WAVE_X4 = dict(flags=0x2 | 0x200)          # d = 4 matrix-core EKF with four trials per wavefront (default only above B = 1024)
-SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_X4, id='wave_four_trials'), pytest.param(WAVE_DPP, id='wave_dpp_ekf'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
+SHAPES = [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_X4, id='wave_four_trials'), pytest.param(WAVE_DPP, id='wave_dpp_ekf'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'), pytest.param(WAVE_GENERIC, id='wave_generic_kernels'),
           pytest.param(THREAD, id='lane_per_trial'), pytest.param(WAVE_LITERAL, id='wave_literal_sigma_sum')]
 
 
