@@ -88,6 +88,35 @@ CGP_DEV void coop4_update(const Coop4Meas& M, double Pp, double f0, double f1, d
     innov_out = innov;
 }
 
+// A trial's output array as a raw buffer: stores take a 32-bit byte offset per lane and the hardware drops the lanes
+// whose offset is past the end (and all of them if the output is not wanted: zero records).  "Which lanes write" thus
+// becomes data instead of control flow -- an exec-masked store costs a skip branch, and a branch in the middle of a
+// step splits the basic block the scheduler works on (cgp_fastmath.hpp).  kOobOffset marks a lane that never writes;
+// windows are limited to 2 GiB so that marker + a small immediate offset stays out of range.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;
+struct OobWindow {
+    __amdgpu_buffer_rsrc_t rsrc;
+    CGP_DEV void init(const double* base, int64_t bytes) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base ? (int)bytes : 0, 0x27000);
+    }
+    CGP_DEV double load(unsigned off) const {          // lanes past the end (and a missing array) read 0
+        const u32x2_t d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+        return __hiloint2double((int)d.y, (int)d.x);
+    }
+    CGP_DEV void store(double v, unsigned off) const {
+        u32x2_t d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)off, 0, 0);
+    }
+    CGP_DEV void store2(double a, double b, unsigned off) const {
+        u32x4_t d; d.x = (unsigned)__double2loint(a); d.y = (unsigned)__double2hiint(a);
+        d.z = (unsigned)__double2loint(b); d.w = (unsigned)__double2hiint(b);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)off, 0, 0);
+    }
+};
+constexpr int64_t kOobMaxBytes = 0x7FFFFF00;
+
 // NLL of up to 64 latched steps: every lane evaluates its increment, inclusive prefix sum across the wave, one
 // coalesced store; returns the new running total (wave-uniform).
 CGP_DEV double nll_flush_wave(double S_l, double innov_l, int lane, int nsteps, double cum, double* __restrict__ nll_chunk) {

@@ -253,15 +253,15 @@ inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
 //
 // The time-parallel smoother of cgp_kernels.hpp composes the affine maps of 64 steps with a six-round suffix scan in
 // which EVERY lane multiplies 8 x 8 matrices every round: 10 000 of its 25 000 wave-instructions per tile at d = 8, with
-// two maps live per lane (register spills).  Here the lanes still build the maps of their own steps in parallel -- that
-// part is 64 independent chains and wants one step per lane -- but the composition is replaced by what it stands for:
-// the 64 maps go to LDS, and the wavefront walks the tile backwards COOPERATIVELY, carrying (ms, Ps) in the tile layout
-// and applying one map per step on the matrix cores,
-//     W = Ps G^T,   Ps <- G W + C,   ms <- G ms + c        (G, c, C of cgp_steps.hpp: "TIME-PARALLEL SMOOTHER")
+// two maps live per lane (register spills).  Here the lanes still do the expensive, independent part of their own steps
+// in parallel -- prediction (model / sigma fan) at (mf, Pf), Cholesky of Pp, the gain G = (Pp^{-1} D^T)^T: 64 chains,
+// one per lane -- but nothing is composed: (G, mp, Pp) of the steps go to LDS and the wavefront walks the tile backwards
+// COOPERATIVELY, carrying (ms, Ps) in the tile layout and applying the reference's own recursion on the matrix cores,
+//     X = Ps' - Pp,   W = X G^T,   Ps = G W + Pf,      ms = G (ms' - mp) + mf          (filters_smoothers.py:83-84)
 // two 8 x 8 x 8 products = four v_mfma_f64_4x4x4 (the G operands come from LDS already arranged per block, the carry is
-// re-arranged between blocks with bank-masked DPP moves).  A step of the walk is a ~150-cycle dependent chain instead of a
-// share of 1400 multiply-adds per lane and scan round; the next map's operands are fetched while the current one is applied.
-constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | C (packed lower, 36) | c (8) | one zero; odd: conflict-free lane stride
+// re-arranged between blocks with bank-masked DPP moves; Pf and mf are read from the input arrays in the tile layout).
+// A step of the walk is a ~150-cycle dependent chain; the next step's operands are fetched while the current one is applied.
+constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | Pp (packed lower, 36) | mp (8) | one zero; odd: conflict-free lane stride
 constexpr int kElemC = 64, kElemc = 100, kElemZero = 108;
 
 // block (I, J) <- block (K, I): the A operand "X[4 I + r][4 K + k]" of a symmetric X held in tile layout
@@ -271,7 +271,7 @@ CGP_DEV double blk_rows_of_k1(double x) { return dpp_banks_f64<kRowRor12, 0x6>(d
 CGP_DEV double blk_cols_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0xC>(x, x); }
 CGP_DEV double blk_cols_of_k1(double x) { return dpp_banks_f64<kRowRor8, 0x3>(x, x); }
 
-struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Cv, cv; };
+struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc; };
 
 template <class Elem>
 __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
 
     Elem elem;
     elem.setup(ma, trial);
-    for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / C and the zero slot stay zero
+    for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / Pp and the zero slot stay zero
     if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
@@ -297,72 +297,96 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     const bool entry = i < D && j < D;
     const bool mean_lane = (J == 0 && q == 0 && i < D);
 
-    // per-lane element offsets (doubles) of the operands of one map
+    // per-lane offsets (doubles) of the operands of one step inside its LDS record, and inside the input rows
     const int oA = (4 * I + q) * 8 + r;              // G[4 I + q'][4 K + r'] at + 4 K
     const int oB = (4 * J + q) * 8 + r;              // G[4 J + q'][4 K + r'] at + 4 K
     const int oM = (4 * I + q) * 8 + 4 * J + r;      // G[4 I + q'][4 J + r']
-    const int oC = entry ? kElemC + Sym<8>::idx(i, j) : kElemZero;
-    const int oc = (i < D) ? kElemc + i : kElemZero;
+    const int oP = entry ? kElemC + Sym<8>::idx(i, j) : kElemZero;
+    const int om = (4 * J + r < D) ? kElemc + 4 * J + r : kElemZero;          // mp[4 J + r]
+    // The walk addresses the input and output rows through buffer windows with per-lane byte offsets: a lane that has
+    // nothing to read or write carries an out-of-range offset (reads 0 / is dropped), so no load or store sits behind an
+    // exec-mask branch and the compiler can count them: it waits for the prefetched loads only, not for the stores behind them.
+    const unsigned bP = entry ? 8u * (unsigned)((i >= j) ? i * D + j : j * D + i) : kOobOffset;      // lower triangle of Pf, like the other kernels
+    const unsigned bS = entry ? 8u * (unsigned)(i * D + j) : kOobOffset;
+    const unsigned bmr = (i < D) ? 8u * (unsigned)i : kOobOffset;                                    // mf[4 I + r]
+    const unsigned bms = mean_lane ? 8u * (unsigned)i : kOobOffset;
+    OobWindow wPf, wmf, wPs, wms;
+    wPf.init(Pfs, T * D * D * 8); wmf.init(mfs, T * D * 8); wPs.init(Pss, T * D * D * 8); wms.init(mss, T * D * 8);
 
     // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
-    double Ps = entry ? ((i >= j) ? Pfs[(T - 1) * D * D + i * D + j] : Pfs[(T - 1) * D * D + j * D + i]) : 0.0;
+    double Ps = entry ? Pfs[(T - 1) * D * D + ((i >= j) ? i * D + j : j * D + i)] : 0.0;
     double xc = (4 * J + r < D) ? mfs[(T - 1) * D + 4 * J + r] : 0.0;
     if (entry) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
     if (mean_lane) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
 
     for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
         const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
-        // ---- every lane: the affine map of its own step -> LDS
-        {
-            const int64_t step = base + lane;
-            Affine<D> e;
-            affine_identity<D>(e);
-            if (step >= 0) {
-                Vec<D> mf; Sym<D> Pf;
-                load_vec<D>(mfs + step * D, mf);
-                load_sym<D>(Pfs + step * D * D, Pf);
-                elem.element(mf, Pf, e);
+        // ---- every lane: prediction and gain of its own step
+        const int64_t mystep = base + lane;
+        Mat<D> G; Vec<D> mp; Sym<D> Pp;
+        if (mystep >= 0) {
+            Vec<D> mf; Sym<D> Pf;
+            load_vec<D>(mfs + mystep * D, mf);
+            load_sym<D>(Pfs + mystep * D * D, Pf);
+            elem.gain(mf, Pf, G, mp, Pp);
+        } else {
+            CGP_UNROLL for (int a = 0; a < D; a++) { mp.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < D; c++) G.a[a][c] = 0.0; }
+            CGP_UNROLL for (int a = 0; a < Sym<D>::N; a++) Pp.a[a] = 0.0;
+        }
+        // The records go to LDS in two halves of 32 (27.9 KB: four workgroups -- one per SIMD -- fit a CU; all 64 at once would
+        // be 55.8 KB, two workgroups per CU, and a batch of 1000 trials would run in two rounds): lanes 32..63, the later
+        // steps, first; lanes 0..31 keep theirs in registers until the first half has been walked.
+        CGP_UNROLL for (int half = 1; half >= 0; half--) {
+            if ((lane >> 5) == half) {
+                double* mine = elems + (lane & 31) * kElemDoubles;
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c < D; c++) mine[a * 8 + c] = G.a[a][c];
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[kElemC + Sym<8>::idx(a, c)] = Pp(a, c);
+                CGP_UNROLL for (int a = 0; a < D; a++) mine[kElemc + a] = mp.v[a];
             }
-            // The maps go to LDS in two halves of 32 (27.9 KB: four workgroups -- one per SIMD -- fit a CU; all 64 at once
-            // would be 55.8 KB, two workgroups per CU, and a batch of 1000 trials would run in two rounds): lanes 32..63,
-            // the later steps, first; lanes 0..31 keep theirs in registers until the first half has been walked.
-            const int s_first = base < 0 ? (int)(-base) : 0;
-            CGP_UNROLL for (int half = 1; half >= 0; half--) {
-                if ((lane >> 5) == half) {
-                    double* mine = elems + (lane & 31) * kElemDoubles;
-                    CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c < D; c++) mine[a * 8 + c] = e.G.a[a][c];
-                    CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[kElemC + Sym<8>::idx(a, c)] = e.C(a, c);
-                    CGP_UNROLL for (int a = 0; a < D; a++) mine[kElemc + a] = e.c.v[a];
+            wave_lds_fence();
+            // ---- the wavefront walks the half from its last step to its first, in four batches of eight steps.  The
+            // filtering rows (Pf, mf) of a batch are requested one batch ahead -- by then the lines a lane read for its own
+            // gain have long left L2, and a miss costs three walk steps -- the LDS operands one step ahead.  Steps before the
+            // start of the record (last tile) are walked too: their loads return 0 and their stores are dropped.
+            auto fetch = [&](int s, Elem8Operands& o) {
+                const double* p = elems + (s & 31) * kElemDoubles;
+                o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Ppv = p[oP]; o.mpc = p[om];
+            };
+            auto request = [&](int s_top, double (&pf)[8], double (&mf)[8]) {
+                CGP_UNROLL for (int u = 0; u < 8; u++) {
+                    const unsigned step = (unsigned)(base + (s_top - u));
+                    pf[u] = wPf.load(bP + step * (unsigned)(D * D * 8));
+                    mf[u] = wmf.load(bmr + step * (unsigned)(D * 8));
                 }
-                wave_lds_fence();
-                // ---- the wavefront walks the half from its last step to its first
-                const int s_hi = 32 * half + 31, s_lo = s_first > 32 * half ? s_first : 32 * half;
-                if (s_lo <= s_hi) {
-                    auto fetch = [&](int s, Elem8Operands& o) {
-                        const double* p = elems + (s & 31) * kElemDoubles;
-                        o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Cv = p[oC]; o.cv = p[oc];
-                    };
-                    Elem8Operands cur, nxt;
-                    fetch(s_hi, cur);
-                    for (int s = s_hi; s >= s_lo; s--) {
-                        nxt = cur;
-                        if (s > s_lo) fetch(s - 1, nxt);
-                        // W = Ps G^T
-                        const double W = mfma4x4(blk_rows_of_k1(Ps), cur.gB1, mfma4x4(blk_rows_of_k0(Ps), cur.gB0, 0.0));
-                        // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] ms[4 J + k] + c
-                        double ym = mfma4x4(cur.gM, xc, 0.0);
-                        ym = (ym + blk_xor1(ym)) + cur.cv;
-                        // Ps <- G W + C
-                        Ps = mfma4x4(cur.gA1, blk_cols_of_k1(W), mfma4x4(cur.gA0, blk_cols_of_k0(W), cur.Cv));
-                        xc = blk_swap12(ym);
-                        const int64_t step = base + s;
-                        if (entry) Pss[step * D * D + i * D + j] = Ps;
-                        if (mean_lane) mss[step * D + i] = ym;
-                        cur = nxt;
-                    }
+            };
+            double pf_cur[8], mf_cur[8], pf_nxt[8], mf_nxt[8];
+            request(32 * half + 31, pf_cur, mf_cur);
+            Elem8Operands cur, nxt;
+            fetch(32 * half + 31, cur);
+#pragma unroll 1
+            for (int batch = 0; batch < 4; batch++) {
+                const int s_top = 32 * half + 31 - 8 * batch;
+                if (batch < 3) request(s_top - 8, pf_nxt, mf_nxt);
+                CGP_UNROLL for (int u = 0; u < 8; u++) {
+                    const int s = s_top - u;
+                    fetch((s - 1) & 31, nxt);                                  // (the record fetched after the half's last step is not used)
+                    // W = (Ps' - Pp) G^T
+                    const double X = Ps - cur.Ppv;
+                    const double W = mfma4x4(blk_rows_of_k1(X), cur.gB1, mfma4x4(blk_rows_of_k0(X), cur.gB0, 0.0));
+                    // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] (ms' - mp)[4 J + k] + mf
+                    double ym = mfma4x4(cur.gM, xc - cur.mpc, 0.0);
+                    ym = (ym + blk_xor1(ym)) + mf_cur[u];
+                    // Ps = G W + Pf
+                    Ps = mfma4x4(cur.gA1, blk_cols_of_k1(W), mfma4x4(cur.gA0, blk_cols_of_k0(W), pf_cur[u]));
+                    xc = blk_swap12(ym);
+                    const unsigned step = (unsigned)(base + s);
+                    wPs.store(Ps, bS + step * (unsigned)(D * D * 8));
+                    wms.store(ym, bms + step * (unsigned)(D * 8));
+                    cur = nxt;
                 }
-                wave_lds_fence();
+                CGP_UNROLL for (int u = 0; u < 8; u++) { pf_cur[u] = pf_nxt[u]; mf_cur[u] = mf_nxt[u]; }
             }
+            wave_lds_fence();
         }
     }
 }
@@ -370,6 +394,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
 template <class Elem>
 inline hipError_t launch_coop8_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    if (io.T * Elem::D * Elem::D * 8 > kOobMaxBytes) return hipErrorInvalidValue;      // 2 GiB buffer windows (callers check coop8_smoother_ok)
     const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
     hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
     return hipGetLastError();

@@ -13,8 +13,8 @@ int dispatch_filter_coop8_sgp(int n_harm, const FilterIO& io, const ModelArgs& m
 // The cooperative smoother keeps 32 affine maps in 27.9 KB of static LDS; with the staged sigma-point set beside it a
 // workgroup must stay within 40 KB so that four of them (one per SIMD) share a CU's 160 KB (every cubature rule fits;
 // larger sets take the lane-scan kernel).
-bool coop8_smoother_ok(int d, const ModelArgs& ma) {
-    return d >= 5 && d <= 8 && sigma_lds_bytes(ma, d) + sizeof(double) * 32 * kElemDoubles + 64 <= 40 * 1024;
+bool coop8_smoother_ok(int d, int64_t T, const ModelArgs& ma) {
+    return d >= 5 && d <= 8 && T * d * d * 8 <= kOobMaxBytes && sigma_lds_bytes(ma, d) + sizeof(double) * 32 * kElemDoubles + 64 <= 40 * 1024;
 }
 int dispatch_smoother_coop8_linear(int method, int d, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
     if (method != CGP_S_EKS && method != CGP_S_SGP) return CGP_E_UNSUPPORTED;

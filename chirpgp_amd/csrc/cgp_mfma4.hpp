@@ -33,30 +33,6 @@
 
 namespace cgp {
 
-// A trial's output array as a raw buffer: stores take a 32-bit byte offset per lane and the hardware drops the lanes
-// whose offset is past the end (and all of them if the output is not wanted: zero records).  "Which lanes write" thus
-// becomes data instead of control flow -- an exec-masked store costs a skip branch, and a branch in the middle of a
-// step splits the basic block the scheduler works on (cgp_fastmath.hpp).  kOobOffset marks a lane that never writes;
-// windows are limited to 2 GiB so that marker + a small immediate offset stays out of range.
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned kOobOffset = 0x80000000u;
-struct OobWindow {
-    __amdgpu_buffer_rsrc_t rsrc;
-    CGP_DEV void init(double* base, int64_t bytes) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base ? (int)bytes : 0, 0x27000);
-    }
-    CGP_DEV void store(double v, unsigned off) const {
-        u32x2_t d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)off, 0, 0);
-    }
-    CGP_DEV void store2(double a, double b, unsigned off) const {
-        u32x4_t d; d.x = (unsigned)__double2loint(a); d.y = (unsigned)__double2hiint(a);
-        d.z = (unsigned)__double2loint(b); d.w = (unsigned)__double2hiint(b);
-        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)off, 0, 0);
-    }
-};
-constexpr int64_t kOobMaxBytes = 0x7FFFFF00;
 
 CGP_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 

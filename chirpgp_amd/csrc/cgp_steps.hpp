@@ -755,6 +755,21 @@ CGP_DEV void affine_from_prediction(const Vec<D>& mf, const Sym<D>& Pf, const Ve
     }
 }
 
+// The gain alone, G = (Pp^{-1} DT)^T row by row (row c = solution for the right-hand side DT[:, c]): what the cooperative
+// d >= 5 smoother keeps per step, next to (mp, Pp) -- it applies the reference's own form ms = mf + G (ms' - mp),
+// Ps = Pf + G (Ps' - Pp) G^T (filters_smoothers.py:83-84) on the matrix cores and never forms c and C.
+template <int D>
+CGP_DEV void gain_from_prediction(const Sym<D>& Pp, const Mat<D>& DT, Mat<D>& G) {
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pp, L, inv);
+    CGP_UNROLL for (int c = 0; c < D; c++) {
+        Vec<D> col;
+        CGP_UNROLL for (int i = 0; i < D; i++) col.v[i] = DT.a[i][c];
+        cho_solve_vec<D>(L, inv, col);
+        CGP_UNROLL for (int i = 0; i < D; i++) G.a[c][i] = col.v[i];
+    }
+}
+
 // Applies a map to a state, row by row.
 template <int D>
 CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps, Vec<D>& xm, Sym<D>& xP) {
@@ -789,6 +804,11 @@ template <class DM> struct EksElement {
         model.propagate(mf, Pf, mp, DT, Pp);
         affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
     }
+    CGP_DEV void gain(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> DT;
+        model.propagate(mf, Pf, mp, DT, Pp);
+        gain_from_prediction<D>(Pp, DT, G);
+    }
 };
 template <class DM, bool COLL = false> struct SgpsElement {
     static constexpr bool USES_SIGMA = true;
@@ -799,6 +819,11 @@ template <class DM, bool COLL = false> struct SgpsElement {
         Vec<D> mp; Sym<D> Pp; Mat<D> DT;
         sgp_prediction<DM, false, true, true, COLL>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
         affine_from_prediction<D>(mf, Pf, mp, Pp, DT, e);
+    }
+    CGP_DEV void gain(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> DT;
+        sgp_prediction<DM, false, true, true, COLL>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
+        gain_from_prediction<D>(Pp, DT, G);
     }
 };
 
