@@ -1,0 +1,78 @@
+"""The five-step script every driver of the reference runs (demos/ekfs_mle.py:39-90, demos/ghfs_mle.py:34-90,
+demos/cd_ghfs_mle.py:28-80, demos/ghfs_harmonics_mle.py:27-80, tetralith/jobs/*_mle.py), on the MI355X engine:
+
+    MLE of the model parameters through the filter  ->  filter  ->  smoother  ->  E[g(V)]  ->  RMSE  (-> .npz result file)
+
+Shared by the demo scripts of this directory; the plots of the reference's demos are not reproduced."""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from chirpgp_amd import filters_smoothers as fs, mle, results                       # noqa: E402
+from chirpgp_amd.models import g, build_chirp_model, build_harmonic_chirp_model     # noqa: E402
+from chirpgp_amd.quadratures import gaussian_expectation                            # noqa: E402
+from chirpgp_amd.toymodels import (gen_chirp, gen_harmonic_chirp, meow_freq, constant_mag, damped_exp_mag,   # noqa: E402
+                                   random_ou_mag)
+from chirpgp_amd.tools import rmse                                                  # noqa: E402
+
+INIT_PARAMS = [0.1, 0.1, 0.1, 1., 1., 7.]       # lam, b, delta, ell, sigma, m0_1 (demos/ekfs_mle.py:39)
+FILTER_OF = {'ekfs': 'ekf', 'ghfs': 'sgp_filter', 'cd_ekfs': 'cd_ekf', 'cd_ghfs': 'cd_sgp_filter'}
+
+
+def magnitudes(rng):
+    """The three magnitude laws of the reference's demos (constant, damped, one Ornstein-Uhlenbeck realisation)."""
+    return (('const', constant_mag(1.)), ('damped', damped_exp_mag(0.3)), ('ou', random_ou_mag(1., 1., rng)))
+
+
+def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=INIT_PARAMS):
+    """MLE -> filter -> smoother -> E[g(V)] on one measurement record.  method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs'.
+    Returns a dict with opt_params, the scipy result, nll0 (objective at the start), the smoothing results and est_freq."""
+    build = build_chirp_model if num_harmonics == 0 else build_harmonic_chirp_model
+    build_kw = {} if num_harmonics == 0 else dict(num_harmonics=num_harmonics)
+    filt = FILTER_OF[method]
+    nll0 = float(mle.batched_nll(filt, build, np.log(np.expm1(np.asarray(init, dtype=np.float64))), ys, Xi, dt, sgps, **build_kw)[0])
+    opt_params, res = mle.fit(filt, build, init, ys, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
+    drift, dispersion, m_and_cov, m0, P0, H = build(opt_params, **build_kw)
+    if method == 'ekfs':
+        mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
+        mss, Pss = fs.eks(m_and_cov, mfs, Pfs, dt)
+    elif method == 'ghfs':
+        mfs, Pfs, _ = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
+        mss, Pss = fs.sgp_smoother(m_and_cov, sgps, mfs, Pfs, dt)
+    elif method == 'cd_ekfs':
+        mfs, Pfs, _ = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
+        mss, Pss = fs.cd_eks(drift, dispersion, mfs, Pfs, dt)
+    else:   # the reference passes the dispersion MATRIX: dispersion(jnp.eye(4)) (demos/cd_ghfs_mle.py:48)
+        mfs, Pfs, _ = fs.cd_sgp_filter(drift, dispersion(None), sgps, H, Xi, m0, P0, dt, ys)
+        mss, Pss = fs.cd_sgp_smoother(drift, dispersion(None), sgps, mfs, Pfs, dt)
+    # the frequency state is the last-but-one component (index 2 of the chirp model, -2 of the harmonic one)
+    est = gaussian_expectation(ms=mss[:, -2], chol_Ps=np.sqrt(Pss[:, -2, -2]), func=g, force_shape=True)[:, 0]
+    return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
+
+
+def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001, maxiter=200, save_dir=None, mags=None, quiet=False):
+    """One run per magnitude law, as the reference's demo scripts do; returns [(name, rmse, nll0, nll_opt), ...]."""
+    ts = np.linspace(dt, dt * T, T)
+    rng = np.random.default_rng(seed)
+    true_freq_func, true_phase_func = meow_freq(offset=8.)
+    out = []
+    for k, (name, mag) in enumerate(magnitudes(rng)):
+        if mags is not None and name not in mags:
+            continue
+        clean = gen_chirp(ts, mag, true_phase_func) if num_harmonics == 0 else gen_harmonic_chirp(ts, [mag] * num_harmonics, true_phase_func)
+        ys = clean + math.sqrt(Xi) * rng.standard_normal(T)
+        t0 = time.time()
+        r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter)
+        err = float(rmse(true_freq_func(ts), r['est_freq'])) if r['res'].success or np.isfinite(r['res'].fun) else float('nan')
+        if save_dir:       # tetralith/jobs/ekfs_mle.py:75-81: NaN results for a diverged run
+            results.save_result(save_dir, method, name, k, r['mss'], r['Pss'], err)
+        if not quiet:
+            print(f'{method:8s} {name:7s} params {np.array2string(r["opt_params"], precision=3)}  nll {r["nll0"]:.2f} -> {r["res"].fun:.2f}  '
+                  f'iters {r["res"].nit} ({r["res"].nfev} launches)  RMSE {err:.3f} Hz  [{time.time() - t0:.2f} s]')
+        out.append((name, err, r['nll0'], float(r['res'].fun)))
+    return out

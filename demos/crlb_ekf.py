@@ -1,4 +1,4 @@
-"""Counterpart of the reference's tetralith/jobs/crlb_ekf.py on the MI355X engine: simulate many chirp-SDE trajectories
+"""Counterpart of the reference's tetralith/jobs/crlb_ekf.py (and, with --filter ghf, tetralith/jobs/crlb_ghf.py) on the MI355X engine: simulate many chirp-SDE trajectories
 on the device (cgp_simulate), run the EKF on all of them in one batched launch (the reference's jax.vmap over ys), and
 report the mean and standard deviation of the squared filtering errors of the chirp and of the frequency state per
 time step.  Nothing but the per-step error statistics (T doubles each) leaves HBM.
@@ -24,7 +24,7 @@ from chirpgp_amd.models import model_chirp, disc_chirp_lcd                    # 
 from chirpgp_amd.parallel import shard_bounds                                 # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     for name, default in (('-lam', 0.1), ('-b', 0.1), ('-delta', 0.1), ('-ell', 1.0), ('-sigma', 1.0), ('-Xi', 0.1)):
         ap.add_argument(name, type=float, default=default)
@@ -32,7 +32,9 @@ def main():
     ap.add_argument('--T', type=int, default=500)
     ap.add_argument('--chunk', type=int, default=250000, help='trials per launch (bounds the HBM held at once)')
     ap.add_argument('--seed', type=int, default=666)
-    args = ap.parse_args()
+    ap.add_argument('--filter', default='ekf', choices=['ekf', 'ghf'], help='ghf: Gauss-Hermite order-3 sigma-point filter (crlb_ghf.py:64-75)')
+    ap.add_argument('--save', default=None, help='write the error statistics to this .npz (keys of crlb_ekf.py:92-95)')
+    args = ap.parse_args(argv)
 
     rank, world = 0, 1
     if 'RANK' in os.environ:
@@ -43,17 +45,26 @@ def main():
     _, _, m0, P0, H = model_chirp(args.lam, args.b, args.ell, args.sigma, args.delta)
     m_and_cov = disc_chirp_lcd(args.lam, args.b, args.ell, args.sigma)
     dt, T = 0.01, args.T
+    if args.filter == 'ghf':
+        from chirpgp_amd.quadratures import SigmaPoints
+        sgps = SigmaPoints.gauss_hermite(d=4, order=3)
+
+        def filtering(yss):
+            return fs.sgp_filter(m_and_cov, sgps, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
+    else:
+        def filtering(yss):
+            return fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
     lo, hi = shard_bounds(args.num_mcs, rank, world)
     sums = torch.zeros((4, T), dtype=torch.float64, device='cuda')        # sum e_chirp, e_chirp^2, e_v, e_v^2 per step
     # warm-up: library load, code-object load and the first allocations are one-off costs of the process
     _, yw = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, 8, args.seed, batch=64)
-    fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yw, want=(True, False, False))
+    filtering(yw)
     torch.cuda.synchronize()
     t0 = time.time()
     for first in range(lo, hi, args.chunk):
         n = min(args.chunk, hi - first)
         xss, yss = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, T, args.seed, batch=n, trial0=first)
-        mfs, _, _ = fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
+        mfs, _, _ = filtering(yss)
         e_chirp = (mfs[:, :, 1] - xss[:, :, 1]) ** 2
         e_v = (mfs[:, :, 2] - xss[:, :, 2]) ** 2
         sums += torch.stack([e_chirp.sum(0), (e_chirp ** 2).sum(0), e_v.sum(0), (e_v ** 2).sum(0)])
@@ -67,12 +78,17 @@ def main():
         mean_c, mean_v = sums[0] / n, sums[2] / n
         std_c = (sums[1] / n - mean_c ** 2).clamp_min(0).sqrt()
         std_v = (sums[3] / n - mean_v ** 2).clamp_min(0).sqrt()
-        print(f'{n} trials x {T} steps on {world} GPU(s): simulate + EKF + error statistics {t1 - t0:.3f} s')
+        print(f'{n} trials x {T} steps on {world} GPU(s): simulate + {args.filter.upper()} + error statistics {t1 - t0:.3f} s')
+        if args.save:
+            import numpy as np
+            np.savez(args.save, ts=dt * np.arange(1, T + 1), err_mean_chirps=mean_c.cpu().numpy(), err_std_chirps=std_c.cpu().numpy(),
+                     err_mean_vs=mean_v.cpu().numpy(), err_std_vs=std_v.cpu().numpy())
         for k in (0, T // 2, T - 1):
             print(f'  t = {dt * (k + 1):5.2f}  chirp err {mean_c[k].item():.4e} +- {std_c[k].item():.2e}   '
                   f'v err {mean_v[k].item():.4e} +- {std_v[k].item():.2e}')
     if world > 1:
         dist.destroy_process_group()
+    return (mean_c, std_c, mean_v, std_v) if rank == 0 else None
 
 
 if __name__ == '__main__':
