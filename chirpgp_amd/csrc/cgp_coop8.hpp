@@ -54,6 +54,15 @@ CGP_DEV double blk_allreduce(double x) {
     return x + dpp_f64<kRowRor4>(x);
 }
 
+// An 8 x 8 x 8 product Z = U V in the tile layout is two chained matrix instructions, Z_IJ = U_I0 V_0J + U_I1 V_1J, whose
+// operands are block re-arrangements of the TRANSPOSE of U and of V (the instruction computes A^T B per block):
+// block (I, J) <- block (K, I): the A operand "U[4 I + r][4 K + k]" from U^T (or from a symmetric U) held in tile layout
+CGP_DEV double blk_rows_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0x8>(dpp_banks_f64<kRowRor4, 0x6>(x, x), x); }
+CGP_DEV double blk_rows_of_k1(double x) { return dpp_banks_f64<kRowRor12, 0x6>(dpp_banks_f64<kRowRor8, 0x1>(x, x), x); }
+// block (I, J) <- block (K, J): the B operand "V[4 K + k][4 J + q]"
+CGP_DEV double blk_cols_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0xC>(x, x); }
+CGP_DEV double blk_cols_of_k1(double x) { return dpp_banks_f64<kRowRor8, 0x3>(x, x); }
+
 // sqrt(s) by v_rsq_f64, one coupled Newton (Goldschmidt) step and one residual correction: 7 instructions, ~1e-16.
 CGP_DEV double sqrt_fast(double s) {
     const double y = __builtin_amdgcn_rsq(s);
@@ -80,6 +89,26 @@ template <int D> CGP_DEV void ldl_lower(const Sym<D>& P, Sym<D>& l, double (&dv)
                 CGP_UNROLL for (int k = j + 1; k <= i; k++) a(i, k) = fma(-l(i, j), c[k], a(i, k));
         }
     }
+}
+
+// Scalar-measurement update (filters_smoothers.py:55-68) in the tile layout.  Pp: the lane's entry of the predicted
+// covariance; mp: the predicted mean in row form (lane (r, (I, J), q) holds mp[4 I + r]); HR = H[4 I + r], HC = H[4 J + r],
+// XiC = Xi on the blocks I = 0 and 0 elsewhere.  Returns the lane's entry of Pf and the updated mean in row form.
+CGP_DEV void coop8_update(double Pp, double mp, double HR, double HC, double XiC, double y, double& P, double& mrow, double& S_out, double& innov_out) {
+    double PHc = mfma4x4(HR, Pp, 0.0);                           // sum_k H[4 I + k] Pp[4 I + k][4 J + q]
+    PHc += blk_xor2(PHc);                                        // PH[4 J + q]
+    double PHr = mfma4x4(blk_swap12(Pp), HC, 0.0);               // sum_k Pp[4 I + r][4 J + k] H[4 J + k]
+    PHr += blk_xor1(PHr);                                        // PH[4 I + r]
+    double S = mfma4x4(HR, PHr, XiC);                            // sum_k H[4 I + k] PH[4 I + k]
+    S += blk_xor2(S);
+    double pred = mfma4x4(HR, mp, 0.0);
+    pred += blk_xor2(pred);
+    const double innov = y - pred;
+    const double rS = rcp_nr1(S);
+    P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
+    mrow = fma(PHr, rS * innov, mp);
+    S_out = S;
+    innov_out = innov;
 }
 
 template <int NH>
@@ -209,18 +238,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             const double Pp = fma(-S1r, S1c, Tt) + fma(dv[D - 1], K1, Sig);
             const double mp = S1r + (fma(Ma, m.v[V], Mb * m.v[V + 1]) + poison);
             // ---- update (filters_smoothers.py:55-68)
-            double PHc = mfma4x4(HR, Pp, 0.0);                           // sum_k H[4 I + k] Pp[4 I + k][4 J + q]
-            PHc += blk_xor2(PHc);                                        // PH[4 J + q]
-            double PHr = mfma4x4(blk_swap12(Pp), HC, 0.0);               // sum_k Pp[4 I + r][4 J + k] H[4 J + k]
-            PHr += blk_xor1(PHr);                                        // PH[4 I + r]
-            double S = mfma4x4(HR, PHr, XiC);                            // sum_k H[4 I + k] PH[4 I + k]
-            S += blk_xor2(S);
-            double pred = mfma4x4(HR, mp, 0.0);
-            pred += blk_xor2(pred);
-            const double innov = y - pred;
-            const double rS = rcp_nr1(S);
-            P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
-            mrow = fma(PHr, rS * innov, mp);
+            double S, innov;
+            coop8_update(Pp, mp, HR, HC, XiC, y, P, mrow, S, innov);
             park[slot] = make_double2(S, innov);
             if (Pfs && entry) Pfs[t * (D * D) + i * D + j] = P;
             if (mfs && mean_lane) mfs[t * D + i] = mrow;
@@ -233,6 +252,120 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
         }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+// ekf8_coop_kernel: ekf (filters_smoothers.py:222-264) for the harmonic chirp LCD model with two or three harmonics, in
+// the tile layout.  J = blockdiag(rho Rot(k theta), M32) + (d f / d u_v column) is held TRANSPOSED, one entry
+// per lane (JT: lane (i, j) holds J[j][i]), assembled from the wave-uniform rotations with per-lane 0 / +-1 / constant
+// coefficients; the predicted mean comes out of two matrix-vector MFMAs (row form for the update, column form for the
+// Jacobian column, which is a quad swap of it, as in cgp_mfma4.hpp); and
+//     W = P J^T,   Pp = J W + Sigma
+// are two 8 x 8 x 8 products = four v_mfma_f64_4x4x4 with bank-masked DPP block moves.  The scalar chain softplus ->
+// sincos of the frequency state (one v_readlane pair from its lane) is evaluated once, wave-uniformly.
+template <int NH>
+__global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma) {
+    constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
+    static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
+    __shared__ double2 park[64];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int I = b >> 1, J = b & 1;
+    const int i = 4 * I + r, j = 4 * J + q;                              // JT: this lane holds J[j][i]; P: P[i][j]
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicLCD<NH> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double HR = (i < D) ? Hp[i] : 0.0;
+    const double HC = (4 * J + r < D) ? Hp[4 * J + r] : 0.0;
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    const double XiC = (I == 0) ? Xi : 0.0;
+    double Sig = 0.0;
+    if (i == j && i < NL) Sig = model.q;
+    else if (i == V && j == V) Sig = model.MS[0];
+    else if ((i == V + 1 && j == V) || (i == V && j == V + 1)) Sig = model.MS[1];
+    else if (i == V + 1 && j == V + 1) Sig = model.MS[2];
+    // J0[row][col] with row = j, col = i (transposed holding): c on the diagonal of a rotation block, -s above, +s below it
+    const int row = j, col = i;
+    const int hk = (row < NL) ? row >> 1 : 0;                            // harmonic (0-based) of this lane's rotation block
+    const bool rot = row < NL && col < NL && (row >> 1) == (col >> 1);
+    const double kc = (rot && row == col) ? 1.0 : 0.0;
+    const double ks = rot ? ((row == col + 1) ? 1.0 : (col == row + 1 ? -1.0 : 0.0)) : 0.0;
+    double kk = 0.0;
+    if (row >= V && row < D && col >= V && col < D) kk = model.M[2 * (row - V) + (col - V)];
+    // d f_row / d u_v = (hk + 1) dtheta/du_v * (-f_{row+1} for even rows, +f_{row-1} for odd rows): a quad swap of f in column form
+    const double kj = (col == V && row < NL) ? ((row & 1) ? 1.0 : -1.0) * (double)(hk + 1) : 0.0;
+    const double ang = (model.dt * kTwoPi) * model.fs;
+    const bool entry = i < D && j < D;
+    const bool mean_lane = (J == 0 && q == 0 && i < D);
+    constexpr int kVLane = 16 * (V & 3) + 4 * (2 * (V >> 2));            // a lane whose row-form entry is u_v
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
+    double mrow = (i < D) ? m0p[i] : 0.0;
+    double P = entry ? ((i >= j) ? P0p[i * D + j] : P0p[j * D + i]) : 0.0;
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
+    double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+
+    double cum = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const int64_t t = t0 + slot;
+            const double y = readlane_f64(ychunk, slot);
+            // ---- wave-uniform scalar chain: rotations at the frequency g(u_v) (models.py:370-376)
+            const double uv = readlane_f64(mrow, kVLane);
+            double sp, dsp, s1, c1;
+            softplus_pair_uniform(uv, sp, dsp);
+            fast_sincos_uniform(ang * sp, s1, c1);
+            double ck = c1, sk = s1, csel = c1, ssel = s1;
+            CGP_UNROLL for (int k = 1; k < NH; k++) {
+                const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+                ck = cn; sk = sn;
+                csel = (hk == k) ? ck : csel; ssel = (hk == k) ? sk : ssel;
+            }
+            const double JT0 = fma(kc, csel * model.rho, fma(ks, ssel * model.rho, kk));        // J0[j][i]
+            // ---- predicted mean: column form f[4 J + q] (for the Jacobian column), row form f[4 I + r] (for the update)
+            double fc = mfma4x4(mrow, JT0, 0.0);                         // sum_k u[4 I + k] J0[4 J + q][4 I + k]
+            fc += blk_xor2(fc);
+            const double xc = blk_swap12(mrow);                          // u[4 J + r]
+            double fr = mfma4x4(blk_swap12(JT0), xc, 0.0);               // sum_k J0[4 I + r][4 J + k] u[4 J + k]
+            fr += blk_xor1(fr);
+            const double JT = fma(kj * (ang * dsp), dpp_f64<kQuadSwap1>(fc), JT0);
+            // ---- W = P J^T, Pp = J W + Sigma
+            const double W = mfma4x4(blk_rows_of_k1(P), blk_cols_of_k1(JT), mfma4x4(blk_rows_of_k0(P), blk_cols_of_k0(JT), 0.0));
+            const double Pp = mfma4x4(blk_rows_of_k1(JT), blk_cols_of_k1(W), mfma4x4(blk_rows_of_k0(JT), blk_cols_of_k0(W), Sig));
+            // ---- update
+            double S, innov;
+            coop8_update(Pp, fr, HR, HC, XiC, y, P, mrow, S, innov);
+            park[slot] = make_double2(S, innov);
+            if (Pfs && entry) Pfs[t * (D * D) + i * D + j] = P;
+            if (mfs && mean_lane) mfs[t * D + i] = mrow;
+        }
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+template <int NH>
+inline int launch_ekf8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    hipLaunchKernelGGL((ekf8_coop_kernel<NH>), dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
 }
 
 // The collapsed quadrature of the kernel above needs the caller's CGP_SIGMA_STANDARD assertion, groups, and at most one
@@ -264,12 +397,6 @@ inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
 constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | Pp (packed lower, 36) | mp (8) | one zero; odd: conflict-free lane stride
 constexpr int kElemC = 64, kElemc = 100, kElemZero = 108;
 
-// block (I, J) <- block (K, I): the A operand "X[4 I + r][4 K + k]" of a symmetric X held in tile layout
-CGP_DEV double blk_rows_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0x8>(dpp_banks_f64<kRowRor4, 0x6>(x, x), x); }
-CGP_DEV double blk_rows_of_k1(double x) { return dpp_banks_f64<kRowRor12, 0x6>(dpp_banks_f64<kRowRor8, 0x1>(x, x), x); }
-// block (I, J) <- block (K, J): the B operand "W[4 K + k][4 J + q]"
-CGP_DEV double blk_cols_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0xC>(x, x); }
-CGP_DEV double blk_cols_of_k1(double x) { return dpp_banks_f64<kRowRor8, 0x3>(x, x); }
 
 struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc; };
 

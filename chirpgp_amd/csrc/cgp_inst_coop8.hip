@@ -10,6 +10,13 @@ int dispatch_filter_coop8_sgp(int n_harm, const FilterIO& io, const ModelArgs& m
     default: return CGP_E_UNSUPPORTED;
     }
 }
+int dispatch_filter_coop8_ekf(int n_harm, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    switch (n_harm) {
+    case 2: return launch_ekf8_coop<2>(io, ma, st);
+    case 3: return launch_ekf8_coop<3>(io, ma, st);
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
 // The cooperative smoother keeps 32 affine maps in 27.9 KB of static LDS; with the staged sigma-point set beside it a
 // workgroup must stay within 40 KB so that four of them (one per SIMD) share a CU's 160 KB (every cubature rule fits;
 // larger sets take the lane-scan kernel).

@@ -453,6 +453,7 @@ int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 // d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
 bool coop8_filter_sgp_ok(int n_harm, const ModelArgs&);
 int dispatch_filter_coop8_sgp(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_coop8_ekf(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 bool coop8_smoother_ok(int d, int64_t T, const ModelArgs&);
 bool coop8_smoother_harm_ok(int method, const ModelArgs&);
 int dispatch_smoother_coop8_linear(int method, int d, const SmootherIO&, const ModelArgs&, hipStream_t);

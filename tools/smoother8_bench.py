@@ -25,7 +25,10 @@ def timeit(name, fn, n=5, **kw):
     print(f'{name:40s} {np.mean([a.elapsed_time(b) for _, a, b in ev]):8.3f} ms')
 
 
-for flags, tag in ((0, 'coop walk'), (0x2 | 0x10, 'lane scan')):
+for flags, tag in ((0, 'tile layout'), (0x2 | 0x10, 'generic')):
+    kw = dict(flags=flags) if flags else {}
+    timeit(f'ekf nh=3 filter [{tag}]', lambda **k: fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys, **k), **kw)
+    timeit(f'sgp_filter nh=3 [{tag}]', lambda **k: fs.sgp_filter(wl['disc'], wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys, **k), **kw)
     kw = dict(flags=flags) if flags else {}
     timeit(f'rts d=8 [{tag}]', lambda **k: fs.rts(F, S, fl[0], fl[1], **k), **kw)
     timeit(f'eks nh=3 [{tag}]', lambda **k: fs.eks(wl['disc'], f[0], f[1], wl['dt'], **k), **kw)
