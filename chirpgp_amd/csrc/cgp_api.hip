@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64) debug_math_uniform_kernel(int op, const do
         const double v = x[i];
         double a, b;
         if (op == 5) softplus_pair_uniform(v, a, b);
-        else if (op == 8) { SpecRegs R; R.init(); softplus_wide(R, v, exp_neg_common(R, v), a, b); }
+        else if (op == 8) { SpecRegs R; R.init(); double q; const double t = exp_neg_lean(R, v); softplus_tail_lean(R, t, q, b); a = fma(q, t, v); }
         else fast_sincos_uniform(v, a, b);
         if (threadIdx.x == 0) { o0[i] = a; if (o1) o1[i] = b; }
     }

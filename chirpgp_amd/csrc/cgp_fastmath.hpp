@@ -320,41 +320,60 @@ constexpr double kLog1pOverT[16] = {
     0.14285495922701988, -0.12497821928598722, 0.11095454366589008, -0.09916989080882566, 0.08761369562912116,
     -0.07344526523759841, 0.05435248977771075, -0.031930229294847796, 0.012725281636614353, -0.002504592860624598};
 
-// Constants of the speculative EKF step (cgp_mfma4.hpp) pinned in VGPRs: exp, the wide log1p tail, the four
-// coefficients of the small-angle rotation.
+// ---- the speculative EKF step's softplus (cgp_mfma4.hpp) ------------------------------------------------------------------
+// That step is one dependent chain, half of it these two polynomials, and its results sat at 1e-13 of the oracle against
+// a gate of 1e-5 (1e-9 in the full-size test): the chain carries near-minimax polynomials of degree 7 (three Estrin levels,
+// 9 instructions each) instead of degree 13 / 15 (four levels, 17 / 18 instructions):
+//     exp(r),        |r| <= ln 2 / 2:        relative error 5.5e-11        (kExpLean)
+//     log1p(t) / t,  0 <= t <= exp(-1.5):    relative error 1.0e-11        (kLog1pOverTLean)
+// (Chebyshev-node interpolants, tools/gen_math_constants.py).  With t = exp(-x) <= 0.223 the softplus x + t q(t) is then
+// good to 1.4e-11 absolute (7e-12 relative: x >= 1.5) and the rotation angle dt 2 pi fs g(x) to 1e-13 rad at the demos'
+// dt = 1e-3; the derivative 1 / (1 + t) to 1.2e-11.  The error is a fixed function of x -- a softplus perturbed by 1e-11 --
+// so it does not accumulate from step to step.  Outside [1.5, 700) the chunk is repeated with the checked step, which
+// uses the full-precision functions (and the reference's naive form where that is what the reference evaluates).
+constexpr double kExpLean[8] = {0.9999999999595294, 0.9999999999955055, 0.5000000107793876, 0.1666666678638044,
+                                0.041666218139710595, 0.008333283518768105, 0.0013948590286863383, 0.00019907582591325134};
+constexpr double kLog1pOverTLean[8] = {0.999999999990116, -0.49999999432118947, 0.3333327946277929, -0.24998038614728868,
+                                       0.19964561452797533, -0.16312923302145096, 0.12263546195074254, -0.059855823415835646};
+
+// Constants of the speculative step pinned in VGPRs (see FastMathRegs).  lq is stored pre-multiplied by `scale` (the
+// step wants the rotation angle scale * softplus, so the scale rides in the coefficients: one multiply less on the chain).
 struct SpecRegs {
-    double ex[14], lq[16];
+    double ex[8], lq[8];
     double log2e, ln2hi, ln2lo;
     double s3, s5, c4, c6;       // -1/6, 1/120, 1/24, -1/720
     // PIN = false leaves the values as ordinary constants the compiler may rematerialise: fewer live registers, a few
     // more moves -- the trade for a kernel that wants two waves per SIMD rather than the shortest chain
-    template <bool PIN = true> CGP_DEV void init() {
-        const double ex_[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
-                                1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+    template <bool PIN = true> CGP_DEV void init(double scale = 1.0) {
         auto keep = [](double v) { return PIN ? FastMathRegs::pin(v) : v; };
-        CGP_UNROLL for (int i = 0; i < 14; i++) ex[i] = keep(ex_[i]);
-        CGP_UNROLL for (int i = 0; i < 16; i++) lq[i] = keep(kLog1pOverT[i]);
+        CGP_UNROLL for (int i = 0; i < 8; i++) ex[i] = keep(kExpLean[i]);
+        CGP_UNROLL for (int i = 0; i < 8; i++) lq[i] = keep(kLog1pOverTLean[i] * scale);
         log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo);
         s3 = keep(-1.0 / 6.0); s5 = keep(1.0 / 120.0);
         c4 = keep(1.0 / 24.0); c6 = keep(-1.0 / 720.0);
     }
 };
-// ln 2 <= x < 700 (t = exp(-x) <= 1/2) as one unsigned compare on the high word of a wave-uniform x.
-CGP_DEV bool softplus_wide_regime(double x) {
-    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
-    return (hx - 0x3FE62E43u) < (0x4085E000u - 0x3FE62E43u);
+// exp(-x) for |x| < 700 with the lean polynomial: x = -(k ln2 + r), three Estrin levels, v_ldexp_f64.
+CGP_DEV double exp_neg_lean(const SpecRegs& R, double x) {
+    const double nx = -x;
+    const double k = __builtin_rint(nx * R.log2e);
+    double r = fma(-k, R.ln2hi, nx);
+    r = fma(-k, R.ln2lo, r);
+    const double r2 = r * r;
+    const double a0 = horner(R.ex[1], r, R.ex[0]), a1 = horner(R.ex[3], r, R.ex[2]);
+    const double a2 = horner(R.ex[5], r, R.ex[4]), a3 = horner(R.ex[7], r, R.ex[6]);
+    const double r4 = r2 * r2;
+    const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2);
+    return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
 }
-// softplus and its derivative from t = exp(-x) <= 1/2.
-CGP_DEV void softplus_wide(const SpecRegs& R, double x, double t, double& sp, double& dsp) {
+// scale * log1p(t) / t  (scale folded into R.lq) and the softplus derivative 1 / (1 + t), t = exp(-x) <= exp(-1.5).
+CGP_DEV void softplus_tail_lean(const SpecRegs& R, double t, double& q_scaled, double& dsp) {
     const double t2 = t * t;
-    const double a0 = horner(R.lq[1], t, R.lq[0]), a1 = horner(R.lq[3], t, R.lq[2]), a2 = horner(R.lq[5], t, R.lq[4]);
-    const double a3 = horner(R.lq[7], t, R.lq[6]), a4 = horner(R.lq[9], t, R.lq[8]), a5 = horner(R.lq[11], t, R.lq[10]);
-    const double a6 = horner(R.lq[13], t, R.lq[12]), a7 = horner(R.lq[15], t, R.lq[14]);
+    const double a0 = horner(R.lq[1], t, R.lq[0]), a1 = horner(R.lq[3], t, R.lq[2]);
+    const double a2 = horner(R.lq[5], t, R.lq[4]), a3 = horner(R.lq[7], t, R.lq[6]);
     const double t4 = t2 * t2;
-    const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2), b2 = horner(a5, t2, a4), b3 = horner(a7, t2, a6);
-    const double t8 = t4 * t4;
-    const double d0 = horner(b1, t4, b0), d1 = horner(b3, t4, b2);
-    sp = fma(horner(d1, t8, d0), t, x);
+    const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2);
+    q_scaled = horner(b1, t4, b0);
     dsp = rcp_nr1(1.0 + t);
 }
 

@@ -88,14 +88,15 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
     ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
 }
 
-// The speculative step.  Softplus: t = exp(-u2), then x + t q(t) with the degree-15 polynomial q = log1p(t) / t, valid for
-// u2 >= ln 2.  Rotation: (cos, sin)(theta) is advanced INCREMENTALLY from the previous step's,
+// The speculative step.  Softplus: t = exp(-u2), then theta = ang (u2 + t q(t)) with the lean degree-7 polynomials of
+// cgp_fastmath.hpp (ang rides in q's coefficients), valid for u2 >= 1.5.  Rotation: (cos, sin)(theta) is advanced
+// INCREMENTALLY from the previous step's,
 //     (cos, sin)(theta) = rotation of (cos, sin)(theta_prev) by d = theta - theta_prev,
 // with sin d, cos d to d^5 / d^6 (remainders < 4e-19 while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
-// fresh sincos.  d is an exact difference (Sterbenz), so the angle does not drift; what accumulates is one rounding
-// per step in the rotation, and the pair is re-anchored with the full sincos at the start of every 64-step chunk
-// (relative error <= 64 x 2e-16).  A step with u2 outside [ln 2, 700) or |d| > 2^-7 (or NaN) sets *uncommon and the
-// whole chunk is repeated with the checked step.
+// fresh sincos.  d is formed as ang q t + (ang u2 - theta_prev), whose second term does not wait for the polynomials; what
+// accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
+// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| > 2^-7 (or NaN) sets
+// *uncommon and the whole chunk is repeated with the checked step.
 struct Ekf4Anchor { double th, c1, s1; };
 
 CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
@@ -108,21 +109,22 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                  double& innov, unsigned* uncommon) {
     const double u2 = x.u2();
-    double sp, dsp;
-    softplus_wide(R, u2, exp_neg_common(R, u2), sp, dsp);
-    const double th = K.ang * sp;
-    const double d = th - a.th;
+    const double t = exp_neg_lean(R, u2);
+    const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
+    double qa, dsp;
+    softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
+    const double d = fma(qa, t, lin);
     const double d2 = d * d, d4 = d2 * d2;
     const double sd = fma(d * d2, horner(R.s5, d2, R.s3), d);                        // d - d^3/6 + d^5/120
     const double cd = fma(d4, horner(R.c6, d2, R.c4), fma(-0.5, d2, 1.0));           // 1 - d^2/2 + d^4/24 - d^6/720
     const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
     // verdicts without compares, scalar registers or branches: clamp the high words into their admissible ranges and
     // OR the bits the clamp changed into a vector accumulator (non-zero = some step left the regime; NaN, inf and
-    // negative u2 fall outside the signed range [ln 2, 700), NaN / inf angles above the magnitude bound)
+    // negative u2 fall outside the signed range [1.5, 700), NaN / inf angles above the magnitude bound)
     const int hx = __double2hiint(u2);
     const unsigned hd = (unsigned)__double2hiint(d) & 0x7fffffffu;
-    *uncommon |= (unsigned)(hx ^ max(0x3FE62E43, min(hx, 0x4085DFFF))) | (hd ^ min(hd, 0x3F7FFFFFu));
-    a.th = th; a.c1 = c1; a.s1 = s1;
+    *uncommon |= (unsigned)(hx ^ max(0x3FF80000, min(hx, 0x4085DFFF))) | (hd ^ min(hd, 0x3F7FFFFFu));
+    a.th += d; a.c1 = c1; a.s1 = s1;
     ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
 }
 
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     const unsigned p_off = 8u * (4 * r + q);
 
     SpecRegs R;
-    R.init();
+    R.init(K.ang);
     // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     __shared__ double2 park[64];
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     const bool want_nll = io.nll != nullptr;
 
     SpecRegs R;
-    R.init<!DENSE>();
+    R.init<!DENSE>(K.ang);
     __shared__ double ych[4][64];
     __shared__ double2 park[4][64];
     double cum[4] = {0.0, 0.0, 0.0, 0.0};

@@ -198,7 +198,7 @@ int cgp_debug_philox(cgp_ctx* ctx, const uint32_t* ctr, const uint32_t* key, int
  * op: 0 exp, 1 log on [1, inf] (softplus argument), 2 sincos (out0 = sin, out1 = cos), 3 reciprocal,
  *     4 softplus pair (out0 = log(exp(x) + 1), out1 = its derivative), 5 / 6 the wave-uniform variants of 4 / 2,
  *     7 the per-lane softplus pair in its wide common-regime form (with the naive fallback), 8 the speculative step's
- *     softplus pair (valid for ln 2 <= x < 700 only), 9 reciprocal with one Newton step.
+ *     lean softplus pair (valid for 1.5 <= x < 700 only; ~1e-11), 9 reciprocal with one Newton step.
  *     out1 may be NULL for one-output ops. */
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream);
 

@@ -111,11 +111,12 @@ def test_wide_softplus_forms():
     pos = fin & (x >= 0)
     assert _ulp_err(sp[pos], [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in x[pos]]) < 1e-15
     assert _ulp_err(dsp[pos & okd], [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x[pos & okd]]) < 1e-15
-    # the speculative step's pair inside its regime; its derivative carries one Newton step (2.2e-15)
-    xr = np.concatenate([rng.uniform(0.6932, 60, 2000), rng.uniform(60, 699, 200), [0.6931476593017578, 699.999]])
+    # the speculative step's LEAN pair inside its regime [1.5, 700): degree-7 polynomials, 7e-12 on the softplus (the chain
+    # of the bench kernel trades five orders of unused accuracy for two Estrin levels; cgp_fastmath.hpp)
+    xr = np.concatenate([rng.uniform(1.5, 60, 2000), rng.uniform(1.5, 3.0, 1000), rng.uniform(60, 699, 200), [1.5, 699.999]])
     sp, dsp = E.debug_math(8, xr)
-    assert _ulp_err(sp, [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in xr]) < 1e-15
-    assert _ulp_err(dsp, [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in xr]) < 5e-15
+    assert _ulp_err(sp, [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in xr]) < 1e-11
+    assert _ulp_err(dsp, [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in xr]) < 2e-11
     d = np.concatenate([10 ** rng.uniform(-8, 8, 2000) * rng.choice([-1, 1], 2000)])
     r1, _ = E.debug_math(9, d)
     assert np.max(np.abs(r1 * d - 1)) < 5e-15

@@ -287,7 +287,11 @@ def test_full_size_properties_and_parity():
     idx = torch.from_numpy(sel).cuda()
     for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
         cs.assert_close(g.cpu().numpy(), w, RTOL, f'full.{n}')
-        print(n, f'{cs.max_rel_err(g.cpu().numpy(), w):.2e}')
+        err = cs.max_rel_err(g.cpu().numpy(), w)
+        print(n, f'{err:.2e}')
+        # the bench kernels spend accuracy nobody asked for on a shorter chain (lean softplus polynomials, one Newton step on
+        # the reciprocals: cgp_fastmath.hpp) -- but no more than this: 1e-9 relative over the whole record, every trial checked
+        assert err <= 1e-9, (n, err)
 
 
 def test_mle_through_the_filter():
