@@ -312,14 +312,6 @@ CGP_DEV bool softplus_common_regime(double x) {
     return (hx - 0x40180000u) < (0x4085E000u - 0x40180000u);
 }
 
-// log1p(t) / t on [0, 1/2] as a polynomial of degree 15 (Chebyshev-node interpolant, tools/gen_math_constants.py;
-// relative error 1.7e-17): with t = exp(-x) it carries the softplus  x + t (log1p(t) / t)  for every x >= ln 2, i.e.
-// every frequency above 1.1 Hz, in four Estrin levels -- one more than the six-term series that only reaches x >= 6.
-constexpr double kLog1pOverT[16] = {
-    1.0, -0.499999999999983, 0.33333333333043524, -0.24999999980360632, 0.19999999298210291, -0.16666651430722035,
-    0.14285495922701988, -0.12497821928598722, 0.11095454366589008, -0.09916989080882566, 0.08761369562912116,
-    -0.07344526523759841, 0.05435248977771075, -0.031930229294847796, 0.012725281636614353, -0.002504592860624598};
-
 // ---- the speculative EKF step's softplus (cgp_mfma4.hpp) ------------------------------------------------------------------
 // That step is one dependent chain, half of it these two polynomials, and its results sat at 1e-13 of the oracle against
 // a gate of 1e-5 (1e-9 in the full-size test): the chain carries near-minimax polynomials of degree 7 (three Estrin levels,

@@ -15,28 +15,36 @@
 
 namespace cgp {
 
-// softplus log(exp(x) + 1) (models.py:50) and its derivative exp(x) / (exp(x) + 1), per lane.
-// Common regime, ln 2 <= x < 700 (frequencies above 1.1 Hz):  x + t q(t)  and  1 / (1 + t)  with t = exp(-x) <= 1/2 and
-// q = log1p(t) / t the degree-15 polynomial of cgp_fastmath.hpp -- one exp and a polynomial instead of exp and a full
-// log (42 instead of 63 instructions, half the latency).  If ANY active lane is outside that regime (or NaN) the
-// wavefront also evaluates the reference's naive form, whose overflow behaviour (inf, NaN) is the reference's, and
-// those lanes take it: one wave-uniform branch, not taken in the common case.
-CGP_DEV double log1p_over_t(double t) {
-    const double t2 = t * t;
-    const double a0 = horner(kLog1pOverT[1], t, kLog1pOverT[0]), a1 = horner(kLog1pOverT[3], t, kLog1pOverT[2]);
-    const double a2 = horner(kLog1pOverT[5], t, kLog1pOverT[4]), a3 = horner(kLog1pOverT[7], t, kLog1pOverT[6]);
-    const double a4 = horner(kLog1pOverT[9], t, kLog1pOverT[8]), a5 = horner(kLog1pOverT[11], t, kLog1pOverT[10]);
-    const double a6 = horner(kLog1pOverT[13], t, kLog1pOverT[12]), a7 = horner(kLog1pOverT[15], t, kLog1pOverT[14]);
-    const double t4 = t2 * t2;
-    const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2), b2 = horner(a5, t2, a4), b3 = horner(a7, t2, a6);
-    const double t8 = t4 * t4;
-    return horner(horner(b3, t4, b2), t8, horner(b1, t4, b0));
+// softplus log(exp(x) + 1) (models.py:50) and its derivative exp(x) / (exp(x) + 1), per lane, for the latency-bound kernels.
+// Common regime, 1.5 <= x < 700 (frequencies above 1.7 Hz):  x + t q(t)  and  1 / (1 + t)  with t = exp(-x) <= 0.223 and
+// q = log1p(t) / t, both by the LEAN degree-7 polynomials of cgp_fastmath.hpp (relative error 7e-12 on the softplus,
+// 1.2e-11 on the derivative: these kernels' results sat eight orders inside the 1e-5 gate) -- 23 instructions instead of
+// the 63 of exp + full log.  If ANY active lane is outside that regime (or NaN) the wavefront also evaluates the
+// reference's naive form, whose overflow behaviour (inf, NaN) is the reference's, and those lanes take it: one
+// wave-uniform branch, not taken in the common case.
+CGP_DEV double exp_neg_lean_lane(double x) {
+    const double nx = -x;
+    const double k = __builtin_rint(nx * kLog2e);
+    double r = fma(-k, kLn2Hi, nx);
+    r = fma(-k, kLn2Lo, r);
+    const double r2 = r * r;
+    const double a0 = horner(kExpLean[1], r, kExpLean[0]), a1 = horner(kExpLean[3], r, kExpLean[2]);
+    const double a2 = horner(kExpLean[5], r, kExpLean[4]), a3 = horner(kExpLean[7], r, kExpLean[6]);
+    const double r4 = r2 * r2;
+    return __builtin_amdgcn_ldexp(horner(horner(a3, r2, a2), r4, horner(a1, r2, a0)), (int)k);
 }
-CGP_DEV bool softplus_lane_common(double x) { return x >= 0.6931476593017578 && x < 700.0; }      // slightly above ln 2
+CGP_DEV double log1p_over_t_lean(double t) {
+    const double t2 = t * t;
+    const double a0 = horner(kLog1pOverTLean[1], t, kLog1pOverTLean[0]), a1 = horner(kLog1pOverTLean[3], t, kLog1pOverTLean[2]);
+    const double a2 = horner(kLog1pOverTLean[5], t, kLog1pOverTLean[4]), a3 = horner(kLog1pOverTLean[7], t, kLog1pOverTLean[6]);
+    const double t4 = t2 * t2;
+    return horner(horner(a3, t2, a2), t4, horner(a1, t2, a0));
+}
+CGP_DEV bool softplus_lane_common(double x) { return x >= 1.5 && x < 700.0; }
 CGP_DEV void softplus_pair_wide(double x, double& sp, double& dsp) {
-    const double t = fast_exp_core(-x);
-    sp = fma(log1p_over_t(t), t, x);
-    dsp = rcp_nr(1.0 + t);
+    const double t = exp_neg_lean_lane(x);
+    sp = fma(log1p_over_t_lean(t), t, x);
+    dsp = rcp_nr1(1.0 + t);
     const bool common = softplus_lane_common(x);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!common) != 0, 0)) {
         const double e = fast_exp(x);
@@ -47,8 +55,8 @@ CGP_DEV void softplus_pair_wide(double x, double& sp, double& dsp) {
     }
 }
 CGP_DEV double softplus_wide(double x) {
-    const double t = fast_exp_core(-x);
-    double sp = fma(log1p_over_t(t), t, x);
+    const double t = exp_neg_lean_lane(x);
+    double sp = fma(log1p_over_t_lean(t), t, x);
     const bool common = softplus_lane_common(x);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!common) != 0, 0)) {
         const double sp_n = fast_log_ge1(fast_exp(x) + 1.0);

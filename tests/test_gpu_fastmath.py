@@ -89,14 +89,14 @@ def test_uniform_variants():
 
 
 def test_wide_softplus_forms():
-    """The common-regime softplus x + t q(t), t = exp(-x), q = log1p(t) / t as a degree-15 polynomial: per lane with the
-    naive fallback for lanes outside [ln 2, 700) (mixed in the same wavefronts), and the speculative step's form."""
+    """The common-regime softplus x + t q(t), t = exp(-x), q = log1p(t) / t with the lean degree-7 polynomials (7e-12): per
+    lane with the naive fallback for lanes outside [1.5, 700) (mixed in the same wavefronts), and the speculative step's form."""
     import mpmath as mp
     from chirpgp_amd import _engine as E
     mp.mp.prec = 200
     rng = np.random.default_rng(11)
-    x = np.concatenate([rng.uniform(0.6, 60, 3000), rng.uniform(-30, 0.8, 800), rng.uniform(0.69, 0.70, 200), rng.uniform(690, 712, 100),
-                        [0.6931471805599453, 0.6931476593017578, 0.69314, 699.99, 700., 710., 800., -800., np.inf, -np.inf, np.nan]])
+    x = np.concatenate([rng.uniform(0.6, 60, 3000), rng.uniform(-30, 1.6, 800), rng.uniform(1.49, 1.51, 200), rng.uniform(690, 712, 100),
+                        [1.5, 1.4999999999, 0.6931471805599453, 699.99, 700., 710., 800., -800., np.inf, -np.inf, np.nan]])
     rng.shuffle(x)                                  # common and uncommon lanes side by side in every wavefront
     sp, dsp = E.debug_math(7, x)
     with np.errstate(over='ignore', invalid='ignore'):
@@ -105,12 +105,14 @@ def test_wide_softplus_forms():
     assert np.array_equal(np.isnan(dsp), np.isnan(ref_d)) and np.array_equal(np.isnan(sp), np.isnan(ref_sp))
     assert np.array_equal(np.isinf(sp), np.isinf(ref_sp))
     fin = np.isfinite(ref_sp) & np.isfinite(x) & (ref_sp > 0)
-    assert np.max(np.abs(sp[fin] - ref_sp[fin]) / ref_sp[fin]) < 1e-13
+    assert np.max(np.abs(sp[fin] - ref_sp[fin]) / ref_sp[fin]) < 1e-11
     okd = fin & np.isfinite(ref_d)
-    assert np.max(np.abs(dsp[okd] - ref_d[okd]) / ref_d[okd]) < 1e-14
+    assert np.max(np.abs(dsp[okd] - ref_d[okd]) / ref_d[okd]) < 2e-11
     pos = fin & (x >= 0)
-    assert _ulp_err(sp[pos], [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in x[pos]]) < 1e-15
-    assert _ulp_err(dsp[pos & okd], [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x[pos & okd]]) < 1e-15
+    assert _ulp_err(sp[pos], [mp.log(mp.exp(mp.mpf(float(v))) + 1) for v in x[pos]]) < 1e-11
+    assert _ulp_err(dsp[pos & okd], [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x[pos & okd]]) < 2e-11
+    out = fin & ~((x >= 1.5) & (x < 700))            # outside the lean regime: the full-precision naive form
+    assert np.max(np.abs(sp[out] - ref_sp[out]) / ref_sp[out]) < 1e-13
     # the speculative step's LEAN pair inside its regime [1.5, 700): degree-7 polynomials, 7e-12 on the softplus (the chain
     # of the bench kernel trades five orders of unused accuracy for two Estrin levels; cgp_fastmath.hpp)
     xr = np.concatenate([rng.uniform(1.5, 60, 2000), rng.uniform(1.5, 3.0, 1000), rng.uniform(60, 699, 200), [1.5, 699.999]])

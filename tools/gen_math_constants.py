@@ -25,23 +25,29 @@ print('kTwoOverPi =', repr(float(2 / mp.pi)))
 print('kSqrtHalf  =', repr(float(mp.sqrt(mp.mpf(1) / 2))))
 
 
-# ---- log1p(t) / t on [0, 1/2] as a polynomial of degree 15 (softplus tail of the speculative EKF step) ----------------
-# Interpolation at the Chebyshev nodes of the interval, solved at 300 bits, coefficients rounded to float64; the maximum
-# relative error of the exact-coefficient polynomial is 1.7e-17 (log1p has its singularity at t = -1: the Chebyshev
-# series converges like 5.8^-n on [0, 1] and 9.9^-n on [0, 1/2]).
-def log1p_over_t_coefficients(b=0.5, n=15):
+# ---- the lean degree-7 polynomials of the latency-bound kernels (cgp_fastmath.hpp: kExpLean, kLog1pOverTLean) --------------
+# Interpolation at the Chebyshev nodes of the interval (near-minimax), solved at 300 bits, coefficients rounded to float64:
+#     exp(r) on |r| <= ln 2 / 2 (x 1.0001): relative error 5.5e-11;   log1p(t) / t on [0, exp(-1.5)]: relative error 1.0e-11
+# (log1p has its singularity at t = -1: the Chebyshev series converges like 19.9^-n on [0, 0.223]).
+def cheb_fit(f, a, b, deg):
     mp.mp.prec = 300
-    f = lambda t: mp.mpf(1) if t == 0 else mp.log1p(t) / t
-    nodes = [mp.mpf(b) / 2 * (1 + mp.cos(mp.pi * (2 * i + 1) / (2 * (n + 1)))) for i in range(n + 1)]
-    V = mp.matrix(n + 1, n + 1)
-    for i, t in enumerate(nodes):
-        for j in range(n + 1):
-            V[i, j] = t ** j
-    c = mp.lu_solve(V, mp.matrix([f(t) for t in nodes]))
-    return [float(c[j]) for j in range(n + 1)]
+    n = deg + 1
+    xs = [(a + b) / 2 + (b - a) / 2 * mp.cos(mp.pi * (2 * k + 1) / (2 * n)) for k in range(n)]
+    V = mp.matrix(n, n)
+    for i, x in enumerate(xs):
+        for j in range(n):
+            V[i, j] = x ** j
+    c = mp.lu_solve(V, mp.matrix([f(x) for x in xs]))
+    return [float(c[j]) for j in range(n)]
 
 
-print('kLog1pOverT[16] = {')
-for v in log1p_over_t_coefficients():
-    print('    %r,' % v)
-print('};')
+def max_rel_err(f, c, a, b, n=4000):
+    return max(abs(sum(cj * (a + (b - a) * mp.mpf(k) / n) ** j for j, cj in enumerate(c)) / f(a + (b - a) * mp.mpf(k) / n) - 1) for k in range(n + 1))
+
+
+ln2h = mp.log(2) / 2
+ex = cheb_fit(mp.exp, -ln2h * mp.mpf('1.0001'), ln2h * mp.mpf('1.0001'), 7)
+q = lambda t: mp.log1p(t) / t if t != 0 else mp.mpf(1)
+lq = cheb_fit(q, mp.mpf(0), mp.exp(mp.mpf('-1.5')), 7)
+print('kExpLean[8] = {' + ', '.join(repr(v) for v in ex) + '};   // max rel err', mp.nstr(max_rel_err(mp.exp, ex, -ln2h, ln2h), 3))
+print('kLog1pOverTLean[8] = {' + ', '.join(repr(v) for v in lq) + '};   // max rel err', mp.nstr(max_rel_err(q, lq, mp.mpf(0), mp.exp(mp.mpf('-1.5'))), 3))
