@@ -238,6 +238,7 @@ def main():
                          f'`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` '
                          f'or let `python bench.py --gpus {args.gpus}` start the ranks itself')
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL; must be set before HIP initialises
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -246,7 +247,6 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.rehearse:
             dist.init_process_group('gloo')
         else:

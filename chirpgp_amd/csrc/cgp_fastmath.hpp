@@ -313,7 +313,7 @@ CGP_DEV bool softplus_common_regime(double x) {
 }
 
 // ---- the speculative EKF step's softplus (cgp_mfma4.hpp) ------------------------------------------------------------------
-// That step is one dependent chain, half of it these two polynomials, and its results sat at 1e-13 of the oracle against
+// That step is one dependent chain, half of it these two polynomials, and its results sat at 1e-13 of the CPU checker against
 // a gate of 1e-5 (1e-9 in the full-size test): the chain carries near-minimax polynomials of degree 7 (three Estrin levels,
 // 9 instructions each) instead of degree 13 / 15 (four levels, 17 / 18 instructions):
 //     exp(r),        |r| <= ln 2 / 2:        relative error 5.5e-11        (kExpLean)

@@ -171,6 +171,20 @@ def test_ragged_lengths(T):
                    bk.run_pairs('port', c, only=('ekf', 'sgp_filter')), RTOL, f'T={T}')
 
 
+@pytest.mark.parametrize('T', [1, 2, 3, 33, 63, 64, 65, 66, 97, 129, 130])
+def test_ragged_lengths_in_the_tile_layout_kernels(T):
+    """d = 6 and d = 8 (cgp_coop8.hpp): the 64-step measurement chunks of the filters, and the cooperative smoother's tiles of
+    64 steps walked in two halves of four batches -- records that end inside a batch, a half, a tile; the last tile is walked
+    past the start of the record with its loads and stores out of the buffer windows."""
+    for nh in (3, 2):
+        c = _batch_case(cs.harmonic_case, 3, T=T, nh=nh)
+        want = bk.run_pairs('port', c, only=('ekf', 'eks', 'sgp_filter', 'sgp_smoother'))
+        got = bk.run_pairs('hip', c, hip_kw=WAVE, only=('ekf', 'eks', 'sgp_filter', 'sgp_smoother'))
+        bk.compare(got, want, RTOL, f'nh={nh} T={T}')
+        sm = bk.smoothers_on('hip', c, want, hip_kw=WAVE)
+        bk.compare(sm, {k: want[k] for k in ('eks', 'sgp_smoother')}, RTOL, f'nh={nh} T={T} smoothers on oracle inputs')
+
+
 @pytest.mark.parametrize('B', [1, 63, 65, 130])
 def test_ragged_batches(B):
     """Partial last wavefront in the one-lane-per-trial shape."""
