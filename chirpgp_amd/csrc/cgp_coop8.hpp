@@ -63,12 +63,13 @@ CGP_DEV double blk_rows_of_k1(double x) { return dpp_banks_f64<kRowRor12, 0x6>(d
 CGP_DEV double blk_cols_of_k0(double x) { return dpp_banks_f64<kRowRor8, 0xC>(x, x); }
 CGP_DEV double blk_cols_of_k1(double x) { return dpp_banks_f64<kRowRor8, 0x3>(x, x); }
 
-// sqrt(s) by v_rsq_f64, one coupled Newton (Goldschmidt) step and one residual correction: 7 instructions, ~1e-16.
+// sqrt(s) by v_rsq_f64 (~2^-24), one Newton (Goldschmidt) step on the root and one residual correction with the seed's own
+// half-reciprocal (its 2^-24 error only scales a correction that is already 2^-47): 6 instructions, rounding-level accuracy.
 CGP_DEV double sqrt_fast(double s) {
     const double y = __builtin_amdgcn_rsq(s);
-    double g = s * y, h = 0.5 * y;
-    const double r = fma(-g, h, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
+    double g = s * y;
+    const double h = 0.5 * y;
+    g = fma(g, fma(-g, h, 0.5), g);
     return fma(fma(-g, g, s), h, g);
 }
 
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
-    const double ONE = 1.0;
+    const double IDENT = (r == q) ? 1.0 : 0.0;                           // per block: A^T B with B = identity transposes A
 
     double cum = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -230,8 +231,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             // ---- G W G^T by tiles, row sums in row and column form
             const double T00 = blk_allreduce(mfma4x4(A0, B0, 0.0)), T01 = blk_allreduce(mfma4x4(A0, B1, 0.0));
             const double T10 = blk_allreduce(mfma4x4(A1, B0, 0.0)), T11 = blk_allreduce(mfma4x4(A1, B1, 0.0));
-            const double R0 = blk_allreduce(mfma4x4(A0, W, 0.0)), R1 = blk_allreduce(mfma4x4(A1, W, 0.0));        // sum W G[4 X + r]
-            const double C0 = blk_allreduce(mfma4x4(ONE, B0, 0.0)), C1 = blk_allreduce(mfma4x4(ONE, B1, 0.0));    // sum W G[4 Y + q]
+            const double R0 = blk_allreduce(mfma4x4(A0, W, 0.0)), R1 = blk_allreduce(mfma4x4(A1, W, 0.0));        // sum W G[4 X + r], every q
+            const double C0 = mfma4x4(R0, IDENT, 0.0), C1 = mfma4x4(R1, IDENT, 0.0);                              // the same sums by column: [r][q] <- [q][r]
             const double Tt = (b == 0) ? T00 : (b == 1) ? T01 : (b == 2) ? T10 : T11;
             const double S1r = I ? R1 : R0, S1c = J ? C1 : C0;
             // ---- predicted moments in tile layout / row form
