@@ -61,18 +61,17 @@ template <int D> CGP_DEV void matvec(const Mat<D>& A, const Vec<D>& x, Vec<D>& y
 // Lower Cholesky factor of a packed symmetric matrix.  Like LAPACK potrf under JAX, a pivot that is <= 0
 // or NaN makes the whole factor NaN (no trap, no exception): SURVEY.md section 5 "silent NaN propagation".
 // Also returns 1/L_ii in inv_diag for the triangular solves.
-// sqrt(s) and 1 / sqrt(s) together from v_rsq_f64 and two coupled Newton (Goldschmidt) steps plus one residual
-// correction: 11 instructions, ~1 ulp, instead of sqrt() + divide (107 + 74 cycles of dependent latency, measured).
+// sqrt(s) and 1 / sqrt(s) together from v_rsq_f64 (~2^-24) and ONE coupled Newton (Goldschmidt) step: 6 instructions,
+// 5e-15 relative (1.5 e^2), instead of sqrt() + divide (107 + 74 cycles of dependent latency, measured).  Round 1 took a
+// second step and a residual correction (11 instructions, ~1 ulp): the Cholesky factors feed filters gated at 1e-5 whose
+// results sat at 1e-13, and every wave-per-trial sigma-point kernel factorises once per step or RK4 stage.
 CGP_DEV void sqrt_rsqrt(double s, double& root, double& inv_root) {
     const double y = __builtin_amdgcn_rsq(s);
-    double g = s * y, h = 0.5 * y;
-    double r = fma(-g, h, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-g, h, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    g = fma(fma(-g, g, s), h, g);
-    root = g;
-    inv_root = h + h;
+    const double g = s * y, h = 0.5 * y;
+    const double r = fma(-g, h, 0.5);
+    root = fma(g, r, g);
+    const double h1 = fma(h, r, h);
+    inv_root = h1 + h1;
 }
 
 template <int D> CGP_DEV void cholesky(const Sym<D>& P, Sym<D>& L, Vec<D>& inv_diag) {
