@@ -639,3 +639,41 @@ def test_wide_sigma_fans_take_the_full_sincos_fallback(kw):
         for g_, w_, n in zip(got_f + got_s, want_f + want_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
             cs.assert_close(g_, w_, RTOL, f'wide fan nh={nh} fs={fscale}: {n}')
         assert np.isnan(got_f[0][3, 250:]).all() and not np.isnan(got_f[0][[0, 1, 2, 4, 5]]).any()
+
+
+@pytest.mark.parametrize('nh', [2, 3])
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='tile_layout'), pytest.param(WAVE_GENERIC, id='generic'), pytest.param(THREAD, id='lane_per_trial')])
+def test_harmonic_models_per_trial_everything_and_nan(nh, kw):
+    """d = 6 / 8 (the tile-layout kernels and their generic counterparts): one parameter vector, H, Xi, m0, P0 per trial; a NaN
+    measurement in one record and an indefinite P0 in another turn exactly those trials NaN where the oracle's do; NLL-only."""
+    from chirpgp_amd import models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    B, T, d = 5, 300, 2 * nh + 2
+    rng = np.random.default_rng(21 + nh)
+    params = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * rng.uniform(0.9, 1.1, size=(B, 6))
+    drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, nh)
+    Hb = np.tile(H, (B, 1)) * rng.uniform(0.8, 1.2, size=(B, 1)) + 0.05 * rng.standard_normal((B, d))
+    Xib = rng.uniform(0.05, 0.2, size=B)
+    P0 = np.array(P0)
+    P0[3, 0, 1] = P0[3, 1, 0] = 2.0 * P0[3, 0, 0]                      # indefinite: trial 3 is NaN from the first Cholesky on
+    ys = np.stack([cs.chirp_measurements(T, 500 + i, num_harmonics=nh)[2] for i in range(B)])
+    ys[1, 170] = np.nan
+    sg = SigmaPoints.cubature(d)
+    for meth, pmeth, smeth, psmeth, sgp in (('ekf', port.F_EKF, 'eks', port.S_EKS, None), ('sgp_filter', port.F_SGP, 'sgp_smoother', port.S_SGP, sg)):
+        want = port.filter(pmeth, disc, sgp, Hb, Xib, m0, P0, 1e-3, ys)
+        args = (disc,) + ((sg,) if sgp is not None else ()) + (Hb, Xib, m0, P0, 1e-3, ys)
+        got = getattr(fs, meth)(*args, **kw)
+        for g_, w_, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+            cs.assert_close(g_, w_, RTOL, f'{meth} nh={nh} {n}')
+        assert np.isnan(got[0][1, 170:]).all() and not np.isnan(got[0][[0, 2, 4]]).any()
+        assert np.isnan(got[0][3]).all() == (meth == 'sgp_filter')       # only the sigma-point filter factorises P (the EKF does not)
+        last = getattr(fs, meth)(*args, nll_final_only=True, want=(False, False, True), **kw)[2]
+        cs.assert_close(last, want[2][:, -1], RTOL, f'{meth} nh={nh} nll-only')
+        # smoothers on the oracle's filtering results of the healthy trials (and the NaN ones: NaN in, NaN out)
+        want_s = port.smoother(psmeth, disc, sgp, 1e-3, want[0], want[1])
+        sargs = (disc,) + ((sg,) if sgp is not None else ()) + (want[0], want[1], 1e-3)
+        got_s = getattr(fs, smeth)(*sargs, **kw)
+        for g_, w_, n in zip(got_s, want_s, ('mss', 'Pss')):
+            cs.assert_close(g_, w_, RTOL, f'{smeth} nh={nh} {n}')
