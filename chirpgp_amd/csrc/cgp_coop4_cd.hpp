@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) cdekf4_coop_kernel(FilterIO io, ModelArgs 
 }
 
 __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArgs ma) {
-    __shared__ double gl[16];
+    __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
     const int lane = threadIdx.x;
     const int li = (lane >> 2) & 3, lj = lane & 3;
     const int64_t trial = blockIdx.x;
@@ -168,19 +168,17 @@ __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArg
     if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
     if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
 
-    Vec<4> mf; Sym<4> Pf;
-    if (T >= 2) { load_vec<4>(mfs + (T - 2) * 4, mf); load_sym<4>(Pfs + (T - 2) * 16, Pf); }
-    for (int64_t t = T - 2; t >= 0; t--) {
-        Vec<4> mf_n = mf; Sym<4> Pf_n = Pf;                                  // prefetch the next (earlier) filtering result
-        if (t >= 1) { load_vec<4>(mfs + (t - 1) * 4, mf_n); load_sym<4>(Pfs + (t - 1) * 16, Pf_n); }
-        Mat<4> PG;                                                           // Pf^{-1} gamma, constant over the 4 stages
-        pinv_gamma<4>(Pf, gamma, PG);
-        CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j++) gl[i * 4 + j] = PG.a[i][j];
-        wave_lds_fence();
+    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+    const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
+    coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);      // Pf^{-1} gamma of the chunk's steps, one step per lane
+    for (int slot = 0; slot < nsteps; slot++) {
+        const int64_t t = t_hi - slot;
+        const double* gl = gbuf + slot * kGainPitch;
+        Mat<4> PG; Vec<4> mf;                                            // constant over the 4 stages
+        coop4_read_gain(gl, PG, mf);
         // A = J + G^T: the lane's A[i][l_r] = J[i][l_r] + G[l_r][i] and A[j][l] = J[j][l] + G[l][j]
         const double gr[4] = {gl[li * 4 + li], gl[lr1 * 4 + li], gl[lr2 * 4 + li], gl[lr3 * 4 + li]};
         const double gc[4] = {gl[0 * 4 + lj], gl[1 * 4 + lj], gl[2 * 4 + lj], gl[3 * 4 + lj]};
-        wave_lds_fence();
 
         Vec<4> tm = ms, am, km;
         double tP = Ps, aP = 0.0;
@@ -206,7 +204,8 @@ __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArg
         Ps = Ps + (dt * aP) / 6.0;
         if (lane < 16) Pss[t * 16 + lane] = Ps;
         if (lane == 0) store_vec<4>(mss + t * 4, ms);
-        mf = mf_n; Pf = Pf_n;
+    }
+    wave_lds_fence();
     }
 }
 

@@ -512,6 +512,38 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
     if (lane == 0 && io.nll && out.nll_final) io.nll[trial] = cum;
 }
 
+// ------------------------------------------------------------------------------------------------ backward gains, a chunk at a time
+// G_k = Pf_k^{-1} gamma of the continuous-discrete smoothers (filters_smoothers.py:429, 617-618) depends on the filtering result
+// of step k alone.  Computed inside the step it is a Cholesky and four solves that all 64 lanes repeat identically (150 of the
+// ~800 / 1200 instructions of a cd_eks / cd_sgp_smoother step); instead each chunk of 64 steps factorises its 64 covariances
+// lane-parallel -- lane l takes step t_hi - l -- and parks (G, mf) in LDS, where the serial walk picks them up as broadcast reads.
+constexpr int kGainPitch = 22;                     // 16 (G, row-major) + 4 (mf) + 2: 16-byte aligned records, conflict-free lane stride
+CGP_DEV void coop4_chunk_gains(double* gbuf, int lane, int n, int64_t t_hi, const double* __restrict__ mfs, const double* __restrict__ Pfs,
+                               const Sym<4>& gamma) {
+    if (lane < n) {
+        const int64_t t = t_hi - lane;
+        Vec<4> mf; Sym<4> Pf;
+        load_vec<4>(mfs + t * 4, mf);
+        load_sym<4>(Pfs + t * 16, Pf);
+        Mat<4> PG;
+        pinv_gamma<4>(Pf, gamma, PG);
+        double* g = gbuf + lane * kGainPitch;
+        CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j += 2) *reinterpret_cast<double2*>(g + i * 4 + j) = make_double2(PG.a[i][j], PG.a[i][j + 1]);
+        *reinterpret_cast<double2*>(g + 16) = make_double2(mf.v[0], mf.v[1]);
+        *reinterpret_cast<double2*>(g + 18) = make_double2(mf.v[2], mf.v[3]);
+    }
+    wave_lds_fence();
+}
+// the record of one step: G and mf as wave-uniform values
+CGP_DEV void coop4_read_gain(const double* g, Mat<4>& PG, Vec<4>& mf) {
+    CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(g + i * 4 + j);
+        PG.a[i][j] = v.x; PG.a[i][j + 1] = v.y;
+    }
+    const double2 a = *reinterpret_cast<const double2*>(g + 16), b = *reinterpret_cast<const double2*>(g + 18);
+    mf.v[0] = a.x; mf.v[1] = a.y; mf.v[2] = b.x; mf.v[3] = b.y;
+}
+
 // ------------------------------------------------------------------------------------------------ cd_sgp_smoother, d = 4
 // Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
 // G is constant over the four stages (hoisted, as in cgp_steps.hpp); its entries reach the lanes through LDS:
@@ -521,7 +553,7 @@ template <class SM, bool COLLAPSED>
 __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
     __shared__ double red[kFanLdsDoubles];
-    __shared__ double gl[16];
+    __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
     const int lane = threadIdx.x;
     const int li = (lane >> 2) & 3, lj = lane & 3;
     const int64_t trial = blockIdx.x;
@@ -558,19 +590,16 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
     if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
     if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
 
-    Vec<4> mf; Sym<4> Pf;
-    if (T >= 2) { load_vec<4>(mfs + (T - 2) * 4, mf); load_sym<4>(Pfs + (T - 2) * 16, Pf); }
-    for (int64_t t = T - 2; t >= 0; t--) {
-        // prefetch the next (earlier) filtering result while this step computes
-        Vec<4> mf_n = mf; Sym<4> Pf_n = Pf;
-        if (t >= 1) { load_vec<4>(mfs + (t - 1) * 4, mf_n); load_sym<4>(Pfs + (t - 1) * 16, Pf_n); }
-        Mat<4> PG;
-        pinv_gamma<4>(Pf, gamma, PG);
-        CGP_UNROLL for (int i = 0; i < 4; i++) CGP_UNROLL for (int j = 0; j < 4; j++) gl[i * 4 + j] = PG.a[i][j];
-        wave_lds_fence();
+    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+    const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
+    coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);
+    for (int slot = 0; slot < nsteps; slot++) {
+        const int64_t t = t_hi - slot;
+        const double* gl = gbuf + slot * kGainPitch;
+        Mat<4> PG; Vec<4> mf;
+        coop4_read_gain(gl, PG, mf);
         const double gr0 = gl[li * 4 + li], gr1 = gl[lr1 * 4 + li], gr2 = gl[lr2 * 4 + li], gr3 = gl[lr3 * 4 + li];
         const double gc0 = gl[0 * 4 + lj], gc1 = gl[1 * 4 + lj], gc2 = gl[2 * 4 + lj], gc3 = gl[3 * 4 + lj];
-        wave_lds_fence();
 
         Vec<4> tm = ms, am, km;
         double tP = Ps, aP = 0.0, kP;
@@ -604,7 +633,8 @@ __global__ void __launch_bounds__(64) cdsgps4_coop_kernel(SmootherIO io, ModelAr
         Ps = Ps + (dt * aP) / 6.0;
         if (lane < 16) Pss[t * 16 + lane] = Ps;
         if (lane == 0) store_vec<4>(mss + t * 4, ms);
-        mf = mf_n; Pf = Pf_n;
+    }
+    wave_lds_fence();
     }
 }
 
