@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
-PMC_PROFILE = 'profiles/r01_v17_ekf_eks_pmc.json'
+PMC_PROFILE = 'profiles/r02_ekf_pmc.json'
 
 
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0):
@@ -56,7 +56,7 @@ def make_workload(B, T, seed=0, kind='ekf'):
     from chirpgp_amd.quadratures import SigmaPoints
     params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
     wl = dict(kind=kind, dt=1e-3, Xi=0.1, B=B, T=T)
-    if kind == 'harmonic':
+    if kind in ('harmonic', 'harmonic_ekf'):
         drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, 3)
         wl.update(ys=chirp_batch(B, T, seed, num_harmonics=3), sgps=SigmaPoints.cubature(8), d=8)
     else:
@@ -128,13 +128,13 @@ def cpu_baseline(wl, target_seconds=12.0):
     n = min(ys.shape[0], max(threads, 8))
     drift_g = copy.copy(wl['drift'])
     drift_g.gamma = wl['disp'].outer()
-    label = {'ekf': 'EKF+EKS', 'sgp': 'sgp_filter+sgp_smoother', 'harmonic': 'sgp_filter+sgp_smoother (cubature, d=8)',
+    label = {'ekf': 'EKF+EKS', 'harmonic_ekf': 'EKF+EKS (d=8)', 'sgp': 'sgp_filter+sgp_smoother', 'harmonic': 'sgp_filter+sgp_smoother (cubature, d=8)',
              'cd_sgp': 'cd_sgp_filter+cd_sgp_smoother', 'cd_ekf': 'cd_ekf+cd_eks'}[k]
 
     def once(nn):
         t0 = time.perf_counter()
         a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys[:nn])
-        if k == 'ekf':
+        if k in ('ekf', 'harmonic_ekf'):
             f = port.filter(port.F_EKF, wl['disc'], None, *a)
             port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], f[0], f[1])
         elif k in ('sgp', 'harmonic'):
@@ -164,6 +164,7 @@ WORKLOADS = {
     'cd_sgp': ("C4: cd_sgp_filter+cd_sgp_smoother RK4", 512, 50000, 'weak', 'valu_f64'),
     'cd_ekf': ("cd_ekf+cd_eks RK4", 1000, 10000, 'weak', 'valu_f64'),
     'harmonic': ("C5: 3-harmonic chirp, cubature sgp_filter+sgp_smoother", 1000, 10000, 'strong', 'valu_f64'),
+    'harmonic_ekf': ("3-harmonic chirp (d = 8), ekf+eks", 1000, 10000, 'weak', 'valu_f64'),
 }
 # float64 vector peak: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2 flop x 2.4 GHz (a wave64 v_fma_f64 occupies its SIMD for
 # 4 cycles: measured 4.0 cycles per independent instruction, one wave per SIMD, tools/ubench/f64_issue.hip)
@@ -287,7 +288,7 @@ def main():
 
         def step():
             k = wl['kind']
-            if k == 'ekf':
+            if k in ('ekf', 'harmonic_ekf'):
                 f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
                 s = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
             elif k in ('sgp', 'harmonic'):
@@ -386,7 +387,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "d": d, "T": T, "batch_per_gpu": B, "global_batch": B_total,
                        "parallelism": f"trials sharded x{world}",
-                       "sigma_points": int(wl['sgps'].n_points) if args.workload not in ('ekf', 'cd_ekf') else None},
+                       "sigma_points": int(wl['sgps'].n_points) if args.workload not in ('ekf', 'cd_ekf', 'harmonic_ekf') else None},
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
             "roofline": roofline,
             "kernels": {"filter_ms": filt_ms, "smoother_ms": smooth_ms,
