@@ -120,7 +120,9 @@ typedef struct cgp_sigma {
  * differ in the LAST coordinate only with sum_{k in group} w_k xi_k[d-1] = 0.  For the chirp / harmonic models, whose
  * last two state components are linear, the kernels may then take the moments of the linear components in closed form
  * and run the quadrature over one representative per group with the group's total weight: an exact regrouping of the
- * reference's sums (filters_smoothers.py:88-137), different only in rounding. */
+ * reference's sums (filters_smoothers.py:88-137), different only in rounding.  The d = 4 kernels and, for sets of at
+ * most 16 groups (every cubature rule), the d = 6 / 8 tile-layout kernels take this form; CGP_LITERAL_SIGMA_SUM forces
+ * the literal sums. */
 #define CGP_SIGMA_STANDARD    0x1u
 
 /* Measurement model and initial condition of a filter. */
