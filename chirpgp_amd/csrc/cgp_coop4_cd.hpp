@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64) cdekf4_coop_kernel(FilterIO io, ModelArgs 
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
     Coop4SdeJac jac;
     jac.init(model, li, lj);
-    FastMathRegs fm;
+    SpecRegs fm;               // the lean wave-uniform softplus: the drift needs no sincos
     fm.init();
     Coop4Meas meas;
     meas.load(io, trial, li, lj);
@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(64) cdeks4_coop_kernel(SmootherIO io, ModelArg
     model.setup(ma.params + trial * ma.param_stride, ma.model_id);
     Coop4SdeJac jac;
     jac.init(model, li, lj);
-    FastMathImm fm;   // 300 registers with the pinned table: the literal form is faster here
+    SpecRegs fm;               // lean softplus, coefficients left to the compiler (the pinned form costs registers this kernel needs)
+    fm.init<false>();
     Sym<4> gamma;
     load_sym<4>(ma.gamma + trial * ma.gamma_stride, gamma);
     const double gam = coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, li, lj);

@@ -369,6 +369,22 @@ CGP_DEV void softplus_tail_lean(const SpecRegs& R, double t, double& q_scaled, d
     dsp = rcp_nr1(1.0 + t);
 }
 
+// The wave-uniform pair with the lean polynomials (regime [1.5, 700), 7e-12 / 1.2e-11; see "the speculative EKF step's
+// softplus" above): evaluated unconditionally, the regime test is a scalar compare consumed by a rarely-taken branch at the end.
+CGP_DEV void softplus_pair_uniform(const SpecRegs& R, double x, double& sp, double& dsp) {
+    const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    const bool common = (hx - 0x3FF80000u) < (0x4085E000u - 0x3FF80000u);
+    const double t = exp_neg_lean(R, x);
+    double q;
+    softplus_tail_lean(R, t, q, dsp);
+    sp = fma(q, t, x);
+    if (__builtin_expect(!common, 0)) {            // elsewhere, and for inf / NaN: the naive form of models.py:50 as is
+        const double e = fast_exp(x);
+        const double z = e + 1.0;
+        sp = fast_log_ge1(z);
+        dsp = e * rcp_nr(z);
+    }
+}
 CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp) {
     const bool common = softplus_common_regime(x);
     softplus_from_exp_neg(R, x, exp_neg_common(R, x), sp, dsp);
