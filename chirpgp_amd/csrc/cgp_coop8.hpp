@@ -301,6 +301,8 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
     const bool entry = i < D && j < D;
     const bool mean_lane = (J == 0 && q == 0 && i < D);
     constexpr int kVLane = 16 * (V & 3) + 4 * (2 * (V >> 2));            // a lane whose row-form entry is u_v
+    SpecRegs R;
+    R.init<false>();
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
             // ---- wave-uniform scalar chain: rotations at the frequency g(u_v) (models.py:370-376)
             const double uv = readlane_f64(mrow, kVLane);
             double sp, dsp, s1, c1;
-            softplus_pair_uniform(uv, sp, dsp);
+            softplus_pair_uniform(R, uv, sp, dsp);                       // lean polynomials on [1.5, 700), the naive form elsewhere
             fast_sincos_uniform(ang * sp, s1, c1);
             double ck = c1, sk = s1, csel = c1, ssel = s1;
             CGP_UNROLL for (int k = 1; k < NH; k++) {
