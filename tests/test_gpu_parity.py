@@ -677,3 +677,49 @@ def test_harmonic_models_per_trial_everything_and_nan(nh, kw):
         got_s = getattr(fs, smeth)(*sargs, **kw)
         for g_, w_, n in zip(got_s, want_s, ('mss', 'Pss')):
             cs.assert_close(g_, w_, RTOL, f'{smeth} nh={nh} {n}')
+
+
+# ------------------------------------------------------------------ BASELINE configs C3, C4, C5 at their full per-GPU size
+@pytest.mark.parametrize('kind,every', [pytest.param('sgp', 50, id='C3_gh3_d4_1000x10000'), pytest.param('harmonic', 50, id='C5_cubature_d8_1000x10000'),
+                                        pytest.param('cd_sgp', 64, id='C4_cd_gh3_d4_512x50000')])
+def test_full_size_sigma_point_configs(kind, every):
+    """The sigma-point configurations at the size bench.py times them (B x T per GPU of BASELINE.json), results resident in HBM:
+    every `every`-th trial against the C port over the whole record, plus the size-independent properties on all trials
+    (finite; last smoothing row == last filtering row bit for bit; the discrete smoothers do not increase the marginal variance)."""
+    import copy
+    import torch
+    import bench
+    from oracle import port
+    fs = _fs()
+    label, B, T, _, _ = bench.WORKLOADS[kind]
+    wl = bench.make_workload(B, T, seed=0, kind=kind)
+    ys = torch.from_numpy(wl['ys']).cuda()
+    a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'])
+    if kind == 'cd_sgp':
+        f = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], *a, ys)
+        s = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], f[0], f[1], wl['dt'])
+    else:
+        f = fs.sgp_filter(wl['disc'], wl['sgps'], *a, ys)
+        s = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'])
+    mfs, Pfs, nll = f
+    mss, Pss = s
+    assert bool(torch.isfinite(mfs).all()) and bool(torch.isfinite(Pss).all()) and bool(torch.isfinite(nll).all())
+    assert torch.equal(mss[:, -1], mfs[:, -1]) and torch.equal(Pss[:, -1], Pfs[:, -1])
+    if kind != 'cd_sgp':      # exact for the discrete smoothers; the RK4-integrated backward ODE keeps it only to its own truncation error
+        dvar = torch.diagonal(Pfs - Pss, dim1=-2, dim2=-1)
+        assert float(dvar.min()) > -1e-9 * float(torch.diagonal(Pfs, dim1=-2, dim2=-1).abs().max())
+    sel = np.arange(0, B, every)
+    if kind == 'cd_sgp':
+        dg = copy.copy(wl['drift'])
+        dg.gamma = wl['disp'].outer()
+        w_f = port.filter(port.F_CD_SGP, dg, wl['sgps'], *a, wl['ys'][sel])
+        w_s = port.smoother(port.S_CD_SGP, dg, wl['sgps'], wl['dt'], w_f[0], w_f[1])
+    else:
+        w_f = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a, wl['ys'][sel])
+        w_s = port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], w_f[0], w_f[1])
+    idx = torch.from_numpy(sel).cuda()
+    for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
+        cs.assert_close(g.cpu().numpy(), w, RTOL, f'{kind} full size: {n}')
+        err = cs.max_rel_err(g.cpu().numpy(), w)
+        print(kind, n, f'{err:.2e}')
+        assert err <= 1e-7, (kind, n, err)
