@@ -117,18 +117,8 @@ CGP_DEV double fast_log_ge1(double z) {
     return (z == __builtin_inf()) ? z : y;
 }
 
-// sin(x), cos(x): 3-term Cody-Waite reduction by pi/2 for |x| < 1e5 (n < 2^16: n * kPio2_1, n * kPio2_2 exact),
-// Taylor to r^17 / r^16 on |r| <= pi/4 (truncation 5e-17).  Larger |x|, inf and NaN take the library's values.
-// The reduced-range evaluation runs unconditionally; only if some active lane is outside the range does the wavefront
-// also call the library and those lanes take its result -- one wave-uniform branch at the END (a branch in front would
-// cut the caller's dependent chain into basic blocks that cannot be interleaved; see cgp_mfma4.hpp).  Signs are flipped
-// on the high word instead of negate-and-select.
-CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
-    const bool common = fabs(x) < 1.0e5;               // false for inf and NaN
-    const double n = __builtin_rint(x * kTwoOverPi);
-    double r = fma(-n, kPio2_1, x);
-    r = fma(-n, kPio2_2, r);
-    r = fma(-n, kPio2_3, r);
+// sin(r), cos(r) on the reduced range |r| <= pi/4: Taylor to r^17 / r^16 (truncation 5e-17), two independent Horner chains.
+CGP_DEV void sincos_reduced(double r, double& s0, double& c0) {
     const double r2 = r * r;
     double ps = -1.0 / 355687428096000.0;          // -1/17!
     ps = horner(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
@@ -145,8 +135,25 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     pc = horner(pc, r2, 1.0 / 40320.0);               //  1/8!
     pc = horner(pc, r2, -1.0 / 720.0);                // -1/6!
     pc = horner(pc, r2, 1.0 / 24.0);                  //  1/4!
-    const double s0 = fma(-(r * r2), ps, r);                // r - r^3 (1/3! - r^2/5! + ...)
-    const double c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0)); // 1 - r^2/2 + r^4 (1/4! - ...)
+    s0 = fma(-(r * r2), ps, r);                       // r - r^3 (1/3! - r^2/5! + ...)
+    c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));        // 1 - r^2/2 + r^4 (1/4! - ...)
+}
+constexpr double kPiOver4 = 0.78539816339744830962;
+
+// sin(x), cos(x): 3-term Cody-Waite reduction by pi/2 for |x| < 1e5 (n < 2^16: n * kPio2_1, n * kPio2_2 exact),
+// Taylor to r^17 / r^16 on |r| <= pi/4 (truncation 5e-17).  Larger |x|, inf and NaN take the library's values.
+// The reduced-range evaluation runs unconditionally; only if some active lane is outside the range does the wavefront
+// also call the library and those lanes take its result -- one wave-uniform branch at the END (a branch in front would
+// cut the caller's dependent chain into basic blocks that cannot be interleaved; see cgp_mfma4.hpp).  Signs are flipped
+// on the high word instead of negate-and-select.
+CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
+    const bool common = fabs(x) < 1.0e5;               // false for inf and NaN
+    const double n = __builtin_rint(x * kTwoOverPi);
+    double r = fma(-n, kPio2_1, x);
+    r = fma(-n, kPio2_2, r);
+    r = fma(-n, kPio2_3, r);
+    double s0, c0;
+    sincos_reduced(r, s0, c0);
     const int q = (int)n;
     const bool swap = (q & 1) != 0;
     const double a = swap ? c0 : s0, b = swap ? s0 : c0;
@@ -346,7 +353,8 @@ struct SpecRegs {
     }
 };
 // exp(-x) for |x| < 700 with the lean polynomial: x = -(k ln2 + r), three Estrin levels, v_ldexp_f64.
-CGP_DEV double exp_neg_lean(const SpecRegs& R, double x) {
+template <class Regs>
+CGP_DEV double exp_neg_lean(const Regs& R, double x) {
     const double nx = -x;
     const double k = __builtin_rint(nx * R.log2e);
     double r = fma(-k, R.ln2hi, nx);
@@ -359,7 +367,8 @@ CGP_DEV double exp_neg_lean(const SpecRegs& R, double x) {
     return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
 }
 // scale * log1p(t) / t  (scale folded into R.lq) and the softplus derivative 1 / (1 + t), t = exp(-x) <= exp(-1.5).
-CGP_DEV void softplus_tail_lean(const SpecRegs& R, double t, double& q_scaled, double& dsp) {
+template <class Regs>
+CGP_DEV void softplus_tail_lean(const Regs& R, double t, double& q_scaled, double& dsp) {
     const double t2 = t * t;
     const double a0 = horner(R.lq[1], t, R.lq[0]), a1 = horner(R.lq[3], t, R.lq[2]);
     const double a2 = horner(R.lq[5], t, R.lq[4]), a3 = horner(R.lq[7], t, R.lq[6]);
@@ -367,6 +376,37 @@ CGP_DEV void softplus_tail_lean(const SpecRegs& R, double t, double& q_scaled, d
     const double b0 = horner(a1, t2, a0), b1 = horner(a3, t2, a2);
     q_scaled = horner(b1, t4, b0);
     dsp = rcp_nr1(1.0 + t);
+}
+
+// Pinned coefficients for a per-lane sigma-point fan that is evaluated without regime branches (cgp_mfma4_sigma.hpp): the
+// lean softplus above and sin / cos on the reduced range |r| <= pi/4 (Taylor to r^17 / r^16) in Estrin form -- four
+// dependent levels instead of the eight of sincos_reduced's Horner chains.
+struct FanRegs {
+    double ex[8], lq[8], log2e, ln2hi, ln2lo;
+    double sn[8];       // -1/17!, 1/15!, ..., 1/3!
+    double cs[7];       // 1/16!, -1/14!, ..., 1/4!
+    CGP_DEV void init() {
+        const double sn_[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0,
+                               -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
+        const double cs_[7] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0,
+                               1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0};
+        CGP_UNROLL for (int i = 0; i < 8; i++) { ex[i] = FastMathRegs::pin(kExpLean[i]); lq[i] = FastMathRegs::pin(kLog1pOverTLean[i]); }
+        CGP_UNROLL for (int i = 0; i < 8; i++) sn[i] = FastMathRegs::pin(sn_[i]);
+        CGP_UNROLL for (int i = 0; i < 7; i++) cs[i] = FastMathRegs::pin(cs_[i]);
+        log2e = FastMathRegs::pin(kLog2e); ln2hi = FastMathRegs::pin(kLn2Hi); ln2lo = FastMathRegs::pin(kLn2Lo);
+    }
+};
+CGP_DEV void sincos_reduced(const FanRegs& R, double r, double& s0, double& c0) {
+    const double z = r * r, z2 = z * z;
+    const double sa0 = horner(R.sn[6], z, R.sn[7]), sa1 = horner(R.sn[4], z, R.sn[5]), sa2 = horner(R.sn[2], z, R.sn[3]);
+    const double sa3 = horner(R.sn[0], z, R.sn[1]);
+    const double ca0 = horner(R.cs[5], z, R.cs[6]), ca1 = horner(R.cs[3], z, R.cs[4]), ca2 = horner(R.cs[1], z, R.cs[2]);
+    const double z4 = z2 * z2;
+    const double sb0 = horner(sa1, z2, sa0), sb1 = horner(sa3, z2, sa2);
+    const double cb0 = horner(ca1, z2, ca0), cb1 = horner(R.cs[0], z2, ca2);
+    const double ps = horner(sb1, z4, sb0), pc = horner(cb1, z4, cb0);
+    s0 = fma(-(r * z), ps, r);
+    c0 = fma(z2, pc, fma(-0.5, z, 1.0));
 }
 
 // The wave-uniform pair with the lean polynomials (regime [1.5, 700), 7e-12 / 1.2e-11; see "the speculative EKF step's

@@ -447,6 +447,7 @@ int dispatch_filter_sde_harm(int method, int key, bool wave, const FilterIO&, co
 int dispatch_filter_kpt(int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop4(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_mfma4(const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_mfma4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 // the matrix-core EKF addresses a trial's outputs through 2 GiB buffer windows (cgp_mfma4.hpp)
 inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00ll; }
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);

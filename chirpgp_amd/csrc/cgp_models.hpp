@@ -163,6 +163,27 @@ template <int NH> struct HarmonicLCD {
     static constexpr int IVC = IV;
     struct Pre { double c[NH], s[NH]; };
     CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus_sel(wide, uv)) * fs, p.c, p.s); }
+    // precompute() WITHOUT its two regime branches and with pinned coefficients, for kernels that interleave several fans
+    // in one basic block: the lean softplus and the reduced-range sin / cos taken as is.  ok = the lane is in the regime
+    // where that is valid (1.5 <= uv < 700 and a rotation angle within pi/4, i.e. n = 0 in the Cody-Waite reduction); the
+    // caller re-evaluates with precompute() if any lane is not.
+    CGP_DEV void precompute_spec(const FanRegs& R, double uv, Pre& p, bool& ok) const {
+        const double t = exp_neg_lean(R, uv);
+        double q, unused;
+        softplus_tail_lean(R, t, q, unused);
+        const double sp = fma(q, t, uv);
+        const double x = sp * ((kTwoPi * fs) * dt);           // loop-invariant factor: one multiplication on the chain
+        ok = softplus_lane_common(uv) && fabs(x) <= kPiOver4;
+        double s1, c1;
+        sincos_reduced(R, x, s1, c1);
+        double ck = c1, sk = s1;
+        p.c[0] = c1 * rho; p.s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            p.c[k] = ck * rho; p.s[k] = sk * rho;
+        }
+    }
     // The sigma points of one prediction spread around the mean, so their rotation angles differ from the mean's by a
     // small d = dt (w - w0): the fan anchors (cos, sin) at the mean once and every point takes the small-angle rotation
     // by d (sin to d^9, cos to d^8: remainders < 3e-19 for |d| <= 2^-4) instead of a full sincos -- 14 instead of ~45
