@@ -18,8 +18,8 @@
 //   * the covariance lives in the OUTPUT layout of the instruction, lane (r, b, q) holding P[r][q] in every block b, so
 //     the scalar-measurement update (filters_smoothers.py:55-68) is three more matrix instructions and no cross-lane
 //     moves: Pp H^T by column (A = H[k], B = Pp), by row (A = Pp, B = H[k]; Pp symmetric) and S = H Pp H^T + Xi;
-//   * chol(Pf) is needed by every point: 10 entries gathered with v_readlane, factorisation replicated; the mean is
-//     replicated (four quad broadcasts of Pp H^T per step).
+//   * chol(Pf) is needed by every point: 10 entries gathered with v_readlane, factorisation replicated (as L D L^T, which
+//     keeps the square roots off the pivot-to-pivot chain); the mean is replicated (four quad broadcasts of Pp H^T per step).
 #pragma once
 #include "cgp_coop8.hpp"
 #include "cgp_coop4_sigma.hpp"
@@ -42,15 +42,15 @@ struct Sgp4LaneCoef {
 // lanes as quad broadcasts.  SPEC: without the regime branches (cgp_models.hpp:precompute_spec); ok = false where that is
 // not valid.
 template <bool SPEC, bool TWO, class DM>
-CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef& K, const Sym<4>& L, double u0, double u1, double u2,
-                           const double (&xi)[2][3], bool odd, double& z0, double& z1, bool& ok) {
+CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef& K, const Sym<4>& l, const double (&sd)[3],
+                           double u0, double u1, double u2, const double (&xi)[2][3], bool odd, double& z0, double& z1, bool& ok) {
     double x1[2], x2[2], d2[2];
-    CGP_UNROLL for (int s = 0; s < (TWO ? 2 : 1); s++) {
-        const double d0 = L(0, 0) * xi[s][0];
-        const double d1 = fma(L(1, 1), xi[s][1], L(1, 0) * xi[s][0]);
-        d2[s] = fma(L(2, 2), xi[s][2], fma(L(2, 1), xi[s][1], L(2, 0) * xi[s][0]));
-        const double d3 = fma(L(3, 2), xi[s][2], fma(L(3, 1), xi[s][1], L(3, 0) * xi[s][0]));
-        x1[s] = K.rot_lane ? u0 + d0 : d2[s];
+    CGP_UNROLL for (int s = 0; s < (TWO ? 2 : 1); s++) {                // d = L xi, L = l diag(sd) (l unit lower), xi_3 left out
+        const double xs0 = xi[s][0] * sd[0], xs1 = xi[s][1] * sd[1], xs2 = xi[s][2] * sd[2];
+        const double d1 = fma(l(1, 0), xs0, xs1);
+        d2[s] = fma(l(2, 1), xs1, fma(l(2, 0), xs0, xs2));
+        const double d3 = fma(l(3, 2), xs2, fma(l(3, 1), xs1, l(3, 0) * xs0));
+        x1[s] = K.rot_lane ? u0 + xs0 : d2[s];
         x2[s] = K.rot_lane ? u1 + d1 : d3;
     }
     typename DM::Pre pre;                                 // rho cos / sin of theta(chi_v)
@@ -69,6 +69,7 @@ CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef
 template <class DM, bool TWO>
 __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
     static_assert(DM::D == 4, "d = 4 kernel");
+    __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int64_t trial = blockIdx.x;
@@ -126,12 +127,12 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;      // block 0 stores the 16 entries: one 128-B row
-    const unsigned offm = (lane < 2) ? (unsigned)lane * 16u : kOobOffset;          // lanes 0, 1 store (m0, m1), (m2, m3)
+    const unsigned offm = (lane == 0) ? 0u : kOobOffset;                           // lane 0 stores the mean: two 16-byte stores
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
 
-    double cum = 0.0, S_l = 1.0, innov_l = 0.0;
+    double cum = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
@@ -140,18 +141,22 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
             // ---- sigma-point prediction (filters_smoothers.py:88-121)
-            Sym<4> Pr, L; Vec<4> inv;
+            Sym<4> Pr, l; double dv[4]; bool bad;
             CGP_UNROLL for (int i = 0; i < 4; i++)
                 CGP_UNROLL for (int j = 0; j <= i; j++) Pr(i, j) = readlane_f64(P, 16 * i + j);
-            cholesky<4>(Pr, L, inv);
-            const double poison = L(0, 0) - L(0, 0);                     // NaN when the factorisation failed
+            // chol(Pf) = l sqrt(diag(dv)): square roots off the pivot-to-pivot chain (cgp_coop8.hpp).  A pivot <= 0 or NaN
+            // turns its square root -- for the last one, which only enters squared, the pivot itself -- into NaN, and with
+            // it every output of this and all later steps, as the reference's NaN factor does
+            ldl_lower<4>(Pr, l, dv, bad);
+            const double sd[3] = {sqrt_fast(dv[0]), sqrt_fast(dv[1]), sqrt_fast(dv[2])};
+            const double l33sq = (dv[3] > 0.0) ? dv[3] : __builtin_nan("");
             // no branches on the way (one basic block to schedule); the rare lane outside the common regime sends the
             // wavefront through the checked forms afterwards
             bool ok;
             double z0, z1 = 0.0;
-            sgp4_mfma_fan<true, TWO>(model, R, K, L, u0, u1, u2, xi, odd, z0, z1, ok);
+            sgp4_mfma_fan<true, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0))
-                sgp4_mfma_fan<false, TWO>(model, R, K, L, u0, u1, u2, xi, odd, z0, z1, ok);
+                sgp4_mfma_fan<false, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
             double Y = mfma4x4(W[0] * z0, z0, 0.0);
             double F = mfma4x4(W[0], z0, 0.0);
             if constexpr (TWO) {
@@ -161,27 +166,33 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             Y = blk_allreduce(Y);                                        // sum_p W z_r z_q
             F = blk_allreduce(F);                                        // sum_p W z_q, in every row r
             const double f0 = dpp_f64<kQuadBcast0>(F), f1 = dpp_f64<kQuadBcast1>(F);
-            const double f2 = fma(M0, u2, M1 * u3) + poison, f3 = fma(M2, u2, M3 * u3) + poison;
+            const double f2 = fma(M0, u2, M1 * u3), f3 = fma(M2, u2, M3 * u3);
             const double Fr = fma(cr0, f0, cr1 * f1);
-            const double Pp = (fma(-Fr, mq * F, Y) + fma(L(3, 3) * L(3, 3), K1, Sig)) + poison;
+            const double Pp = fma(-Fr, mq * F, Y) + fma(l33sq, K1, Sig);
             // ---- update (filters_smoothers.py:55-68)
             const double PHc = mfma4x4(Hk, Pp, 0.0);                     // sum_k H[k] Pp[k][q]: (Pp H^T)[q] in every row
             const double PHr = mfma4x4(Pp, Hk, 0.0);                     // sum_k Pp[k][r] H[k]: (Pp H^T)[r] in every column
             const double S = mfma4x4(Hk, PHr, Xi);                       // H Pp H^T + Xi
             const double pred = fma(H3, f3, fma(H2, f2, fma(H1, f1, H0 * f0)));
             const double innov = y - pred;
-            const double rS = rcp_nr(S);
+            const double rS = rcp_nr1(S);
             P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
             const double g = rS * innov;
             u0 = fma(dpp_f64<kQuadBcast0>(PHc), g, f0);                  // mf = mp + K innov
             u1 = fma(dpp_f64<kQuadBcast1>(PHc), g, f1);
             u2 = fma(dpp_f64<kQuadBcast2>(PHc), g, f2);
             u3 = fma(dpp_f64<kQuadBcast3>(PHc), g, f3);
-            if (lane == slot) { S_l = S; innov_l = innov; }
+            park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
             wP.store(P, t * 128u + offP);
-            wm.store2(lane == 1 ? u2 : u0, lane == 1 ? u3 : u1, t * 32u + offm);
+            wm.store2(u0, u1, t * 32u + offm);
+            wm.store2(u2, u3, t * 32u + 16u + offm);
         }
-        if (want_nll) cum = nll_flush_wave(S_l, innov_l, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
