@@ -378,11 +378,18 @@ CGP_DEV void softplus_tail_lean(const Regs& R, double t, double& q_scaled, doubl
     dsp = rcp_nr1(1.0 + t);
 }
 
-// Pinned coefficients for a per-lane sigma-point fan that is evaluated without regime branches (cgp_mfma4_sigma.hpp): the
-// lean softplus above and sin / cos on the reduced range |r| <= pi/4 (Taylor to r^17 / r^16) in Estrin form -- four
-// dependent levels instead of the eight of sincos_reduced's Horner chains.
-struct FanRegs {
+// Pinned coefficients for a per-lane sigma-point fan that is evaluated without regime branches (cgp_mfma4_sigma.hpp,
+// cgp_mfma4_cd.hpp): the lean softplus above (SoftplusRegs) and, for the discrete model's rotation, sin / cos on the
+// reduced range |r| <= pi/4 (Taylor to r^17 / r^16) in Estrin form -- four dependent levels instead of the eight of
+// sincos_reduced's Horner chains (FanRegs).
+struct SoftplusRegs {
     double ex[8], lq[8], log2e, ln2hi, ln2lo;
+    CGP_DEV void init() {
+        CGP_UNROLL for (int i = 0; i < 8; i++) { ex[i] = FastMathRegs::pin(kExpLean[i]); lq[i] = FastMathRegs::pin(kLog1pOverTLean[i]); }
+        log2e = FastMathRegs::pin(kLog2e); ln2hi = FastMathRegs::pin(kLn2Hi); ln2lo = FastMathRegs::pin(kLn2Lo);
+    }
+};
+struct FanRegs : SoftplusRegs {
     double sn[8];       // -1/17!, 1/15!, ..., 1/3!
     double cs[7];       // 1/16!, -1/14!, ..., 1/4!
     CGP_DEV void init() {
@@ -390,10 +397,9 @@ struct FanRegs {
                                -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
         const double cs_[7] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0,
                                1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0};
-        CGP_UNROLL for (int i = 0; i < 8; i++) { ex[i] = FastMathRegs::pin(kExpLean[i]); lq[i] = FastMathRegs::pin(kLog1pOverTLean[i]); }
+        SoftplusRegs::init();
         CGP_UNROLL for (int i = 0; i < 8; i++) sn[i] = FastMathRegs::pin(sn_[i]);
         CGP_UNROLL for (int i = 0; i < 7; i++) cs[i] = FastMathRegs::pin(cs_[i]);
-        log2e = FastMathRegs::pin(kLog2e); ln2hi = FastMathRegs::pin(kLn2Hi); ln2lo = FastMathRegs::pin(kLn2Lo);
     }
 };
 CGP_DEV void sincos_reduced(const FanRegs& R, double r, double& s0, double& c0) {

@@ -5,12 +5,18 @@ namespace cgp {
 int dispatch_filter_coop4(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     return ((io.flags & CGP_DPP_KERNEL) || !ekf4_mfma_fits(io)) ? launch_ekf4_coop(io, ma, st) : dispatch_filter_mfma4(io, ma, st);
 }
+// the matrix-core sigma-point kernels take collapsible sets of at most 32 groups whose output windows fit a raw buffer
+// (cgp_mfma4_sigma.hpp:sgp4_mfma_fits); CGP_DPP_KERNEL keeps the LDS-reduced cooperative kernels
+static bool sigma_mfma(uint32_t flags, int64_t T, const ModelArgs& ma) { return !(flags & CGP_DPP_KERNEL) && collapsed_ok(ma) && T * 128 <= kOobMaxBytes; }
 int dispatch_filter_coop4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
-    const bool mfma = !(io.flags & CGP_DPP_KERNEL) && collapsed_ok(ma) && io.T * 128 <= kOobMaxBytes;      // cgp_mfma4_sigma.hpp:sgp4_mfma_fits
-    return mfma ? dispatch_filter_mfma4_sgp(io, ma, st) : launch_sgp4_coop<HarmonicLCD<1>>(io, ma, st);
+    return sigma_mfma(io.flags, io.T, ma) ? dispatch_filter_mfma4_sgp(io, ma, st) : launch_sgp4_coop<HarmonicLCD<1>>(io, ma, st);
 }
-int dispatch_filter_coop4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgp4_coop<HarmonicSDE<1>>(io, ma, st); }
-int dispatch_smoother_coop4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgps4_coop<HarmonicSDE<1>>(io, ma, st); }
+int dispatch_filter_coop4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    return sigma_mfma(io.flags, io.T, ma) ? dispatch_filter_mfma4_cdsgp(io, ma, st) : launch_cdsgp4_coop<HarmonicSDE<1>>(io, ma, st);
+}
+int dispatch_smoother_coop4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    return sigma_mfma(io.flags, io.T, ma) ? dispatch_smoother_mfma4_cdsgp(io, ma, st) : launch_cdsgps4_coop<HarmonicSDE<1>>(io, ma, st);
+}
 int dispatch_filter_coop4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdekf4_coop(io, ma, st); }
 int dispatch_smoother_coop4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdeks4_coop(io, ma, st); }
 }  // namespace cgp

@@ -1,0 +1,299 @@
+// cgp_mfma4_cd.hpp -- cd_sgp_filter / cd_sgp_smoother (filters_smoothers.py:534-632) for the chirp / La Scala SDE model,
+// d = 4, with the sigma-point moment ODE (filters_smoothers.py:124-137) on the float64 matrix cores (BASELINE config C4:
+// Gauss-Hermite order 3, RK4, T = 50 000).
+//
+// Same layout and fan as cgp_mfma4_sigma.hpp: the covariance one entry per lane in the OUTPUT layout of
+// v_mfma_f64_4x4x4_4b_f64 (lane (r, b, q): P[r][q]), group p = 16 s + 4 b + k evaluated by the four lanes of (k, b), the
+// softplus of a group evaluated once (lane q & 1 = s) and broadcast inside the quad, nothing through LDS.  One RK4 stage:
+//   * the collapsed quadrature of cgp_coop4_sigma.hpp:coop4_cd_sgp_rhs_collapsed.  The drift's last two components are
+//     linear, a_2 = x_3, a_3 = -g^2 x_2 - 2 g x_3, so their expectations and the columns 2, 3 of C = E[(x - m) a^T] are
+//     closed forms in (m, P): C[r][2] = P[r][3], C[r][3] = -g^2 P[r][2] - 2 g P[r][3] -- two quad broadcasts of the lane's
+//     own row.  The columns 0, 1 are sums over the groups (xi_3 drops out: a_0, a_1 do not depend on it and its mean is 0),
+//         C[r][q] = sum_p W_p d_r a_q,   d = L xi (xi_0..2),   a_0 = -lam c_0 - w c_1,  a_1 = w c_0 - lam c_1,  c = m + d,
+//     i.e. two chained matrix instructions (A = W d_r, B = a_q) plus the sum over the four blocks, and E[a_q] two more;
+//   * dP/dt = C + C^T + gamma: the transpose is one more matrix instruction (B = identity), with C + gamma riding in as its
+//     accumulator;
+//   * the smoother's  G^T P + P G  (filters_smoothers.py:615-621, G = Pf^{-1} gamma) is two chained matrix instructions on
+//     the distributed G and P (P symmetric) instead of eight cross-lane moves and eight multiply-adds.
+// A factorisation that fails (a pivot <= 0) poisons every output with NaN like the reference's NaN Cholesky factor does.
+#pragma once
+#include "cgp_mfma4_sigma.hpp"
+
+namespace cgp {
+
+// Per-lane constants of the moment ODE in the matrix-core layout.
+struct Cd4LaneCoef {
+    bool odd;                          // q & 1: the pass whose softplus this lane evaluates
+    double we[2][4];                   // W_s on the component of d the lane feeds as the A operand (lane & 3), 0 elsewhere
+    double k1, kn, kl0, kl1;           // a_q = (k1 w + kl0) c_0 + (kn w + kl1) c_1
+    double cc2, cc3;                   // closed-form columns: C[r][q] = cc2 P[r][2] + cc3 P[r][3] for q >= 2
+    double ident, gam;                 // (r == q), gamma[r][q]
+    double g2, g1;                     // -g^2, -2 g
+    CGP_DEV void init(int row, int q, const double (&W)[2], double lam, double g, double gamma_rq) {
+        odd = (q & 1) != 0;
+        CGP_UNROLL for (int s = 0; s < 2; s++) CGP_UNROLL for (int c = 0; c < 4; c++) we[s][c] = (q == c) ? W[s] : 0.0;
+        k1 = (q == 1) ? 1.0 : 0.0; kn = (q == 0) ? -1.0 : 0.0;
+        kl0 = (q == 0) ? -lam : 0.0; kl1 = (q == 1) ? -lam : 0.0;
+        g2 = -(g * g); g1 = -2.0 * g;
+        cc2 = (q == 3) ? g2 : 0.0; cc3 = (q == 2) ? 1.0 : (q == 3) ? g1 : 0.0;
+        ident = (row == q) ? 1.0 : 0.0;
+        gam = gamma_rq;
+    }
+};
+
+// The fan of one stage: B operands a_q and A operands W d_r of both passes.
+template <bool SPEC, bool TWO, class SM>
+CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp, const Sym<4>& l,
+                          const double (&sd)[3], const Vec<4>& m, double (&a)[2], double (&wd)[2], bool& ok) {
+    double c0[2], c1[2], d2[2];
+    CGP_UNROLL for (int s = 0; s < (TWO ? 2 : 1); s++) {                // d = L xi, L = l diag(sd) (l unit lower), xi_3 left out
+        const double xs0 = grp.xi[s][0] * sd[0], xs1 = grp.xi[s][1] * sd[1], xs2 = grp.xi[s][2] * sd[2];
+        const double d1 = fma(l(1, 0), xs0, xs1);
+        d2[s] = fma(l(2, 1), xs1, fma(l(2, 0), xs0, xs2));
+        const double d3 = fma(l(3, 2), xs2, fma(l(3, 1), xs1, l(3, 0) * xs0));
+        c0[s] = m.v[0] + xs0; c1[s] = m.v[1] + d1;
+        wd[s] = fma(K.we[s][3], d3, fma(K.we[s][2], d2[s], fma(K.we[s][1], d1, K.we[s][0] * xs0)));   // W d_r: a select as arithmetic
+    }
+    typename SM::Pre pre;
+    const double uv = m.v[2] + ((TWO && K.odd) ? d2[1] : d2[0]);
+    if constexpr (SPEC) model.precompute_spec(R, uv, pre, ok);
+    else { model.precompute(uv, pre); ok = true; }
+    const double w0 = TWO ? dpp_f64<kQuadBcast0>(pre.w) : pre.w;
+    a[0] = fma(fma(K.k1, w0, K.kl0), c0[0], fma(K.kn, w0, K.kl1) * c1[0]);
+    if constexpr (TWO) {
+        const double w1 = dpp_f64<kQuadBcast1>(pre.w);
+        a[1] = fma(fma(K.k1, w1, K.kl0), c0[1], fma(K.kn, w1, K.kl1) * c1[1]);
+    }
+}
+
+// One evaluation of the sigma-point moment ODE at (m replicated, P distributed): km = E[a] (replicated) and the lane's
+// entry of C + C^T + gamma.
+template <bool TWO, class SM>
+CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp,
+                          const Vec<4>& m, double P, Vec<4>& km, double& kP) {
+    Sym<4> l; double sd[3], dv[4];
+    mfma4_factor(P, l, sd, dv);
+    const double worst = fmin(fmin(dv[0], dv[1]), fmin(dv[2], dv[3]));
+    const double poison = (worst > 0.0) ? 0.0 : __builtin_nan("");      // NaN pivots reach the outputs on their own
+    double a[2], wd[2]; bool ok;
+    cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m, a, wd, ok);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) cd4_mfma_fan<false, TWO>(model, R, K, grp, l, sd, m, a, wd, ok);
+    double C = mfma4x4(wd[0], a[0], 0.0);
+    double F = mfma4x4(grp.W[0], a[0], 0.0);
+    if constexpr (TWO) {
+        C = mfma4x4(wd[1], a[1], C);
+        F = mfma4x4(grp.W[1], a[1], F);
+    }
+    C = blk_allreduce(C);                                                // sum_p W d_r a_q   (columns 0, 1; zero elsewhere)
+    F = blk_allreduce(F) + poison;                                       // sum_p W a_q, in every row
+    km.v[0] = dpp_f64<kQuadBcast0>(F); km.v[1] = dpp_f64<kQuadBcast1>(F);
+    km.v[2] = m.v[3] + poison;
+    km.v[3] = fma(K.g2, m.v[2], K.g1 * m.v[3]) + poison;
+    const double P2 = dpp_f64<kQuadBcast2>(P), P3 = dpp_f64<kQuadBcast3>(P);      // P[r][2], P[r][3]
+    const double Cf = (C + fma(K.cc2, P2, K.cc3 * P3)) + poison;
+    kP = mfma4x4(Cf, K.ident, Cf + K.gam);                               // C^T + (C + gamma)
+}
+
+// Scalar-measurement update (filters_smoothers.py:55-68) in the matrix-core layout: three matrix instructions (see
+// cgp_mfma4_sigma.hpp); the mean is replicated.
+CGP_DEV void mfma4_update(double Pp, const Vec<4>& f, double Hk, const double (&H)[4], double Xi, double y,
+                          double& P, Vec<4>& u, double& S, double& innov) {
+    const double PHc = mfma4x4(Hk, Pp, 0.0);                             // (Pp H^T)[q] in every row
+    const double PHr = mfma4x4(Pp, Hk, 0.0);                             // (Pp H^T)[r] in every column
+    S = mfma4x4(Hk, PHr, Xi);                                            // H Pp H^T + Xi
+    const double pred = fma(H[3], f.v[3], fma(H[2], f.v[2], fma(H[1], f.v[1], H[0] * f.v[0])));
+    innov = y - pred;
+    const double rS = rcp_nr1(S);
+    P = fma(-(PHr * rS), PHc, Pp);                                       // Pf = Pp - K (Pp H)^T
+    const double g = rS * innov;
+    u.v[0] = fma(dpp_f64<kQuadBcast0>(PHc), g, f.v[0]);                  // mf = mp + K innov
+    u.v[1] = fma(dpp_f64<kQuadBcast1>(PHc), g, f.v[1]);
+    u.v[2] = fma(dpp_f64<kQuadBcast2>(PHc), g, f.v[2]);
+    u.v[3] = fma(dpp_f64<kQuadBcast3>(PHc), g, f.v[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
+template <class SM, bool TWO>
+__global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    static_assert(SM::D == 4, "d = 4 kernel");
+    __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    SM model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    model.wide = true;
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, 4);
+    Fan4Groups grp;
+    grp.template load<TWO>(sg, r, b);
+    Cd4LaneCoef K;
+    K.init(r, q, grp.W, model.lam, model.gam, coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, r, q));
+    SoftplusRegs R;
+    R.init();
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double H[4] = {Hp[0], Hp[1], Hp[2], Hp[3]};
+    const double Hk = Hp[r];                                             // H[k] for the lane's k = lane >> 4, as A or B operand
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    const double dt = ma.dt;
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    Vec<4> u;
+    u.v[0] = m0p[0]; u.v[1] = m0p[1]; u.v[2] = m0p[2]; u.v[3] = m0p[3];
+    double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    OobWindow wP, wm;
+    wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
+    wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
+    const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;      // block 0 stores the 16 entries: one 128-B row
+    const unsigned offm = (lane == 0) ? 0u : kOobOffset;                           // lane 0 stores the mean: two 16-byte stores
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+
+    double cum = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const unsigned t = (unsigned)(t0 + slot);
+            const double y = readlane_f64(ychunk, slot);
+            // ---- RK4 on (m, P) (quadratures.py:34-54), same operation order as cgp_steps.hpp:rk4_m_cov
+            Vec<4> tm = u, am, km, f;
+            double tP = P, aP = 0.0, kP;
+            CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                cd4_mfma_rhs<TWO>(model, R, K, grp, tm, tP, km, kP);
+                const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+                const double half = (stage == 2) ? 1.0 : 0.5;
+                CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = u.v[i] + (dt * km.v[i]) * half; }
+                aP = fma(wgt, kP, aP);
+                tP = P + (dt * kP) * half;
+            }
+            CGP_UNROLL for (int i = 0; i < 4; i++) f.v[i] = u.v[i] + (dt * am.v[i]) / 6.0;
+            const double Pp = P + (dt * aP) / 6.0;
+            // ---- update
+            double S, innov;
+            mfma4_update(Pp, f, Hk, H, Xi, y, P, u, S, innov);
+            park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
+            wP.store(P, t * 128u + offP);
+            wm.store2(u.v[0], u.v[1], t * 32u + offm);
+            wm.store2(u.v[2], u.v[3], t * 32u + 16u + offm);
+        }
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+// ------------------------------------------------------------------------------------------------ cd_sgp_smoother, d = 4
+// Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
+// G is constant over the four stages and computed a chunk of 64 steps at a time, lane-parallel (cgp_coop4_sigma.hpp:
+// coop4_chunk_gains); the walk reads it back from LDS both replicated (for the mean) and one entry per lane.
+template <class SM, bool TWO>
+__global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelArgs ma) {
+    static_assert(SM::D == 4, "d = 4 kernel");
+    __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    SM model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    model.wide = true;
+    SigmaSet sg = ma.sg;
+    sg.stage(dyn_lds(), lane, 64, 4);
+    Fan4Groups grp;
+    grp.template load<TWO>(sg, r, b);
+    Sym<4> gamma;
+    load_sym<4>(ma.gamma + trial * ma.gamma_stride, gamma);
+    Cd4LaneCoef K;
+    K.init(r, q, grp.W, model.lam, model.gam, coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, r, q));
+    SoftplusRegs R;
+    R.init();
+    const double dt = -ma.dt;
+
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * 4;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * 16;
+    double* __restrict__ mss = io.mss + trial * T * 4;
+    double* __restrict__ Pss = io.Pss + trial * T * 16;
+    OobWindow wP, wm;
+    wP.init(Pss, T * 128);
+    wm.init(mss, T * 32);
+    const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
+    const unsigned offm = (lane == 0) ? 0u : kOobOffset;
+
+    Vec<4> ms;
+    load_vec<4>(mfs + (T - 1) * 4, ms);
+    double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, r, q);
+    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
+    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+
+    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+        const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
+        coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);
+        for (int slot = 0; slot < nsteps; slot++) {
+            const unsigned t = (unsigned)(t_hi - slot);
+            const double* gl = gbuf + slot * kGainPitch;
+            Mat<4> PG; Vec<4> mf;
+            coop4_read_gain(gl, PG, mf);
+            const double Gd = gl[r * 4 + q];                             // G[r][q]: A operand G[k][r'], B operand G[k][q']
+
+            Vec<4> tm = ms, am, km;
+            double tP = Ps, aP = 0.0, kP;
+            CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                cd4_mfma_rhs<TWO>(model, R, K, grp, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
+                CGP_UNROLL for (int i = 0; i < 4; i++) {
+                    double s = km.v[i];
+                    CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);
+                    km.v[i] = s;                                                                    // _m + G^T (m - mf)
+                }
+                const double sym = mfma4x4(Gd, tP, mfma4x4(tP, Gd, 0.0));                           // G^T P + P G (P symmetric)
+                kP = (kP + sym) - 2.0 * K.gam;
+                const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+                const double half = (stage == 2) ? 1.0 : 0.5;
+                CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = ms.v[i] + (dt * km.v[i]) * half; }
+                aP = fma(wgt, kP, aP);
+                tP = Ps + (dt * kP) * half;
+            }
+            CGP_UNROLL for (int i = 0; i < 4; i++) ms.v[i] = ms.v[i] + (dt * am.v[i]) / 6.0;
+            Ps = Ps + (dt * aP) / 6.0;
+            wP.store(Ps, t * 128u + offP);
+            wm.store2(ms.v[0], ms.v[1], t * 32u + offm);
+            wm.store2(ms.v[2], ms.v[3], t * 32u + 16u + offm);
+        }
+        wave_lds_fence();
+    }
+}
+
+template <class SM>
+inline int launch_cdsgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (!sgp4_mfma_fits(io, ma)) return CGP_E_UNSUPPORTED;
+    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+template <class SM>
+inline int launch_cdsgps4_mfma(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (!collapsed_ok(ma) || io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
+    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace cgp

@@ -26,6 +26,36 @@
 
 namespace cgp {
 
+// The groups a lane evaluates: p = 16 s + 4 b + k, pass s = 0, 1 (the four lanes q of (k, b) share them); xi_0..2 of the
+// group's first member and its total weight, zero beyond the set's groups.
+struct Fan4Groups {
+    double xi[2][3], W[2];
+    template <bool TWO> CGP_DEV void load(const SigmaSet& sg, int k, int b) {
+        CGP_UNROLL for (int s = 0; s < 2; s++) {
+            W[s] = 0.0;
+            CGP_UNROLL for (int c = 0; c < 3; c++) xi[s][c] = 0.0;
+            const int p = 16 * s + 4 * b + k;
+            if ((s == 0 || TWO) && p < sg.groups()) {
+                const int p0 = sg.template begin<true>(p), p1 = sg.template end<true>(p);
+                CGP_UNROLL for (int c = 0; c < 3; c++) xi[s][c] = sg.template coord<true>(p0 * 4 + c);
+                for (int i = p0; i < p1; i++) W[s] += sg.template weight<true>(i);
+            }
+        }
+    }
+};
+
+// chol(P) = l sqrt(diag(dv)) for a covariance held in the matrix-core layout (lane (r, b, q): P[r][q]): 10 entries
+// gathered with v_readlane, the factorisation replicated in every lane as L D L^T -- the square roots sd = sqrt(dv_0..2)
+// stay off the pivot-to-pivot chain (cgp_coop8.hpp); dv[3] is returned as is (the collapsed quadratures use L_33 squared
+// or not at all).
+CGP_DEV void mfma4_factor(double P, Sym<4>& l, double (&sd)[3], double (&dv)[4]) {
+    Sym<4> Pr; bool bad;
+    CGP_UNROLL for (int i = 0; i < 4; i++)
+        CGP_UNROLL for (int j = 0; j <= i; j++) Pr(i, j) = readlane_f64(P, 16 * i + j);
+    ldl_lower<4>(Pr, l, dv, bad);
+    CGP_UNROLL for (int c = 0; c < 3; c++) sd[c] = sqrt_fast(dv[c]);
+}
+
 // One pass of the fan: component q of z for the lane's group, from the replicated factor and mean.  SPEC: without the
 // regime branches of the softplus and the sin / cos (cgp_models.hpp:precompute_spec), ok = false where that is not exact.
 struct Sgp4LaneCoef {
@@ -81,18 +111,10 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
     SigmaSet sg = ma.sg;
     sg.stage(dyn_lds(), lane, 64, 4);
 
-    // ---- the groups this lane evaluates: p = 16 s + 4 b + r (the four lanes q share them)
-    double xi[2][3], W[2];
-    CGP_UNROLL for (int s = 0; s < 2; s++) {
-        W[s] = 0.0;
-        CGP_UNROLL for (int c = 0; c < 3; c++) xi[s][c] = 0.0;
-        const int p = 16 * s + 4 * b + r;
-        if ((s == 0 || TWO) && p < sg.groups()) {
-            const int p0 = sg.template begin<true>(p), p1 = sg.template end<true>(p);
-            CGP_UNROLL for (int c = 0; c < 3; c++) xi[s][c] = sg.template coord<true>(p0 * 4 + c);
-            for (int k = p0; k < p1; k++) W[s] += sg.template weight<true>(k);
-        }
-    }
+    Fan4Groups grp;
+    grp.template load<TWO>(sg, r, b);
+    const double (&xi)[2][3] = grp.xi;
+    const double (&W)[2] = grp.W;
 
     // ---- per-lane constants
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
@@ -141,14 +163,10 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
             // ---- sigma-point prediction (filters_smoothers.py:88-121)
-            Sym<4> Pr, l; double dv[4]; bool bad;
-            CGP_UNROLL for (int i = 0; i < 4; i++)
-                CGP_UNROLL for (int j = 0; j <= i; j++) Pr(i, j) = readlane_f64(P, 16 * i + j);
-            // chol(Pf) = l sqrt(diag(dv)): square roots off the pivot-to-pivot chain (cgp_coop8.hpp).  A pivot <= 0 or NaN
-            // turns its square root -- for the last one, which only enters squared, the pivot itself -- into NaN, and with
-            // it every output of this and all later steps, as the reference's NaN factor does
-            ldl_lower<4>(Pr, l, dv, bad);
-            const double sd[3] = {sqrt_fast(dv[0]), sqrt_fast(dv[1]), sqrt_fast(dv[2])};
+            // A pivot <= 0 or NaN turns its square root -- for the last one, which only enters squared, the pivot itself --
+            // into NaN, and with it every output of this and all later steps, as the reference's NaN factor does
+            Sym<4> l; double sd[3], dv[4];
+            mfma4_factor(P, l, sd, dv);
             const double l33sq = (dv[3] > 0.0) ? dv[3] : __builtin_nan("");
             // no branches on the way (one basic block to schedule); the rare lane outside the common regime sends the
             // wavefront through the checked forms afterwards

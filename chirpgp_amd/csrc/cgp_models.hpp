@@ -309,6 +309,15 @@ template <int NH> struct HarmonicSDE {
     static constexpr int IVC = IV;
     struct Pre { double w; };
     CGP_DEV void precompute(double uv, Pre& p) const { p.w = (kTwoPi * softplus_sel(wide, uv)) * fs; }
+    // precompute() without the regime branch and with pinned coefficients (see HarmonicLCD::precompute_spec): ok = the
+    // lane is where the lean softplus is valid, 1.5 <= uv < 700; the caller re-evaluates with precompute() otherwise.
+    CGP_DEV void precompute_spec(const SoftplusRegs& R, double uv, Pre& p, bool& ok) const {
+        const double t = exp_neg_lean(R, uv);
+        double q, unused;
+        softplus_tail_lean(R, t, q, unused);
+        p.w = (kTwoPi * fma(q, t, uv)) * fs;
+        ok = softplus_lane_common(uv);
+    }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
         Pre p;
         precompute(u.v[IV], p);
