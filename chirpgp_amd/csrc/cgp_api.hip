@@ -183,7 +183,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
         else if (method == CGP_F_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4_sgp(io, ma, st);
         else if (method == CGP_F_EKF && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && (model->n_harm == 2 || model->n_harm == 3))
             rc = dispatch_filter_coop8_ekf(model->n_harm, io, ma, st);
-        else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, ma))
+        else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, io.T, ma))
             rc = dispatch_filter_coop8_sgp(model->n_harm, io, ma, st);
         else rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st);
         break;

@@ -116,7 +116,7 @@ template <int NH>
 __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma) {
     constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
     static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
-    __shared__ __attribute__((aligned(16))) double pbuf[64 + 8];       // the covariance row-major (pitch 8) and the mean
+    __shared__ __attribute__((aligned(16))) double pbuf[64 + 8 + 64];  // the covariance row-major (pitch 8), the mean, a dump for the lanes without a mean entry
     __shared__ double2 park[64];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     const double Ma = lin_i ? model.M[2 * (i - V)] : 0.0, Mb = lin_i ? model.M[2 * (i - V) + 1] : 0.0;
     const bool entry = i < D && j < D;
     const bool mean_lane = (J == 0 && q == 0 && i < D);
+    const int mslot = mean_lane ? 64 + i : 72 + lane;
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
@@ -173,6 +174,14 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
     const double IDENT = (r == q) ? 1.0 : 0.0;                           // per block: A^T B with B = identity transposes A
+    FanRegs R;
+    R.init();
+    // outputs as raw buffer windows: which lanes store is an offset, not a branch (cgp_coop4.hpp:OobWindow)
+    OobWindow wP, wm;
+    wP.init(Pfs, T * (D * D * 8));
+    wm.init(mfs, T * (D * 8));
+    const unsigned offP = entry ? (unsigned)(i * D + j) * 8u : kOobOffset;
+    const unsigned offm = mean_lane ? (unsigned)i * 8u : kOobOffset;
 
     double cum = 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -180,11 +189,11 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         for (int slot = 0; slot < nsteps; slot++) {
-            const int64_t t = t0 + slot;
+            const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
             // ---- distributed (Pf, mf) -> every lane: through LDS, read back as broadcasts
             pbuf[i * 8 + j] = P;
-            if (mean_lane) pbuf[64 + i] = mrow;
+            pbuf[mslot] = mrow;                                          // the lanes without a mean entry write to their dump slot: no branch
             wave_lds_fence();
             Sym<D> Pr; Vec<D> m;
             CGP_UNROLL for (int a = 0; a < D; a++) {
@@ -212,8 +221,12 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
                 CGP_UNROLL for (int c = 0; c < (a <= D - 2 ? a : D - 1); c++) s = fma(l(a, c), xs[c], s);
                 dd[a] = s;
             }
+            // rho cos / sin of k theta(chi_v), k = 1..NH: without regime branches (one basic block to schedule); the rare
+            // lane outside the common regime sends the wavefront through the checked form afterwards
             typename HarmonicLCD<NH>::Pre pre;
-            model.precompute(m.v[V] + dd[V], pre);                      // rho cos / sin of k theta(chi_v), k = 1..NH
+            bool ok;
+            model.precompute_spec(R, m.v[V] + dd[V], pre, ok);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) model.precompute(m.v[V] + dd[V], pre);
             double gg[NL];
             CGP_UNROLL for (int k = 0; k < NH; k++) {
                 const double h0 = m.v[2 * k] + dd[2 * k], h1 = m.v[2 * k + 1] + dd[2 * k + 1];
@@ -227,14 +240,17 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             double A1;
             if constexpr (NH == 3) A1 = (q == 0) ? gg[4] : (q == 1) ? gg[5] : (q == 2) ? e0 : e1;
             else A1 = (q == 0) ? e0 : (q == 1) ? e1 : 0.0;
-            const double B0 = W * A0, B1 = W * A1;
-            // ---- G W G^T by tiles, row sums in row and column form
-            const double T00 = blk_allreduce(mfma4x4(A0, B0, 0.0)), T01 = blk_allreduce(mfma4x4(A0, B1, 0.0));
-            const double T10 = blk_allreduce(mfma4x4(A1, B0, 0.0)), T11 = blk_allreduce(mfma4x4(A1, B1, 0.0));
-            const double R0 = blk_allreduce(mfma4x4(A0, W, 0.0)), R1 = blk_allreduce(mfma4x4(A1, W, 0.0));        // sum W G[4 X + r], every q
-            const double C0 = mfma4x4(R0, IDENT, 0.0), C1 = mfma4x4(R1, IDENT, 0.0);                              // the same sums by column: [r][q] <- [q][r]
-            const double Tt = (b == 0) ? T00 : (b == 1) ? T01 : (b == 2) ? T10 : T11;
-            const double S1r = I ? R1 : R0, S1c = J ? C1 : C0;
+            // ---- G W G^T by tiles, row sums in row and column form.  Block (I, J) wants tile (I, J) summed over the points
+            // of ALL four blocks.  Instead of four all-reduced tiles and a select, the tile each partner needs is picked on
+            // the OPERANDS -- "mine" (A_I, B_J) or "the partner's" (A_{I^1}, B_{J^1}) -- so the sum is a reduce-scatter:
+            //     tile = [mine x mine] + xor2[other x mine] + xor1([mine x other] + xor2[other x other])
+            const double AI = I ? A1 : A0, AIx = I ? A0 : A1;
+            const double BJ = W * (J ? A1 : A0), BJx = W * (J ? A0 : A1);
+            const double Tt = (mfma4x4(AI, BJ, 0.0) + blk_xor2(mfma4x4(AIx, BJ, 0.0)))
+                            + blk_xor1(mfma4x4(AI, BJx, 0.0) + blk_xor2(mfma4x4(AIx, BJx, 0.0)));
+            const double Rh = mfma4x4(AI, W, 0.0) + blk_xor2(mfma4x4(AIx, W, 0.0));
+            const double S1r = Rh + blk_xor1(Rh);                                    // sum W G[4 I + r], every q
+            const double S1c = mfma4x4(blk_swap12(S1r), IDENT, 0.0);                 // sum W G[4 J + q], every r: [r][q] <- [q][r] of row block J
             // ---- predicted moments in tile layout / row form
             const double Pp = fma(-S1r, S1c, Tt) + fma(dv[D - 1], K1, Sig);
             const double mp = S1r + (fma(Ma, m.v[V], Mb * m.v[V + 1]) + poison);
@@ -242,8 +258,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             double S, innov;
             coop8_update(Pp, mp, HR, HC, XiC, y, P, mrow, S, innov);
             park[slot] = make_double2(S, innov);
-            if (Pfs && entry) Pfs[t * (D * D) + i * D + j] = P;
-            if (mfs && mean_lane) mfs[t * D + i] = mrow;
+            wP.store(P, t * (unsigned)(D * D * 8) + offP);
+            wm.store(mrow, t * (unsigned)(D * 8) + offm);
         }
         if (want_nll) {
             wave_lds_fence();
@@ -380,6 +396,7 @@ inline bool coop8_sigma_ok(const ModelArgs& ma) {
 template <int NH>
 inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (io.T * ((2 * NH + 2) * (2 * NH + 2) * 8) > kOobMaxBytes) return CGP_E_UNSUPPORTED;        // output windows (OobWindow)
     hipLaunchKernelGGL((sgp8_coop_kernel<NH>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
     return hip_rc(hipGetLastError());
 }

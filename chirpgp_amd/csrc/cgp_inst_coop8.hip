@@ -2,7 +2,11 @@
 #define CGP_COOP4_HELPERS_ONLY
 #include "cgp_coop8.hpp"
 namespace cgp {
-bool coop8_filter_sgp_ok(int n_harm, const ModelArgs& ma) { return (n_harm == 2 || n_harm == 3) && coop8_sigma_ok(ma); }
+// the kernel stores through raw buffer windows: one trial's Pf must fit one (cgp_coop4.hpp:kOobMaxBytes)
+bool coop8_filter_sgp_ok(int n_harm, int64_t T, const ModelArgs& ma) {
+    const int64_t d = 2 * n_harm + 2;
+    return (n_harm == 2 || n_harm == 3) && coop8_sigma_ok(ma) && T * d * d * 8 <= kOobMaxBytes;
+}
 int dispatch_filter_coop8_sgp(int n_harm, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     switch (n_harm) {
     case 2: return launch_sgp8_coop<2>(io, ma, st);

@@ -454,7 +454,7 @@ int dispatch_smoother_mfma4_cdsgp(const SmootherIO&, const ModelArgs&, hipStream
 inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00ll; }
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 // d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
-bool coop8_filter_sgp_ok(int n_harm, const ModelArgs&);
+bool coop8_filter_sgp_ok(int n_harm, int64_t T, const ModelArgs&);
 int dispatch_filter_coop8_sgp(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop8_ekf(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 bool coop8_smoother_ok(int d, int64_t T, const ModelArgs&);
