@@ -538,6 +538,37 @@ def test_nan_in_one_trial_of_the_chirp_ekf(kw):
     assert not np.isnan(got[0][[0, 2, 3, 5]]).any()
 
 
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='matrix_core'), pytest.param(WAVE_DPP, id='lds_reduced')])
+def test_nan_in_the_d4_sigma_point_kernels(kw):
+    """sgp_filter / cd_sgp_filter / cd_sgp_smoother, d = 4, on the matrix-core kernels (cgp_mfma4_sigma.hpp, cgp_mfma4_cd.hpp)
+    and on the LDS-reduced ones: a NaN measurement in one record, a P0 whose FIRST pivot fails in another, and one whose
+    LAST pivot alone fails (the collapsed quadratures never take that pivot's square root: the kernels have to notice it) --
+    those trials are NaN exactly where the C port's are, the others are untouched."""
+    c = _batch_case(cs.chirp_case, 6, T=260)
+    c.ys = c.ys.copy()
+    c.ys[1, 130] = np.nan
+    P0 = np.repeat(np.asarray(c.P0)[None], 6, axis=0)
+    P0[2] = np.array([[1., 2., 0, 0], [2., 1., 0, 0], [0, 0, 1., 0], [0, 0, 0, 1.]])
+    P0[4] = np.diag([1., 1., 1., -0.5])
+    c.P0 = P0
+    only = ('sgp_filter', 'sgp_smoother', 'cd_sgp_filter', 'cd_sgp_smoother')
+    want = bk.run_pairs('port', c, only=only)
+    got = bk.run_pairs('hip', c, hip_kw=kw, only=only)
+    bk.compare(got, want, RTOL, 'nan_d4_sigma')
+    for k in ('sgp_filter', 'cd_sgp_filter'):
+        m = got[k][0]
+        assert np.isnan(m[2]).all() and np.isnan(m[4]).all() and np.isnan(m[1, 130:]).all() and not np.isnan(m[1, :130]).any()
+        assert not np.isnan(m[[0, 3, 5]]).any()
+
+
+@pytest.mark.parametrize('T', [1, 2, 63, 64, 65, 129])
+def test_ragged_lengths_cd_sigma_point(T):
+    """The 64-step chunks of the matrix-core cd_sgp filter (measurements, NLL latch) and smoother (backward gains)."""
+    c = cs.chirp_case(T=T, seed=37)
+    only = ('cd_sgp_filter', 'cd_sgp_smoother')
+    bk.compare(bk.run_pairs('hip', c, hip_kw=WAVE, only=only), bk.run_pairs('port', c, only=only), RTOL, f'cd T={T}')
+
+
 # ------------------------------------------------------------------ BASELINE config C1
 @pytest.mark.parametrize('kw', [pytest.param(WAVE, id='wave_per_trial'), pytest.param(WAVE_SEQ, id='wave_sequential_scan'),
                                 pytest.param(THREAD, id='lane_per_trial'), pytest.param({}, id='default_shape')])
