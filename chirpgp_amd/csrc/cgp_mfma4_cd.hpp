@@ -15,6 +15,10 @@
 //     accumulator;
 //   * the smoother's  G^T P + P G  (filters_smoothers.py:615-621, G = Pf^{-1} gamma) is two chained matrix instructions on
 //     the distributed G and P (P symmetric) instead of eight cross-lane moves and eight multiply-adds.
+//   * the mean lives in COLUMN form, lane (r, b, q) holding m[q]: the RK4 bookkeeping and the mean update are one
+//     instruction for all four components, E[a] comes out of the matrix instruction in that form, the fan takes m_0..3 as
+//     quad broadcasts, and the smoother's G^T (m - mf) is two matrix instructions (a transpose to row form, then A = the
+//     row form, B = G).
 // A factorisation that fails (a pivot <= 0) poisons every output with NaN like the reference's NaN Cholesky factor does.
 #pragma once
 #include "cgp_mfma4_sigma.hpp"
@@ -44,18 +48,18 @@ struct Cd4LaneCoef {
 // The fan of one stage: B operands a_q and A operands W d_r of both passes.
 template <bool SPEC, bool TWO, class SM>
 CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp, const Sym<4>& l,
-                          const double (&sd)[3], const Vec<4>& m, double (&a)[2], double (&wd)[2], bool& ok) {
+                          const double (&sd)[3], double m0, double m1, double m2, double (&a)[2], double (&wd)[2], bool& ok) {
     double c0[2], c1[2], d2[2];
     CGP_UNROLL for (int s = 0; s < (TWO ? 2 : 1); s++) {                // d = L xi, L = l diag(sd) (l unit lower), xi_3 left out
         const double xs0 = grp.xi[s][0] * sd[0], xs1 = grp.xi[s][1] * sd[1], xs2 = grp.xi[s][2] * sd[2];
         const double d1 = fma(l(1, 0), xs0, xs1);
         d2[s] = fma(l(2, 1), xs1, fma(l(2, 0), xs0, xs2));
         const double d3 = fma(l(3, 2), xs2, fma(l(3, 1), xs1, l(3, 0) * xs0));
-        c0[s] = m.v[0] + xs0; c1[s] = m.v[1] + d1;
+        c0[s] = m0 + xs0; c1[s] = m1 + d1;
         wd[s] = fma(K.we[s][3], d3, fma(K.we[s][2], d2[s], fma(K.we[s][1], d1, K.we[s][0] * xs0)));   // W d_r: a select as arithmetic
     }
     typename SM::Pre pre;
-    const double uv = m.v[2] + ((TWO && K.odd) ? d2[1] : d2[0]);
+    const double uv = m2 + ((TWO && K.odd) ? d2[1] : d2[0]);
     if constexpr (SPEC) model.precompute_spec(R, uv, pre, ok);
     else { model.precompute(uv, pre); ok = true; }
     const double w0 = TWO ? dpp_f64<kQuadBcast0>(pre.w) : pre.w;
@@ -66,18 +70,19 @@ CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneC
     }
 }
 
-// One evaluation of the sigma-point moment ODE at (m replicated, P distributed): km = E[a] (replicated) and the lane's
-// entry of C + C^T + gamma.
+// One evaluation of the sigma-point moment ODE at (m in column form, P distributed): km = E[a] in column form and the
+// lane's entry of C + C^T + gamma.
 template <bool TWO, class SM>
 CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp,
-                          const Vec<4>& m, double P, Vec<4>& km, double& kP) {
+                          double mcol, double P, double& kmcol, double& kP) {
     Sym<4> l; double sd[3], dv[4];
     mfma4_factor(P, l, sd, dv);
     const double worst = fmin(fmin(dv[0], dv[1]), fmin(dv[2], dv[3]));
     const double poison = (worst > 0.0) ? 0.0 : __builtin_nan("");      // NaN pivots reach the outputs on their own
+    const double m0 = dpp_f64<kQuadBcast0>(mcol), m1 = dpp_f64<kQuadBcast1>(mcol), m2 = dpp_f64<kQuadBcast2>(mcol), m3 = dpp_f64<kQuadBcast3>(mcol);
     double a[2], wd[2]; bool ok;
-    cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m, a, wd, ok);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) cd4_mfma_fan<false, TWO>(model, R, K, grp, l, sd, m, a, wd, ok);
+    cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) cd4_mfma_fan<false, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
     double C = mfma4x4(wd[0], a[0], 0.0);
     double F = mfma4x4(grp.W[0], a[0], 0.0);
     if constexpr (TWO) {
@@ -85,31 +90,27 @@ CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneC
         F = mfma4x4(grp.W[1], a[1], F);
     }
     C = blk_allreduce(C);                                                // sum_p W d_r a_q   (columns 0, 1; zero elsewhere)
-    F = blk_allreduce(F) + poison;                                       // sum_p W a_q, in every row
-    km.v[0] = dpp_f64<kQuadBcast0>(F); km.v[1] = dpp_f64<kQuadBcast1>(F);
-    km.v[2] = m.v[3] + poison;
-    km.v[3] = fma(K.g2, m.v[2], K.g1 * m.v[3]) + poison;
+    F = blk_allreduce(F) + poison;                                       // sum_p W a_q, in every row (zero for q >= 2)
+    kmcol = fma(K.cc2, m2, fma(K.cc3, m3, F));                           // E[a_2] = m_3, E[a_3] = -g^2 m_2 - 2 g m_3: the closed-form columns' coefficients
     const double P2 = dpp_f64<kQuadBcast2>(P), P3 = dpp_f64<kQuadBcast3>(P);      // P[r][2], P[r][3]
     const double Cf = (C + fma(K.cc2, P2, K.cc3 * P3)) + poison;
     kP = mfma4x4(Cf, K.ident, Cf + K.gam);                               // C^T + (C + gamma)
 }
 
 // Scalar-measurement update (filters_smoothers.py:55-68) in the matrix-core layout: three matrix instructions (see
-// cgp_mfma4_sigma.hpp); the mean is replicated.
-CGP_DEV void mfma4_update(double Pp, const Vec<4>& f, double Hk, const double (&H)[4], double Xi, double y,
-                          double& P, Vec<4>& u, double& S, double& innov) {
+// cgp_mfma4_sigma.hpp); the mean in column form (Hq = H[q]: H f is a sum over the quad).
+CGP_DEV void mfma4_update_col(double Pp, double fcol, double Hk, double Hq, double Xi, double y,
+                              double& P, double& ucol, double& S, double& innov) {
     const double PHc = mfma4x4(Hk, Pp, 0.0);                             // (Pp H^T)[q] in every row
     const double PHr = mfma4x4(Pp, Hk, 0.0);                             // (Pp H^T)[r] in every column
     S = mfma4x4(Hk, PHr, Xi);                                            // H Pp H^T + Xi
-    const double pred = fma(H[3], f.v[3], fma(H[2], f.v[2], fma(H[1], f.v[1], H[0] * f.v[0])));
+    double pred = Hq * fcol;
+    pred += dpp_f64<kQuadSwap1>(pred);
+    pred += dpp_f64<kQuadSwap2>(pred);
     innov = y - pred;
     const double rS = rcp_nr1(S);
     P = fma(-(PHr * rS), PHc, Pp);                                       // Pf = Pp - K (Pp H)^T
-    const double g = rS * innov;
-    u.v[0] = fma(dpp_f64<kQuadBcast0>(PHc), g, f.v[0]);                  // mf = mp + K innov
-    u.v[1] = fma(dpp_f64<kQuadBcast1>(PHc), g, f.v[1]);
-    u.v[2] = fma(dpp_f64<kQuadBcast2>(PHc), g, f.v[2]);
-    u.v[3] = fma(dpp_f64<kQuadBcast3>(PHc), g, f.v[3]);
+    ucol = fma(PHc, rS * innov, fcol);                                   // mf = mp + K innov
 }
 
 // ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
@@ -134,14 +135,11 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     SoftplusRegs R;
     R.init();
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
-    const double H[4] = {Hp[0], Hp[1], Hp[2], Hp[3]};
-    const double Hk = Hp[r];                                             // H[k] for the lane's k = lane >> 4, as A or B operand
+    const double Hk = Hp[r], Hq = Hp[q];                                 // H[k] for the lane's k = lane >> 4 (A or B operand); H[q]
     const double Xi = io.Xi[trial * io.Xi_stride];
     const double dt = ma.dt;
 
-    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
-    Vec<4> u;
-    u.v[0] = m0p[0]; u.v[1] = m0p[1]; u.v[2] = m0p[2]; u.v[3] = m0p[3];
+    double u = io.m0[trial * io.m0_stride + q];                          // the mean in column form
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
     const int64_t T = io.T;
     const double* __restrict__ ys = io.ys + trial * T;
@@ -149,7 +147,7 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;      // block 0 stores the 16 entries: one 128-B row
-    const unsigned offm = (lane == 0) ? 0u : kOobOffset;                           // lane 0 stores the mean: two 16-byte stores
+    const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;           // lanes 0..3 store the mean
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
@@ -163,27 +161,24 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
             const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
             // ---- RK4 on (m, P) (quadratures.py:34-54), same operation order as cgp_steps.hpp:rk4_m_cov
-            Vec<4> tm = u, am, km, f;
-            double tP = P, aP = 0.0, kP;
-            CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+            double tm = u, am = 0.0, km, tP = P, aP = 0.0, kP;
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 cd4_mfma_rhs<TWO>(model, R, K, grp, tm, tP, km, kP);
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
                 const double half = (stage == 2) ? 1.0 : 0.5;
-                CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = u.v[i] + (dt * km.v[i]) * half; }
+                am = fma(wgt, km, am); tm = u + (dt * km) * half;
                 aP = fma(wgt, kP, aP);
                 tP = P + (dt * kP) * half;
             }
-            CGP_UNROLL for (int i = 0; i < 4; i++) f.v[i] = u.v[i] + (dt * am.v[i]) / 6.0;
+            const double f = u + (dt * am) / 6.0;
             const double Pp = P + (dt * aP) / 6.0;
             // ---- update
             double S, innov;
-            mfma4_update(Pp, f, Hk, H, Xi, y, P, u, S, innov);
+            mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
             wP.store(P, t * 128u + offP);
-            wm.store2(u.v[0], u.v[1], t * 32u + offm);
-            wm.store2(u.v[2], u.v[3], t * 32u + 16u + offm);
+            wm.store(u, t * 32u + offm);
         }
         if (want_nll) {
             wave_lds_fence();
@@ -198,7 +193,7 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
 // ------------------------------------------------------------------------------------------------ cd_sgp_smoother, d = 4
 // Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
 // G is constant over the four stages and computed a chunk of 64 steps at a time, lane-parallel (cgp_coop4_sigma.hpp:
-// coop4_chunk_gains); the walk reads it back from LDS both replicated (for the mean) and one entry per lane.
+// coop4_chunk_gains); the walk reads it back from LDS one entry per lane, and mf in column form.
 template <class SM, bool TWO>
 __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
@@ -232,10 +227,9 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
     wP.init(Pss, T * 128);
     wm.init(mss, T * 32);
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
-    const unsigned offm = (lane == 0) ? 0u : kOobOffset;
+    const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
 
-    Vec<4> ms;
-    load_vec<4>(mfs + (T - 1) * 4, ms);
+    double ms = mfs[(T - 1) * 4 + q];                                    // the mean in column form
     double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, r, q);
     if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
     if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
@@ -246,34 +240,27 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
         for (int slot = 0; slot < nsteps; slot++) {
             const unsigned t = (unsigned)(t_hi - slot);
             const double* gl = gbuf + slot * kGainPitch;
-            Mat<4> PG; Vec<4> mf;
-            coop4_read_gain(gl, PG, mf);
             const double Gd = gl[r * 4 + q];                             // G[r][q]: A operand G[k][r'], B operand G[k][q']
+            const double mf = gl[16 + q];
 
-            Vec<4> tm = ms, am, km;
-            double tP = Ps, aP = 0.0, kP;
-            CGP_UNROLL for (int i = 0; i < 4; i++) am.v[i] = 0.0;
+            double tm = ms, am = 0.0, km, tP = Ps, aP = 0.0, kP;
 #pragma unroll 1
             for (int stage = 0; stage < 4; stage++) {
                 cd4_mfma_rhs<TWO>(model, R, K, grp, tm, tP, km, kP);    // (_m, _P), _P includes + gamma
-                CGP_UNROLL for (int i = 0; i < 4; i++) {
-                    double s = km.v[i];
-                    CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(PG.a[k][i], tm.v[k] - mf.v[k], s);
-                    km.v[i] = s;                                                                    // _m + G^T (m - mf)
-                }
+                const double drow = mfma4x4(tm - mf, K.ident, 0.0);     // m - mf from column to row form: [r][q] <- [q][r]
+                km = mfma4x4(drow, Gd, km);                             // _m + G^T (m - mf): sum_k (m - mf)[k] G[k][q]
                 const double sym = mfma4x4(Gd, tP, mfma4x4(tP, Gd, 0.0));                           // G^T P + P G (P symmetric)
                 kP = (kP + sym) - 2.0 * K.gam;
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
                 const double half = (stage == 2) ? 1.0 : 0.5;
-                CGP_UNROLL for (int i = 0; i < 4; i++) { am.v[i] = fma(wgt, km.v[i], am.v[i]); tm.v[i] = ms.v[i] + (dt * km.v[i]) * half; }
+                am = fma(wgt, km, am); tm = ms + (dt * km) * half;
                 aP = fma(wgt, kP, aP);
                 tP = Ps + (dt * kP) * half;
             }
-            CGP_UNROLL for (int i = 0; i < 4; i++) ms.v[i] = ms.v[i] + (dt * am.v[i]) / 6.0;
+            ms = ms + (dt * am) / 6.0;
             Ps = Ps + (dt * aP) / 6.0;
             wP.store(Ps, t * 128u + offP);
-            wm.store2(ms.v[0], ms.v[1], t * 32u + offm);
-            wm.store2(ms.v[2], ms.v[3], t * 32u + 16u + offm);
+            wm.store(ms, t * 32u + offm);
         }
         wave_lds_fence();
     }
