@@ -417,7 +417,8 @@ CGP_DEV void sincos_reduced(const FanRegs& R, double r, double& s0, double& c0) 
 
 // The wave-uniform pair with the lean polynomials (regime [1.5, 700), 7e-12 / 1.2e-11; see "the speculative EKF step's
 // softplus" above): evaluated unconditionally, the regime test is a scalar compare consumed by a rarely-taken branch at the end.
-CGP_DEV void softplus_pair_uniform(const SpecRegs& R, double x, double& sp, double& dsp) {
+template <class Regs>
+CGP_DEV void softplus_pair_uniform_lean(const Regs& R, double x, double& sp, double& dsp) {
     const unsigned hx = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
     const bool common = (hx - 0x3FF80000u) < (0x4085E000u - 0x3FF80000u);
     const double t = exp_neg_lean(R, x);
@@ -431,6 +432,8 @@ CGP_DEV void softplus_pair_uniform(const SpecRegs& R, double x, double& sp, doub
         dsp = e * rcp_nr(z);
     }
 }
+CGP_DEV void softplus_pair_uniform(const SpecRegs& R, double x, double& sp, double& dsp) { softplus_pair_uniform_lean(R, x, sp, dsp); }
+CGP_DEV void softplus_pair_uniform(const SoftplusRegs& R, double x, double& sp, double& dsp) { softplus_pair_uniform_lean(R, x, sp, dsp); }
 CGP_DEV void softplus_pair_uniform(const FastMathRegs& R, double x, double& sp, double& dsp) {
     const bool common = softplus_common_regime(x);
     softplus_from_exp_neg(R, x, exp_neg_common(R, x), sp, dsp);

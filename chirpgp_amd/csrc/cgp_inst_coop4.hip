@@ -17,6 +17,10 @@ int dispatch_filter_coop4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStre
 int dispatch_smoother_coop4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
     return sigma_mfma(io.flags, io.T, ma) ? dispatch_smoother_mfma4_cdsgp(io, ma, st) : launch_cdsgps4_coop<HarmonicSDE<1>>(io, ma, st);
 }
-int dispatch_filter_coop4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdekf4_coop(io, ma, st); }
-int dispatch_smoother_coop4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdeks4_coop(io, ma, st); }
+int dispatch_filter_coop4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    return (!(io.flags & CGP_DPP_KERNEL) && io.T * 128 <= kOobMaxBytes) ? dispatch_filter_mfma4_cdekf(io, ma, st) : launch_cdekf4_coop(io, ma, st);
+}
+int dispatch_smoother_coop4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    return (!(io.flags & CGP_DPP_KERNEL) && io.T * 128 <= kOobMaxBytes) ? dispatch_smoother_mfma4_cdeks(io, ma, st) : launch_cdeks4_coop(io, ma, st);
+}
 }  // namespace cgp

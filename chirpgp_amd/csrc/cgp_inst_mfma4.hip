@@ -1,5 +1,5 @@
-// The matrix-core d = 4 kernels -- EKF (cgp_mfma4.hpp), sigma-point filter (cgp_mfma4_sigma.hpp), continuous-discrete
-// sigma-point filter and smoother (cgp_mfma4_cd.hpp) -- in their own translation unit: it is compiled with the max-ILP scheduling strategy and VGPR-form MFMA results (Makefile), which suit
+// The matrix-core d = 4 kernels -- EKF (cgp_mfma4.hpp), sigma-point filter (cgp_mfma4_sigma.hpp), the continuous-discrete
+// filters and smoothers (cgp_mfma4_cd.hpp) -- in their own translation unit: it is compiled with the max-ILP scheduling strategy and VGPR-form MFMA results (Makefile), which suit
 // their single long dependent chain and not the other kernels.
 #define CGP_COOP4_HELPERS_ONLY
 #include "cgp_mfma4.hpp"
@@ -10,4 +10,6 @@ int dispatch_filter_mfma4(const FilterIO& io, const ModelArgs& ma, hipStream_t s
 int dispatch_filter_mfma4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_sgp4_mfma<HarmonicLCD<1>>(io, ma, st); }
 int dispatch_filter_mfma4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgp4_mfma<HarmonicSDE<1>>(io, ma, st); }
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgps4_mfma<HarmonicSDE<1>>(io, ma, st); }
+int dispatch_filter_mfma4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdekf4_mfma(io, ma, st); }
+int dispatch_smoother_mfma4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdeks4_mfma(io, ma, st); }
 }  // namespace cgp

@@ -450,6 +450,8 @@ int dispatch_filter_mfma4(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_mfma4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_mfma4_cdsgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_mfma4_cdekf(const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_mfma4_cdeks(const SmootherIO&, const ModelArgs&, hipStream_t);
 // the matrix-core EKF addresses a trial's outputs through 2 GiB buffer windows (cgp_mfma4.hpp)
 inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00ll; }
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);

@@ -266,6 +266,186 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ cd_ekf / cd_eks, d = 4
+// dm = a(m), dP = J P + P J^T + gamma (filters_smoothers.py:384-394) and the smoother's dm = a(m) + G^T (m - mf),
+// dP = A P + P A^T - gamma, A = J + G^T (filters_smoothers.py:427-438) in the same layout: the drift Jacobian
+//     J_a = [[-lam, -w, -dw u1, 0], [w, -lam, dw u0, 0], [0, 0, 0, 1], [0, 0, -g^2, -2 g]]    
+// is held TRANSPOSED, one entry per lane (lane (r, b, q): J[q][r], i.e. the A operand "J[r'][k]"), assembled from the
+// wave-uniform (w, dw) with per-lane 0 / +-1 / constant coefficients; then J P is ONE matrix instruction and
+// (J P)^T + J P + gamma another (B = identity, the accumulator carries J P + gamma).  G enters A^T as the lane's own G[r][q].
+struct Cd4JacCoef {
+    double cb, cg0, cg1, ck;           // J[q][r] = cb w + cg0 jv0 + cg1 jv1 + ck
+    CGP_DEV void init(int r, int q, double lam, double g) {
+        cb = (q == 0 && r == 1) ? -1.0 : (q == 1 && r == 0) ? 1.0 : 0.0;
+        cg0 = (q == 0 && r == 2) ? 1.0 : 0.0; cg1 = (q == 1 && r == 2) ? 1.0 : 0.0;
+        ck = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? -lam : (q == 2 && r == 3) ? 1.0 : (q == 3 && r == 2) ? -(g * g) : (q == 3 && r == 3) ? -2.0 * g : 0.0;
+    }
+};
+// a(m) in column form and the lane's entry of J^T at the mean (column form in, quad broadcasts).
+CGP_DEV void cd4_ekf_eval(const SoftplusRegs& R, const Cd4LaneCoef& K, const Cd4JacCoef& Jc, double fs, double mcol, double& acol, double& JT) {
+    const double m0 = dpp_f64<kQuadBcast0>(mcol), m1 = dpp_f64<kQuadBcast1>(mcol), m2 = dpp_f64<kQuadBcast2>(mcol), m3 = dpp_f64<kQuadBcast3>(mcol);
+    double sp, dsp;
+    softplus_pair_uniform(R, m2, sp, dsp);
+    const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
+    acol = fma(fma(K.k1, w, K.kl0), m0, fma(K.kn, w, K.kl1) * m1) + fma(K.cc2, m2, K.cc3 * m3);
+    const double jv0 = -dw * m1, jv1 = dw * m0;
+    JT = fma(Jc.cb, w, fma(Jc.cg0, jv0, fma(Jc.cg1, jv1, Jc.ck)));
+}
+
+__global__ void __launch_bounds__(64) cdekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicSDE<1> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    const double W0[2] = {0.0, 0.0};
+    Cd4LaneCoef K;
+    K.init(r, q, W0, model.lam, model.gam, coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, r, q));
+    Cd4JacCoef Jc;
+    Jc.init(r, q, model.lam, model.gam);
+    SoftplusRegs R;
+    R.init();
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double Hk = Hp[r], Hq = Hp[q];
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    const double dt = ma.dt, fs = model.fs;
+
+    double u = io.m0[trial * io.m0_stride + q];                          // the mean in column form
+    double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.ys + trial * T;
+    OobWindow wP, wm;
+    wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
+    wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
+    const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
+    const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+
+    double cum = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        for (int slot = 0; slot < nsteps; slot++) {
+            const unsigned t = (unsigned)(t0 + slot);
+            const double y = readlane_f64(ychunk, slot);
+            double tm = u, am = 0.0, tP = P, aP = 0.0;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                double km, JT;
+                cd4_ekf_eval(R, K, Jc, fs, tm, km, JT);
+                const double JP = mfma4x4(JT, tP, 0.0);                  // sum_k J[r][k] P[k][q]
+                const double kP = mfma4x4(JP, K.ident, JP + K.gam);      // (J P)^T + J P + gamma
+                const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+                const double half = (stage == 2) ? 1.0 : 0.5;
+                am = fma(wgt, km, am); tm = u + (dt * km) * half;
+                aP = fma(wgt, kP, aP);
+                tP = P + (dt * kP) * half;
+            }
+            const double f = u + (dt * am) / 6.0;
+            const double Pp = P + (dt * aP) / 6.0;
+            double S, innov;
+            mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
+            park[slot] = make_double2(S, innov);
+            wP.store(P, t * 128u + offP);
+            wm.store(u, t * 32u + offm);
+        }
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+            wave_lds_fence();
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+__global__ void __launch_bounds__(64) cdeks4_mfma_kernel(SmootherIO io, ModelArgs ma) {
+    __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+
+    HarmonicSDE<1> model;
+    model.setup(ma.params + trial * ma.param_stride, ma.model_id);
+    const double W0[2] = {0.0, 0.0};
+    Cd4LaneCoef K;
+    K.init(r, q, W0, model.lam, model.gam, coop4_load_sym_entry(ma.gamma + trial * ma.gamma_stride, r, q));
+    Cd4JacCoef Jc;
+    Jc.init(r, q, model.lam, model.gam);
+    SoftplusRegs R;
+    R.init();
+    Sym<4> gamma;
+    load_sym<4>(ma.gamma + trial * ma.gamma_stride, gamma);
+    const double dt = -ma.dt, fs = model.fs;
+
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * 4;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * 16;
+    double* __restrict__ mss = io.mss + trial * T * 4;
+    double* __restrict__ Pss = io.Pss + trial * T * 16;
+    OobWindow wP, wm;
+    wP.init(Pss, T * 128);
+    wm.init(mss, T * 32);
+    const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
+    const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
+
+    double ms = mfs[(T - 1) * 4 + q];
+    double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, r, q);
+    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
+    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+
+    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+        const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
+        coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);  // Pf^{-1} gamma of the chunk's steps, one step per lane
+        for (int slot = 0; slot < nsteps; slot++) {
+            const unsigned t = (unsigned)(t_hi - slot);
+            const double* gl = gbuf + slot * kGainPitch;
+            const double Gd = gl[r * 4 + q];                             // G[r][q] = (G^T)[q][r]: the lane's entry of A^T - J^T
+            const double mf = gl[16 + q];
+            double tm = ms, am = 0.0, tP = Ps, aP = 0.0;
+#pragma unroll 1
+            for (int stage = 0; stage < 4; stage++) {
+                double km, JT;
+                cd4_ekf_eval(R, K, Jc, fs, tm, km, JT);
+                const double drow = mfma4x4(tm - mf, K.ident, 0.0);     // m - mf from column to row form
+                km = mfma4x4(drow, Gd, km);                             // a(m) + G^T (m - mf)
+                const double AP = mfma4x4(JT + Gd, tP, 0.0);            // sum_k A[r][k] P[k][q], A = J + G^T
+                const double kP = mfma4x4(AP, K.ident, AP - K.gam);     // (A P)^T + A P - gamma
+                const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+                const double half = (stage == 2) ? 1.0 : 0.5;
+                am = fma(wgt, km, am); tm = ms + (dt * km) * half;
+                aP = fma(wgt, kP, aP);
+                tP = Ps + (dt * kP) * half;
+            }
+            ms = ms + (dt * am) / 6.0;
+            Ps = Ps + (dt * aP) / 6.0;
+            wP.store(Ps, t * 128u + offP);
+            wm.store(ms, t * 32u + offm);
+        }
+        wave_lds_fence();
+    }
+}
+
+inline int launch_cdekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(cdekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+inline int launch_cdeks4_mfma(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(cdeks4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
 template <class SM>
 inline int launch_cdsgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
