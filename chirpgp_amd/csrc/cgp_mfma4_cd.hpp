@@ -25,6 +25,9 @@
 
 namespace cgp {
 
+// RK4's "/ 6" (quadratures.py:53) as a multiplication: within an ulp of the division, a dozen instructions less per use.
+constexpr double kSixth = 1.0 / 6.0;
+
 // Per-lane constants of the moment ODE in the matrix-core layout.
 struct Cd4LaneCoef {
     bool odd;                          // q & 1: the pass whose softplus this lane evaluates
@@ -75,10 +78,12 @@ CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneC
 template <bool TWO, class SM>
 CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp,
                           double mcol, double P, double& kmcol, double& kP) {
+    // A pivot <= 0 among the first three makes its square root NaN, and through d every sum of the fan; the last pivot's
+    // root is never taken (xi_3 is left out), so its sign is checked and folded into sd[2]: C, E[a] -- all entries,
+    // their zero columns included (0 x NaN) -- and with them every output turn NaN, as the reference's NaN factor does
     Sym<4> l; double sd[3], dv[4];
     mfma4_factor(P, l, sd, dv);
-    const double worst = fmin(fmin(dv[0], dv[1]), fmin(dv[2], dv[3]));
-    const double poison = (worst > 0.0) ? 0.0 : __builtin_nan("");      // NaN pivots reach the outputs on their own
+    sd[2] += (dv[3] > 0.0) ? 0.0 : __builtin_nan("");
     const double m0 = dpp_f64<kQuadBcast0>(mcol), m1 = dpp_f64<kQuadBcast1>(mcol), m2 = dpp_f64<kQuadBcast2>(mcol), m3 = dpp_f64<kQuadBcast3>(mcol);
     double a[2], wd[2]; bool ok;
     cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
@@ -90,10 +95,10 @@ CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneC
         F = mfma4x4(grp.W[1], a[1], F);
     }
     C = blk_allreduce(C);                                                // sum_p W d_r a_q   (columns 0, 1; zero elsewhere)
-    F = blk_allreduce(F) + poison;                                       // sum_p W a_q, in every row (zero for q >= 2)
+    F = blk_allreduce(F);                                                // sum_p W a_q, in every row (zero for q >= 2)
     kmcol = fma(K.cc2, m2, fma(K.cc3, m3, F));                           // E[a_2] = m_3, E[a_3] = -g^2 m_2 - 2 g m_3: the closed-form columns' coefficients
     const double P2 = dpp_f64<kQuadBcast2>(P), P3 = dpp_f64<kQuadBcast3>(P);      // P[r][2], P[r][3]
-    const double Cf = (C + fma(K.cc2, P2, K.cc3 * P3)) + poison;
+    const double Cf = C + fma(K.cc2, P2, K.cc3 * P3);
     kP = mfma4x4(Cf, K.ident, Cf + K.gam);                               // C^T + (C + gamma)
 }
 
@@ -166,13 +171,13 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
             for (int stage = 0; stage < 4; stage++) {
                 cd4_mfma_rhs<TWO>(model, R, K, grp, tm, tP, km, kP);
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
-                const double half = (stage == 2) ? 1.0 : 0.5;
-                am = fma(wgt, km, am); tm = u + (dt * km) * half;
+                const double dth = (stage == 2) ? dt : 0.5 * dt;                 // (dt k) half == k (dt half): half is a power of two
+                am = fma(wgt, km, am); tm = u + dth * km;
                 aP = fma(wgt, kP, aP);
-                tP = P + (dt * kP) * half;
+                tP = P + dth * kP;
             }
-            const double f = u + (dt * am) / 6.0;
-            const double Pp = P + (dt * aP) / 6.0;
+            const double f = u + (dt * am) * kSixth;
+            const double Pp = P + (dt * aP) * kSixth;
             // ---- update
             double S, innov;
             mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
@@ -252,13 +257,13 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
                 const double sym = mfma4x4(Gd, tP, mfma4x4(tP, Gd, 0.0));                           // G^T P + P G (P symmetric)
                 kP = (kP + sym) - 2.0 * K.gam;
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
-                const double half = (stage == 2) ? 1.0 : 0.5;
-                am = fma(wgt, km, am); tm = ms + (dt * km) * half;
+                const double dth = (stage == 2) ? dt : 0.5 * dt;                 // (dt k) half == k (dt half): half is a power of two
+                am = fma(wgt, km, am); tm = ms + dth * km;
                 aP = fma(wgt, kP, aP);
-                tP = Ps + (dt * kP) * half;
+                tP = Ps + dth * kP;
             }
-            ms = ms + (dt * am) / 6.0;
-            Ps = Ps + (dt * aP) / 6.0;
+            ms = ms + (dt * am) * kSixth;
+            Ps = Ps + (dt * aP) * kSixth;
             wP.store(Ps, t * 128u + offP);
             wm.store(ms, t * 32u + offm);
         }
@@ -342,13 +347,13 @@ __global__ void __launch_bounds__(64) cdekf4_mfma_kernel(FilterIO io, ModelArgs 
                 const double JP = mfma4x4(JT, tP, 0.0);                  // sum_k J[r][k] P[k][q]
                 const double kP = mfma4x4(JP, K.ident, JP + K.gam);      // (J P)^T + J P + gamma
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
-                const double half = (stage == 2) ? 1.0 : 0.5;
-                am = fma(wgt, km, am); tm = u + (dt * km) * half;
+                const double dth = (stage == 2) ? dt : 0.5 * dt;                 // (dt k) half == k (dt half): half is a power of two
+                am = fma(wgt, km, am); tm = u + dth * km;
                 aP = fma(wgt, kP, aP);
-                tP = P + (dt * kP) * half;
+                tP = P + dth * kP;
             }
-            const double f = u + (dt * am) / 6.0;
-            const double Pp = P + (dt * aP) / 6.0;
+            const double f = u + (dt * am) * kSixth;
+            const double Pp = P + (dt * aP) * kSixth;
             double S, innov;
             mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
             park[slot] = make_double2(S, innov);
@@ -419,13 +424,13 @@ __global__ void __launch_bounds__(64) cdeks4_mfma_kernel(SmootherIO io, ModelArg
                 const double AP = mfma4x4(JT + Gd, tP, 0.0);            // sum_k A[r][k] P[k][q], A = J + G^T
                 const double kP = mfma4x4(AP, K.ident, AP - K.gam);     // (A P)^T + A P - gamma
                 const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
-                const double half = (stage == 2) ? 1.0 : 0.5;
-                am = fma(wgt, km, am); tm = ms + (dt * km) * half;
+                const double dth = (stage == 2) ? dt : 0.5 * dt;                 // (dt k) half == k (dt half): half is a power of two
+                am = fma(wgt, km, am); tm = ms + dth * km;
                 aP = fma(wgt, kP, aP);
-                tP = Ps + (dt * kP) * half;
+                tP = Ps + dth * kP;
             }
-            ms = ms + (dt * am) / 6.0;
-            Ps = Ps + (dt * aP) / 6.0;
+            ms = ms + (dt * am) * kSixth;
+            Ps = Ps + (dt * aP) * kSixth;
             wP.store(Ps, t * 128u + offP);
             wm.store(ms, t * 32u + offm);
         }
