@@ -141,7 +141,8 @@ typedef struct cgp_init {
 #define CGP_GENERIC_KERNEL    0x10u  /* force the generic kernel where a lane-cooperative specialisation exists (filters; d >= 5
                                         time-parallel smoothers: the lane-scan kernel instead of the cooperative walk)      */
 #define CGP_LITERAL_SIGMA_SUM  0x40u  /* sigma-point methods: sum over every point even when the set is CGP_SIGMA_STANDARD     */
-#define CGP_DPP_KERNEL        0x80u  /* d = 4 EKF: the DPP cooperative kernel instead of the matrix-core (MFMA) one             */
+#define CGP_DPP_KERNEL        0x80u  /* d = 4 chirp / La Scala models (ekf, sgp_filter, cd_ekf, cd_eks, cd_sgp_filter, cd_sgp_smoother):
+                                        the DPP / LDS-reduced cooperative kernels instead of the matrix-core (MFMA) ones       */
 #define CGP_FOUR_TRIALS_PER_WAVE 0x200u /* d = 4 matrix-core EKF: four trials per wavefront whatever the batch (default above 1024) */
 #define CGP_ONE_TRIAL_PER_WAVE   0x400u /* ... one trial per wavefront whatever the batch                                      */
 #define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
