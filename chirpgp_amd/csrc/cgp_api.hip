@@ -181,7 +181,8 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
         // d = 4 EKF, one wavefront per trial: the lane-cooperative kernel (covariance spread over a 16-lane DPP row)
         if (method == CGP_F_EKF && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4(io, ma, st);
         else if (method == CGP_F_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_filter_coop4_sgp(io, ma, st);
-        else if (method == CGP_F_EKF && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && (model->n_harm == 2 || model->n_harm == 3))
+        else if (method == CGP_F_EKF && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && (model->n_harm == 2 || model->n_harm == 3)
+                 && io.T * model->d * model->d * 8 <= 0x7FFFFF00LL)                              // the kernel's output windows (cgp_coop4.hpp:kOobMaxBytes)
             rc = dispatch_filter_coop8_ekf(model->n_harm, io, ma, st);
         else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, io.T, ma))
             rc = dispatch_filter_coop8_sgp(model->n_harm, io, ma, st);

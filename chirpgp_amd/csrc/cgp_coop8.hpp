@@ -317,8 +317,8 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
     const bool entry = i < D && j < D;
     const bool mean_lane = (J == 0 && q == 0 && i < D);
     constexpr int kVLane = 16 * (V & 3) + 4 * (2 * (V >> 2));            // a lane whose row-form entry is u_v
-    SpecRegs R;
-    R.init<false>();
+    FanRegs R;
+    R.init();
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     const double* __restrict__ P0p = io.P0 + trial * io.P0_stride;
@@ -327,8 +327,11 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
 
     const int64_t T = io.T;
     const double* __restrict__ ys = io.ys + trial * T;
-    double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
-    double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
+    OobWindow wP, wm;                                                    // which lanes store is an offset, not a branch
+    wP.init(io.Pfs ? io.Pfs + trial * T * D * D : nullptr, T * (D * D * 8));
+    wm.init(io.mfs ? io.mfs + trial * T * D : nullptr, T * (D * 8));
+    const unsigned offP = entry ? (unsigned)(i * D + j) * 8u : kOobOffset;
+    const unsigned offm = mean_lane ? (unsigned)i * 8u : kOobOffset;
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
@@ -339,13 +342,22 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         for (int slot = 0; slot < nsteps; slot++) {
-            const int64_t t = t0 + slot;
+            const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
             // ---- wave-uniform scalar chain: rotations at the frequency g(u_v) (models.py:370-376)
             const double uv = readlane_f64(mrow, kVLane);
-            double sp, dsp, s1, c1;
-            softplus_pair_uniform(R, uv, sp, dsp);                       // lean polynomials on [1.5, 700), the naive form elsewhere
-            fast_sincos_uniform(ang * sp, s1, c1);
+            // evaluated without regime branches (lean softplus on [1.5, 700), sin / cos on the reduced range |x| <= pi/4 in
+            // Estrin form, coefficients pinned): one block to schedule; outside the regime the checked forms run afterwards
+            const double et = exp_neg_lean(R, uv);
+            double lq, dsp, s1, c1;
+            softplus_tail_lean(R, et, lq, dsp);
+            double sp = fma(lq, et, uv);
+            sincos_reduced(R, ang * sp, s1, c1);
+            const bool ok = softplus_lane_common(uv) && fabs(ang * sp) <= kPiOver4;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+                softplus_pair_uniform(uv, sp, dsp);
+                fast_sincos_uniform(ang * sp, s1, c1);
+            }
             double ck = c1, sk = s1, csel = c1, ssel = s1;
             CGP_UNROLL for (int k = 1; k < NH; k++) {
                 const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
@@ -367,8 +379,8 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
             double S, innov;
             coop8_update(Pp, fr, HR, HC, XiC, y, P, mrow, S, innov);
             park[slot] = make_double2(S, innov);
-            if (Pfs && entry) Pfs[t * (D * D) + i * D + j] = P;
-            if (mfs && mean_lane) mfs[t * D + i] = mrow;
+            wP.store(P, t * (unsigned)(D * D * 8) + offP);
+            wm.store(mrow, t * (unsigned)(D * 8) + offm);
         }
         if (want_nll) {
             wave_lds_fence();
@@ -383,6 +395,7 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
 template <int NH>
 inline int launch_ekf8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (io.T * ((2 * NH + 2) * (2 * NH + 2) * 8) > kOobMaxBytes) return CGP_E_UNSUPPORTED;        // output windows (OobWindow)
     hipLaunchKernelGGL((ekf8_coop_kernel<NH>), dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
