@@ -66,7 +66,7 @@ static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt, 
     a.model_id = m->model_id;
     a.sg.xi = sg ? sg->xi : nullptr; a.sg.w = sg ? sg->w : nullptr; a.sg.s = sg ? sg->s : 0;
     a.sg.group_start = sg ? sg->group_start : nullptr; a.sg.n_groups = (sg && sg->group_start) ? sg->n_groups : 0;
-    a.sg.lds_xi = 0; a.sg.lds_w = 0; a.sg.lds_gs = 0;
+    a.sg.lds_xi = 0; a.sg.lds_w = 0; a.sg.lds_gs = 0; a.sg.lds_tab = 0;
     a.sg.flags = (sg && !(flags & CGP_LITERAL_SIGMA_SUM)) ? sg->flags : 0u;
     a.dt = dt;
     return a;

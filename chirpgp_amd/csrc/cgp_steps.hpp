@@ -25,6 +25,8 @@ constexpr int kSigLdsMaxBytes = 44 * 1024;   // + 17 KB static reduction buffer 
 // LDS pointers carry their address space explicitly: the reads become ds_read_* (not flat_load with an aperture test).
 using LdsConstDoublePtr = const __attribute__((address_space(3))) double*;
 using LdsConstIntPtr = const __attribute__((address_space(3))) int*;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+using LdsConstDouble2Ptr = const __attribute__((address_space(3))) double2_t*;
 struct SigmaSet {
     const double* __restrict__ xi;          // [s][d]   (global)
     const double* __restrict__ w;           // [s]
@@ -33,7 +35,7 @@ struct SigmaSet {
     unsigned flags;                          // CGP_SIGMA_* with CGP_SIGMA_STANDARD cleared when the launch wants the literal sums
     // LDS copies as 32-bit LDS addresses (this struct travels in the kernel arguments, where an address_space(3)
     // pointer member would have different sizes in the host and device layouts).
-    unsigned lds_xi, lds_w, lds_gs;
+    unsigned lds_xi, lds_w, lds_gs, lds_tab;
     CGP_DEV int groups() const { return group_start ? n_groups : s; }
     template <bool ST> CGP_DEV int begin(int g) const {
         if (!group_start) return g;
@@ -49,8 +51,29 @@ struct SigmaSet {
     template <bool ST> CGP_DEV double coord(int idx) const {
         if constexpr (ST) return ((LdsConstDoublePtr)lds_xi)[idx]; else return xi[idx];
     }
+    // The representative of group g for the collapsed quadratures: xi_0..D-2 of its first member and the group's total
+    // weight.  Staged sets keep them as a table of D doubles per group (built once by stage()): D / 2 16-byte LDS reads
+    // at an address that depends on g alone, instead of group bounds -> member weights -> coordinates one after the other.
+    template <bool ST, int D> CGP_DEV void group(int g, double (&x)[D - 1], double& W) const {
+        static_assert(D % 2 == 0, "collapsed quadratures: even state dimensions");
+        if constexpr (ST) {
+            const LdsConstDouble2Ptr t = (LdsConstDouble2Ptr)lds_tab + g * (D / 2);
+            CGP_UNROLL for (int k = 0; k < D / 2; k++) {
+                const double2_t v = t[k];
+                x[2 * k] = v.x;
+                if (2 * k + 1 < D - 1) x[2 * k + 1] = v.y; else W = v.y;
+            }
+        } else {
+            const int p0 = begin<false>(g), p1 = end<false>(g);
+            W = 0.0;
+            for (int p = p0; p < p1; p++) W += w[p];
+            CGP_UNROLL for (int c = 0; c < D - 1; c++) x[c] = xi[p0 * D + c];
+        }
+    }
+    // doubles in front of the group table: points, weights, group bounds (ints), rounded up to a 16-byte boundary
+    static inline size_t table_offset(int s, int d, int n_groups) { return ((size_t)s * d + s + (n_groups + 2) / 2 + 1) & ~(size_t)1; }
     static inline size_t stage_bytes(int s, int d, int n_groups, bool grouped) {
-        return ((size_t)s * d + s + (grouped ? (n_groups + 2) / 2 : 0)) * sizeof(double);
+        return (grouped ? table_offset(s, d, n_groups) + (size_t)n_groups * d : (size_t)s * d + s) * sizeof(double);
     }
     // Cooperative copy into `buf` (stage_bytes of LDS); all `nthreads` threads of the block must call it.
     CGP_DEV void stage(double* buf, int tid, int nthreads, int d) {
@@ -59,10 +82,21 @@ struct SigmaSet {
         for (int i = tid; i < s; i += nthreads) buf[nxi + i] = w[i];
         int* gs = reinterpret_cast<int*>(buf + nxi + s);
         for (int i = tid; i < ngs; i += nthreads) gs[i] = group_start[i];
+        double* tab = buf + (((size_t)nxi + s + (n_groups + 2) / 2 + 1) & ~(size_t)1);
+        if (group_start) {
+            for (int g = tid; g < n_groups; g += nthreads) {
+                const int p0 = group_start[g], p1 = group_start[g + 1];
+                for (int c = 0; c < d - 1; c++) tab[g * d + c] = xi[p0 * d + c];
+                double W = 0.0;
+                for (int p = p0; p < p1; p++) W += w[p];
+                tab[g * d + d - 1] = W;
+            }
+        }
         __syncthreads();
         lds_xi = (unsigned)(uintptr_t)(LdsConstDoublePtr)buf;
         lds_w = (unsigned)(uintptr_t)(LdsConstDoublePtr)(buf + nxi);
         lds_gs = (unsigned)(uintptr_t)(LdsConstIntPtr)gs;
+        lds_tab = (unsigned)(uintptr_t)(LdsConstDoublePtr)tab;
     }
 };
 
@@ -240,10 +274,9 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
     HarmonicLCD<1>::Anchor anchor;
     model.anchor(mf.v[2], anchor);
     for (int g = 0; g < ng; g++) {
-        const int p0 = sg.template begin<ST>(g), p1 = sg.template end<ST>(g);
-        double W = 0.0;
-        for (int p = p0; p < p1; p++) W += sg.template weight<ST>(p);
-        const double xi0 = sg.template coord<ST>(p0 * 4), xi1 = sg.template coord<ST>(p0 * 4 + 1), xi2 = sg.template coord<ST>(p0 * 4 + 2);
+        double xg[3], W;
+        sg.template group<ST, 4>(g, xg, W);
+        const double xi0 = xg[0], xi1 = xg[1], xi2 = xg[2];
         const double d0 = L(0, 0) * xi0;
         const double d1 = fma(L(1, 1), xi1, L(1, 0) * xi0);
         const double d2 = fma(L(2, 2), xi2, fma(L(2, 1), xi1, L(2, 0) * xi0));
@@ -304,11 +337,8 @@ CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const Sigma
     typename HarmonicLCD<NH>::Anchor anchor;
     model.anchor(mf.v[V], anchor);
     for (int g = 0; g < ng; g++) {
-        const int p0 = sg.template begin<ST>(g), p1 = sg.template end<ST>(g);
-        double W = 0.0;
-        for (int p = p0; p < p1; p++) W += sg.template weight<ST>(p);
-        double xi[D - 1], dd[D];
-        CGP_UNROLL for (int c = 0; c < D - 1; c++) xi[c] = sg.template coord<ST>(p0 * D + c);
+        double xi[D - 1], dd[D], W;
+        sg.template group<ST, D>(g, xi, W);
         CGP_UNROLL for (int a = 0; a < D; a++) {
             double t = L(a, 0) * xi[0];
             CGP_UNROLL for (int c = 1; c <= (a < D - 1 ? a : D - 2); c++) t = fma(L(a, c), xi[c], t);
