@@ -216,6 +216,26 @@ template <int NH> struct HarmonicLCD {
             p.c[k] = ck * rho; p.s[k] = sk * rho;
         }
     }
+    // The anchored form without its two regime branches (lean softplus as is, small-angle rotation as is), for a lane
+    // that walks many groups in a loop the scheduler should see as one block: ok = false where precompute(uv, a, p)
+    // would have taken a fallback (uv outside [1.5, 700) or |d| > 1/16); the caller then repeats the fan with that.
+    CGP_DEV void precompute_spec(double uv, const Anchor& a, Pre& p, bool& ok) const {
+        const double t = exp_neg_lean_lane(uv);
+        const double w = (kTwoPi * fma(log1p_over_t_lean(t), t, uv)) * fs;
+        const double d = dt * (w - a.w0), d2 = d * d;
+        const double ps = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        const double cd = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+        const double sd = d * ps;
+        const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
+        ok = softplus_lane_common(uv) && fabs(d) <= 0.0625;
+        double ck = c1, sk = s1;
+        p.c[0] = c1 * rho; p.s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            p.c[k] = ck * rho; p.s[k] = sk * rho;
+        }
+    }
     CGP_DEV void mean_pre(const Vec<D>& u, const Pre& p, Vec<D>& f) const {
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             f.v[2 * k] = p.c[k] * u.v[2 * k] - p.s[k] * u.v[2 * k + 1];

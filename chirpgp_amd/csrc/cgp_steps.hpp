@@ -263,10 +263,13 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
 // an exact regrouping of filters_smoothers.py:88-121 / :525 -- one evaluation per GROUP (27 for Gauss-Hermite order 3
 // instead of 81 points), 9 (13 with the cross term) partial sums instead of 15 (31).  One lane does all groups; a
 // failed Cholesky poisons every output with NaN like the literal sums do.
-template <bool CROSS, bool ST>
-CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
-                                       Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
+// SPEC: the groups' softplus and rotation without regime branches (cgp_models.hpp:precompute_spec), so the loop body is ONE
+// basic block; returns false if some group of this lane was outside the regime -- the caller then repeats with SPEC = false.
+template <bool CROSS, bool ST, bool SPEC>
+CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
+                                            Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
     Sym<4> L; Vec<4> inv;
+    bool all_ok = true;
     cholesky<4>(Pf, L, inv);
     double sf0 = 0.0, sf1 = 0.0, s00 = 0.0, s10 = 0.0, s11 = 0.0;
     double x02 = 0.0, x12 = 0.0, x03 = 0.0, x13 = 0.0, c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
@@ -283,7 +286,8 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
         const double d3 = fma(L(3, 2), xi2, fma(L(3, 1), xi1, L(3, 0) * xi0));
         const double h0 = mf.v[0] + d0, h1 = mf.v[1] + d1;
         HarmonicLCD<1>::Pre pre;
-        model.precompute(mf.v[2] + d2, anchor, pre);
+        if constexpr (SPEC) { bool ok; model.precompute_spec(mf.v[2] + d2, anchor, pre, ok); all_ok = all_ok && ok; }
+        else model.precompute(mf.v[2] + d2, anchor, pre);
         const double f0 = pre.c[0] * h0 - pre.s[0] * h1, f1 = pre.s[0] * h0 + pre.c[0] * h1;
         const double w0 = W * f0, w1 = W * f1;
         sf0 += w0; sf1 += w1;
@@ -316,6 +320,13 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
             DT.a[3][i] = fma(M2, pi2, M3 * pi3) + poison;
         }
     }
+    return all_ok;
+}
+template <bool CROSS, bool ST>
+CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
+                                       Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
+    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
 }
 // The same regrouping for n harmonics (d = 2 n + 2; rotating components a < 2 n, linear pair v = 2 n, v + 1), one lane doing
 // all groups: with d = L xi restricted to xi_0..d-2 and g_a = f_a(m + d) of a group's representative,
@@ -323,10 +334,12 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
 //     mp_lin = M m_lin,   Pp_lin,lin = M P_lin,lin M^T + Sigma_lin,
 //     D[i][a] = sum W d_i g_a   (cross covariance, smoother),   D[i][v+b] = sum_c M_bc P[i][v+c]
 // -- 15 evaluations and 39 (75 with the cross term) partial sums for the cubature rule in d = 8, instead of 16 and 45 (109).
-template <int NH, bool CROSS, bool ST>
-CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const SigmaSet& sg, const Vec<2 * NH + 2>& mf, const Sym<2 * NH + 2>& Pf,
-                                       Vec<2 * NH + 2>& mp, Sym<2 * NH + 2>& Pp, Mat<2 * NH + 2>& DT) {
+// SPEC as in sgp4_prediction_collapsed_impl.
+template <int NH, bool CROSS, bool ST, bool SPEC>
+CGP_DEV bool sgpn_prediction_collapsed_impl(const HarmonicLCD<NH>& model, const SigmaSet& sg, const Vec<2 * NH + 2>& mf, const Sym<2 * NH + 2>& Pf,
+                                            Vec<2 * NH + 2>& mp, Sym<2 * NH + 2>& Pp, Mat<2 * NH + 2>& DT) {
     constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
+    bool all_ok = true;
     Sym<D> L; Vec<D> inv;
     cholesky<D>(Pf, L, inv);                       // L[D-1][D-1] is never used: its square root is dead code
     double sf[NL], sab[NL * (NL + 1) / 2], x[NL][2], cr[CROSS ? NL : 1][NL];
@@ -345,7 +358,8 @@ CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const Sigma
             dd[a] = t;
         }
         typename HarmonicLCD<NH>::Pre pre;
-        model.precompute(mf.v[V] + dd[V], anchor, pre);
+        if constexpr (SPEC) { bool ok; model.precompute_spec(mf.v[V] + dd[V], anchor, pre, ok); all_ok = all_ok && ok; }
+        else model.precompute(mf.v[V] + dd[V], anchor, pre);
         double wg[NL], gg[NL];
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             const double h0 = mf.v[2 * k] + dd[2 * k], h1 = mf.v[2 * k + 1] + dd[2 * k + 1];
@@ -390,6 +404,18 @@ CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const Sigma
             DT.a[V][c] = fma(M0, pv, M1 * pw) + poison;
             DT.a[V + 1][c] = fma(M2, pv, M3 * pw) + poison;
         }
+    }
+    return all_ok;
+}
+template <int NH, bool CROSS, bool ST>
+CGP_DEV void sgpn_prediction_collapsed(const HarmonicLCD<NH>& model, const SigmaSet& sg, const Vec<2 * NH + 2>& mf, const Sym<2 * NH + 2>& Pf,
+                                       Vec<2 * NH + 2>& mp, Sym<2 * NH + 2>& Pp, Mat<2 * NH + 2>& DT) {
+    // the branch-free loop pays where a lane runs the whole filter (C5 parameter sweep 49 -> 45.5 ms per 262144 x 1000); in the
+    // d = 6 / 8 smoother, whose lanes also carry the cooperative walk's state, it measured slower (C5 smoother 4.74 -> 5.17 ms)
+    if constexpr (ST) sgpn_prediction_collapsed_impl<NH, CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+    else {
+        const bool ok = sgpn_prediction_collapsed_impl<NH, CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) sgpn_prediction_collapsed_impl<NH, CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
     }
 }
 // Whether a launch may take the collapsed path: the caller's assertion, groups, and the d = 4 harmonic family (run-time
