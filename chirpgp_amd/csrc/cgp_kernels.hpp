@@ -359,15 +359,18 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
     }
     for (int64_t hi = T - 2; hi >= 0; hi -= 64 * K) {
         const int64_t base = hi - (64 * K - 1) + (int64_t)lane * K;      // first (earliest) step of this lane
+        // all K rows are requested before the first element is built (rows before the start of the record are clamped to
+        // row 0 and not used): one memory round trip per tile instead of one per element
         Affine<D> e[K];
+        Vec<D> mfk[K]; Sym<D> Pfk[K];
+        CGP_UNROLL for (int j = 0; j < K; j++) {
+            const int64_t t = base + j >= 0 ? base + j : 0;
+            load_vec<D>(mfs + t * D, mfk[j]);
+            load_sym<D>(Pfs + t * D * D, Pfk[j]);
+        }
         CGP_UNROLL for (int j = 0; j < K; j++) {
             affine_identity<D>(e[j]);
-            if (base + j >= 0) {
-                Vec<D> mf; Sym<D> Pf;
-                load_vec<D>(mfs + (base + j) * D, mf);
-                load_sym<D>(Pfs + (base + j) * D * D, Pf);
-                elem.element(mf, Pf, e[j]);
-            }
+            if (base + j >= 0) elem.element(mfk[j], Pfk[j], e[j]);
         }
         // lane aggregate a = e_0 o e_1 o ... o e_{K-1}
         Affine<D> a = e[K - 1];
