@@ -9,6 +9,7 @@ run --workload sgp
 run --workload cd_sgp --batch 512 --T 50000
 run --workload harmonic
 run --workload cd_ekf
+run --workload harmonic_ekf
 python - <<'PY'
 import json, time, numpy as np, torch
 import bench
