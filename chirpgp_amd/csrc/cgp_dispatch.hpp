@@ -12,7 +12,7 @@ namespace cgp {
 
 // d >= 6 harmonic models, one lane per fan: the collapsed quadrature is a compile-time property of the kernel (cgp_steps.hpp).
 template <class DM> inline bool sgp_collapsible_host(const ModelArgs& ma) {
-    return (std::is_same<DM, HarmonicLCD<2>>::value || std::is_same<DM, HarmonicLCD<3>>::value) &&
+    return (std::is_same<DM, HarmonicLCD<1>>::value || std::is_same<DM, HarmonicLCD<2>>::value || std::is_same<DM, HarmonicLCD<3>>::value) &&
            (ma.sg.flags & CGP_SIGMA_STANDARD) && ma.sg.group_start;
 }
 
@@ -38,6 +38,10 @@ static int smoother_disc(int method, bool wave, const SmootherIO& io, const Mode
         if constexpr (DM::D <= CGP_TP_MAX_D) { if (tp) return hip_rc(launch_tp_smoother<EksElement<DM>>(io, ma, st)); }
         return hip_rc(wave ? launch_smoother<EksStep<DM, true>>(io, ma, st) : launch_smoother<EksStep<DM, false>>(io, ma, st));
     case CGP_S_SGP:
+        if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) {
+            // d = 4: the time-parallel kernel with the collapsed path alone (the lane-per-trial kernel decides at run time)
+            if (tp && sgp_collapsible_host<DM>(ma)) return hip_rc(launch_tp_smoother<SgpsElement<DM, true>>(io, ma, st));
+        }
         if constexpr (std::is_same<DM, HarmonicLCD<2>>::value || std::is_same<DM, HarmonicLCD<3>>::value) {
             if (sgp_collapsible_host<DM>(ma)) {
                 if (tp) return hip_rc(launch_tp_smoother<SgpsElement<DM, true>>(io, ma, st));

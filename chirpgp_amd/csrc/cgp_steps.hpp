@@ -192,7 +192,11 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
     constexpr int D = DM::D;
     constexpr int NS = Sym<D>::N;
     constexpr int R = 1 + D + NS + (CROSS ? D * D : 0);
-    if constexpr (!WAVE && std::is_same<DM, HarmonicLCD<1>>::value) {
+    if constexpr (!WAVE && COLL && std::is_same<DM, HarmonicLCD<1>>::value) {
+        // the launch has checked the set on the host: the kernel contains the collapsed path only (fewer registers, less code)
+        sgp4_prediction_collapsed<CROSS, ST>(model, sg, mf, Pf, mp, Pp, DT);
+        return;
+    } else if constexpr (!WAVE && std::is_same<DM, HarmonicLCD<1>>::value) {
         // one lane does the whole fan: the collapsed quadrature where the set allows it (wave-uniform decision)
         if (sgp_collapsible<DM>(sg)) {
             sgp4_prediction_collapsed<CROSS, ST>(model, sg, mf, Pf, mp, Pp, DT);
