@@ -228,11 +228,14 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     case CGP_M_LINEAR:
         // 5 <= d <= 8, one wavefront per trial: maps built per lane, applied cooperatively in the tile layout (cgp_coop8.hpp)
         if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && coop8_smoother_ok(model->d, T, ma)) rc = dispatch_smoother_coop8_linear(method, model->d, io, ma, st);
+        // d = 4: gains per lane, the recursion walked on the matrix cores (cgp_walk4.hpp)
+        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->d == 4 && walk4_smoother_fits(T, ma)) rc = dispatch_smoother_walk4_linear(method, io, ma, st);
         else rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st);
         break;
     case CGP_M_HARMONIC_LCD:
     case CGP_M_LASCALA_LCD:
         if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm >= 2 && coop8_smoother_ok(model->d, T, ma) && coop8_smoother_harm_ok(method, ma)) rc = dispatch_smoother_coop8_harm(method, model->n_harm, io, ma, st);
+        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm == 1 && walk4_smoother_fits(T, ma)) rc = dispatch_smoother_walk4_harm(method, io, ma, st);
         else rc = dispatch_smoother_disc_harm(method, model->n_harm, wave, io, ma, st);
         break;
     case CGP_M_LINEAR_SDE:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;

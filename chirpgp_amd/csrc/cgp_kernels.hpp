@@ -460,6 +460,9 @@ inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 // d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
 bool coop8_filter_sgp_ok(int n_harm, int64_t T, const ModelArgs&);
+bool walk4_smoother_fits(int64_t T, const ModelArgs&);
+int dispatch_smoother_walk4_linear(int method, const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_walk4_harm(int method, const SmootherIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop8_sgp(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_coop8_ekf(int n_harm, const FilterIO&, const ModelArgs&, hipStream_t);
 bool coop8_smoother_ok(int d, int64_t T, const ModelArgs&);
