@@ -167,6 +167,22 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     }
 }
 
+// fast_sincos without its fallback branch: ok = false for |x| >= 1e5, inf and NaN (the caller repeats with fast_sincos).
+CGP_DEV void fast_sincos_spec(double x, double& sn, double& cs, bool& ok) {
+    ok = fabs(x) < 1.0e5;
+    const double n = __builtin_rint(x * kTwoOverPi);
+    double r = fma(-n, kPio2_1, x);
+    r = fma(-n, kPio2_2, r);
+    r = fma(-n, kPio2_3, r);
+    double s0, c0;
+    sincos_reduced(r, s0, c0);
+    const int q = (int)n;
+    const bool swap = (q & 1) != 0;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    sn = __hiloint2double(__double2hiint(a) ^ ((q & 2) << 30), __double2loint(a));
+    cs = __hiloint2double(__double2hiint(b) ^ (((q + 1) & 2) << 30), __double2loint(b));
+}
+
 // exp(x) without the overflow / underflow / NaN handling, for arguments known to lie in (-700, 700).
 CGP_DEV double fast_exp_core(double x) {
     const double k = __builtin_rint(x * kLog2e);

@@ -250,11 +250,41 @@ template <int NH> struct HarmonicLCD {
         mean_pre(u, p, f);
     }
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
+        bool ok;
+        propagate_impl<false>(u, P, f, T, Pp, ok);
+    }
+    // the same without the regime branches of the softplus and the sin / cos (lean softplus as is, reduced sin / cos as is):
+    // ok = false where propagate() would have taken a fallback; the caller then repeats with propagate()
+    CGP_DEV void propagate_spec(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp, bool& ok) const {
+        propagate_impl<true>(u, P, f, T, Pp, ok);
+    }
+    template <bool SPEC>
+    CGP_DEV void propagate_impl(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp, bool& ok) const {
         double sp, dsp;
-        softplus_pair_sel(uniform, wide, u.v[IV], sp, dsp);
-        const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;
         double c[NH], s[NH], jv[2 * NH];
-        rotations(w, c, s);
+        double w, dw;
+        if constexpr (SPEC) {
+            const double x = u.v[IV];
+            const double t = exp_neg_lean_lane(x);
+            sp = fma(log1p_over_t_lean(t), t, x);
+            dsp = rcp_nr1(1.0 + t);
+            w = (kTwoPi * sp) * fs; dw = (kTwoPi * dsp) * fs;
+            double s1, c1; bool ok2;
+            fast_sincos_spec(dt * w, s1, c1, ok2);
+            ok = softplus_lane_common(x) && ok2;
+            double ck = c1, sk = s1;
+            c[0] = c1 * rho; s[0] = s1 * rho;
+            CGP_UNROLL for (int k = 1; k < NH; k++) {
+                const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+                ck = cn; sk = sn;
+                c[k] = ck * rho; s[k] = sk * rho;
+            }
+        } else {
+            ok = true;
+            softplus_pair_sel(uniform, wide, u.v[IV], sp, dsp);
+            w = (kTwoPi * sp) * fs; dw = (kTwoPi * dsp) * fs;
+            rotations(w, c, s);
+        }
         CGP_UNROLL for (int k = 0; k < NH; k++) {
             const double u0 = u.v[2 * k], u1 = u.v[2 * k + 1];
             f.v[2 * k] = c[k] * u0 - s[k] * u1;

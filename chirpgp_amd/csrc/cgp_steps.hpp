@@ -869,8 +869,18 @@ template <class DM> struct EksElement {
         model.propagate(mf, Pf, mp, DT, Pp);
         gain_from_prediction<D>(Pp, DT, G);
     }
+    // gain() as straight-line code where the model has a branch-free form (cgp_models.hpp:propagate_spec): ok = false where
+    // gain() would have taken a regime fallback
+    static constexpr bool HAS_SPEC = std::is_same<DM, HarmonicLCD<1>>::value;
+    CGP_DEV void gain_spec(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& mp, Sym<D>& Pp, bool& ok) const {
+        Mat<D> DT;
+        if constexpr (HAS_SPEC) model.propagate_spec(mf, Pf, mp, DT, Pp, ok);
+        else { model.propagate(mf, Pf, mp, DT, Pp); ok = true; }
+        gain_from_prediction<D>(Pp, DT, G);
+    }
 };
 template <class DM, bool COLL = false> struct SgpsElement {
+    static constexpr bool HAS_SPEC = false;
     static constexpr bool USES_SIGMA = true;
     static constexpr int D = DM::D;
     DM model; SigmaSet sg;

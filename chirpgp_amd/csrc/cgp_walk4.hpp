@@ -21,7 +21,8 @@
 //   * the results of FOUR steps leave in one store instruction each for Ps and ms -- the instruction's four blocks of 16
 //     lanes carry the four steps' rows, 512 contiguous bytes -- because a wavefront may have only 63 memory instructions in
 //     flight and two stores per step used that up (0.63 against 0.47 ms for the walk of the bench configuration);
-//   * a lane's own filtering row for the NEXT tile is requested before the walk starts.
+//   * a lane's own filtering row for the NEXT tile is requested before the walk starts;
+//   * for the EKS of the chirp model the gains of the next tile are built during the walk (see the kernel).
 // HBM is read once and written once (320 B a step).
 #pragma once
 #include "cgp_coop8.hpp"
@@ -65,46 +66,35 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
     if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
 
-    // the lane's own filtering row of the first tile (a row before the start of the record is clamped and not used)
-    Vec<4> mf; Sym<4> Pf;
-    {
-        const int64_t t = T - 2 - 63 + lane;
+    // the lane's row of a tile (a row before the start of the record is clamped and not used)
+    auto request = [&](int64_t base, Vec<4>& mf, Sym<4>& Pf) {
+        const int64_t t = base + lane;
         load_vec<4>(mfs + (t >= 0 ? t : 0) * 4, mf);
         load_sym<4>(Pfs + (t >= 0 ? t : 0) * 16, Pf);
-    }
-    for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
-        const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
-        // ---- every lane: prediction and gain of its own step, then its record
-        {
-            Mat<4> G; Vec<4> mp; Sym<4> Pp;
-            if (base + lane >= 0) elem.gain(mf, Pf, G, mp, Pp);
-            else {
-                CGP_UNROLL for (int a = 0; a < 4; a++) { mp.v[a] = 0.0; mf.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < 4; c++) G.a[a][c] = 0.0; }
-                CGP_UNROLL for (int a = 0; a < Sym<4>::N; a++) { Pp.a[a] = 0.0; Pf.a[a] = 0.0; }
-            }
-            double* mine = recs + lane * kWalkRec;
-            CGP_UNROLL for (int a = 0; a < 4; a++) {
-                double v = mf.v[a];
-                CGP_UNROLL for (int c = 0; c < 4; c++) {
-                    double n = 0.0;                                         // -(Pp G^T)[a][c] = -sum_k Pp[a][k] G[c][k]
-                    CGP_UNROLL for (int k = 0; k < 4; k++) n = fma(-Pp(a, k), G.a[c][k], n);
-                    mine[kWalkG + a * 4 + c] = G.a[a][c];
-                    mine[kWalkN + a * 4 + c] = n;
-                    mine[kWalkPf + a * 4 + c] = Pf(a, c);                   // Sym::operator() is symmetric in its arguments
-                    v = fma(-G.a[a][c], mp.v[c], v);                        // mf - G mp
-                }
-                mine[kWalkV + a] = v;
-            }
+    };
+    // the lane's record: G, N = -Pp G^T, Pf, v = mf - G mp; all zero for a step before the start of the record
+    auto write_record = [&](bool valid, Mat<4>& G, Vec<4>& mp, Sym<4>& Pp, Vec<4>& mf, Sym<4>& Pf) {
+        if (!valid) {
+            CGP_UNROLL for (int a = 0; a < 4; a++) { mp.v[a] = 0.0; mf.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < 4; c++) G.a[a][c] = 0.0; }
+            CGP_UNROLL for (int a = 0; a < Sym<4>::N; a++) { Pp.a[a] = 0.0; Pf.a[a] = 0.0; }
         }
-        wave_lds_fence();
-        // ---- the lane's row of the NEXT (earlier) tile: requested now, used after the walk
-        {
-            const int64_t t = base - 64 + lane;
-            load_vec<4>(mfs + (t >= 0 ? t : 0) * 4, mf);
-            load_sym<4>(Pfs + (t >= 0 ? t : 0) * 16, Pf);
+        double* mine = recs + lane * kWalkRec;
+        CGP_UNROLL for (int a = 0; a < 4; a++) {
+            double v = mf.v[a];
+            CGP_UNROLL for (int c = 0; c < 4; c++) {
+                double n = 0.0;                                             // -(Pp G^T)[a][c] = -sum_k Pp[a][k] G[c][k]
+                CGP_UNROLL for (int k = 0; k < 4; k++) n = fma(-Pp(a, k), G.a[c][k], n);
+                mine[kWalkG + a * 4 + c] = G.a[a][c];
+                mine[kWalkN + a * 4 + c] = n;
+                mine[kWalkPf + a * 4 + c] = Pf(a, c);                       // Sym::operator() is symmetric in its arguments
+                v = fma(-G.a[a][c], mp.v[c], v);                            // mf - G mp
+            }
+            mine[kWalkV + a] = v;
         }
-        // ---- the wavefront walks the tile from its last step to its first.  Steps before the start of the record (last
-        // tile) are walked too: their records are zero and their stores fall outside the windows (the step index wraps).
+    };
+    // the wavefront walks the tile in LDS from its last step to its first.  Steps before the start of the record (last tile)
+    // are walked too: their records are zero and their stores fall outside the windows (the step index wraps).
+    auto walk = [&](int64_t base) {
         auto fetch = [&](int s, Walk4Operands& o) {
             const double* p = recs + (s & 63) * kWalkRec;
             o.g = p[oG]; o.N = p[oN]; o.Pf = p[oPf]; o.v = p[oV];
@@ -120,14 +110,62 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             Ps = mfma4x4(cur.g, W, cur.Pf);                                // G W + Pf
             P4[s & 3] = Ps; m4[s & 3] = ms;
             if ((s & 3) == 0) {
-                const double Pv = (b == 0) ? P4[0] : (b == 1) ? P4[1] : (b == 2) ? P4[2] : P4[3];
-                const double mv = (b == 0) ? m4[0] : (b == 1) ? m4[1] : (b == 2) ? m4[2] : m4[3];
+                // block b takes step s + b: bank-masked moves (a DPP bank is a block), which -- unlike a select on b -- the
+                // compiler cannot turn into divergent branches that would cut the walk into sixteen basic blocks
+                constexpr int kSame = 0xE4;                                 // quad_perm:[0,1,2,3]
+                const double Pv = dpp_banks_f64<kSame, 0x8>(dpp_banks_f64<kSame, 0x4>(dpp_banks_f64<kSame, 0x2>(P4[0], P4[1]), P4[2]), P4[3]);
+                const double mv = dpp_banks_f64<kSame, 0x8>(dpp_banks_f64<kSame, 0x4>(dpp_banks_f64<kSame, 0x2>(m4[0], m4[1]), m4[2]), m4[3]);
                 const unsigned step = (unsigned)(base + s);
                 wPs.store(Pv, offP + step * 128u);
                 wms.store(mv, offm + step * 32u);
             }
         }
-        wave_lds_fence();
+    };
+
+    Vec<4> mf; Sym<4> Pf;
+    if constexpr (Elem::HAS_SPEC) {
+        // The gains of tile n + 1 are built WHILE tile n is walked: the walk is a serial chain of matrix instructions that leaves
+        // most issue slots empty, the gain of a step is ~400 independent vector instructions -- as straight-line code without
+        // regime branches (gain_spec) both sit in one basic block for the scheduler to interleave.  A lane outside the regime
+        // (rare) has its gain rebuilt by the checked form after the walk.  Rows are requested two tiles ahead.
+        {
+            Mat<4> G; Vec<4> mp; Sym<4> Pp;
+            request(T - 2 - 63, mf, Pf);
+            const bool valid = T - 2 - 63 + lane >= 0;
+            if (valid) elem.gain(mf, Pf, G, mp, Pp);
+            write_record(valid, G, mp, Pp, mf, Pf);
+            wave_lds_fence();
+            request(T - 2 - 127, mf, Pf);
+        }
+        for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+            const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
+            Vec<4> mf2; Sym<4> Pf2;
+            request(base - 128, mf2, Pf2);                                 // two tiles ahead: used at the end of the next iteration
+            Mat<4> G; Vec<4> mp; Sym<4> Pp; bool ok;
+            elem.gain_spec(mf, Pf, G, mp, Pp, ok);                         // tile n + 1 (on the clamped row where it does not exist)
+            walk(base);                                                    // tile n
+            wave_lds_fence();
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) elem.gain(mf, Pf, G, mp, Pp);
+            write_record(base - 64 + lane >= 0, G, mp, Pp, mf, Pf);
+            wave_lds_fence();
+            mf = mf2; Pf = Pf2;
+        }
+    } else {
+        request(T - 2 - 63, mf, Pf);
+        for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+            const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
+            // ---- every lane: prediction and gain of its own step, then its record
+            {
+                Mat<4> G; Vec<4> mp; Sym<4> Pp;
+                const bool valid = base + lane >= 0;
+                if (valid) elem.gain(mf, Pf, G, mp, Pp);
+                write_record(valid, G, mp, Pp, mf, Pf);
+            }
+            wave_lds_fence();
+            request(base - 64, mf, Pf);                                    // the NEXT (earlier) tile's row: requested now, used after the walk
+            walk(base);
+            wave_lds_fence();
+        }
     }
 }
 
