@@ -171,6 +171,34 @@ def test_ragged_lengths(T):
                    bk.run_pairs('port', c, only=('ekf', 'sgp_filter')), RTOL, f'T={T}')
 
 
+@pytest.mark.parametrize('T', [1, 2, 3, 4, 5, 63, 64, 65, 66, 67, 68, 129, 130, 200])
+def test_ragged_lengths_in_the_d4_walk_smoothers(T):
+    """d = 4 eks / sgp_smoother / rts on the wavefront walk (cgp_walk4.hpp): tiles of 64 steps whose results leave four steps
+    per store instruction -- records that end inside a store group, a tile, and the last tile walked past the start of the
+    record (its stores wrap out of the buffer windows); one trial of the batch carries NaN from the middle on."""
+    c = _batch_case(cs.chirp_case, 3, T=T)
+    c.ys = c.ys.copy()
+    if T > 8:
+        c.ys[1, T // 2] = np.nan
+    only = ('ekf', 'eks', 'sgp_filter', 'sgp_smoother')
+    want = bk.run_pairs('port', c, only=only)
+    got = bk.run_pairs('hip', c, hip_kw=WAVE, only=only)
+    bk.compare(got, want, RTOL, f'd4 walk T={T}')
+    sm = bk.smoothers_on('hip', c, want, hip_kw=WAVE)
+    bk.compare(sm, {k: want[k] for k in ('eks', 'sgp_smoother')}, RTOL, f'd4 walk T={T} smoothers on oracle inputs')
+    # linear model, d = 4: rts on the same kernel
+    from oracle import np_filters as nf
+    fs = _fs()
+    rng = np.random.default_rng(1000 + T)
+    F = 0.8 * np.eye(4) + 0.05 * rng.standard_normal((4, 4)); Sigma = 0.1 * np.eye(4)      # stable (spectral radius below 0.95 for these seeds): a well-conditioned smoother
+    H = np.array([1., 0.5, 0., 0.2]); ys = rng.standard_normal(T)
+    wf = nf.kf(F, Sigma, H, 0.3, np.zeros(4), np.eye(4), ys)
+    ws = nf.rts(F, Sigma, wf[0], wf[1])
+    gs = fs.rts(F, Sigma, wf[0], wf[1], **WAVE)
+    npt.assert_allclose(gs[0], ws[0], rtol=1e-9, atol=1e-12)
+    npt.assert_allclose(gs[1], ws[1], rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize('T', [1, 2, 3, 33, 63, 64, 65, 66, 97, 129, 130])
 def test_ragged_lengths_in_the_tile_layout_kernels(T):
     """d = 6 and d = 8 (cgp_coop8.hpp): the 64-step measurement chunks of the filters, and the cooperative smoother's tiles of
