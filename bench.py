@@ -175,8 +175,8 @@ N_SIMDS = 1024
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='ekf', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None,
                     help='trials: per GPU under weak scaling, in total under strong scaling (default: BASELINE config)')
