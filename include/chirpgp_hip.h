@@ -137,9 +137,9 @@ typedef struct cgp_init {
 #define CGP_NLL_FINAL_ONLY    0x1u   /* nll is [B]: only the last cumulative value (the MLE objective ekf(...)[-1][-1]) */
 #define CGP_WAVE_PER_TRIAL    0x2u   /* force one 64-lane wavefront per trial (small batches; default below a threshold)  */
 #define CGP_THREAD_PER_TRIAL  0x4u   /* force one lane per trial (large batches)                                           */
-#define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the time-parallel one    */
-#define CGP_GENERIC_KERNEL    0x10u  /* force the generic kernel where a lane-cooperative specialisation exists (filters; d >= 5
-                                        time-parallel smoothers: the lane-scan kernel instead of the cooperative walk)      */
+#define CGP_SEQUENTIAL_SCAN   0x8u   /* smoothers: force the step-by-step reverse scan instead of the tile-parallel forms   */
+#define CGP_GENERIC_KERNEL    0x10u  /* force the generic kernel where a lane-cooperative specialisation exists (filters; discrete
+                                        smoothers at d >= 4: the lane-scan time-parallel kernel instead of the cooperative walk) */
 #define CGP_LITERAL_SIGMA_SUM  0x40u  /* sigma-point methods: sum over every point even when the set is CGP_SIGMA_STANDARD     */
 #define CGP_DPP_KERNEL        0x80u  /* d = 4 chirp / La Scala models (ekf, sgp_filter, cd_ekf, cd_eks, cd_sgp_filter, cd_sgp_smoother):
                                         the DPP / LDS-reduced cooperative kernels instead of the matrix-core (MFMA) ones       */
