@@ -79,5 +79,8 @@ def test_real_launch_reaches_both_ranks():
     if has_gpu:
         pytest.skip('GPU box: covered by the -m gpu rehearsal test')
     assert p.returncode != 0
-    assert p.stderr.count('bench.py needs a GPU') >= 2, p.stderr[-2000:]
+    # the launcher terminates the surviving rank as soon as the first one fails, so the message may be seen once;
+    # its failure report names both ranks
+    assert p.stderr.count('bench.py needs a GPU') >= 1, p.stderr[-2000:]
+    assert 'local_rank: 0' in p.stderr and 'local_rank: 1' in p.stderr, p.stderr[-2000:]
     assert '"n_gpus"' not in p.stdout
