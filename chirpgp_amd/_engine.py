@@ -68,7 +68,7 @@ def load_library():
         lib.cgp_last_error.argtypes = [_vp]
         lib.cgp_filter.restype = C.c_int
         lib.cgp_filter.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.POINTER(CgpInit), C.c_double,
-                                   _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
+                                   _vp, C.c_int64, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_smoother.restype = C.c_int
         lib.cgp_smoother.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
@@ -278,17 +278,33 @@ def _out(t, like_numpy, squeeze):
     return t.cpu().numpy() if like_numpy else t
 
 
-def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, flags=0, want=(True, True, True)):
-    """cgp_filter with NumPy / torch marshalling.  ys (T,) or (B, T) -> (mfs, Pfs, nll) with matching leading axes."""
+def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, flags=0, want=(True, True, True),
+               trials_per_record=None, record_index=None):
+    """cgp_filter with NumPy / torch marshalling.  ys (T,) or (B, T) -> (mfs, Pfs, nll) with matching leading axes.
+
+    Shared records (include/chirpgp_hip.h, cgp_filter): with ``trials_per_record = k`` every record of ys -- (T,) or (R, T) --
+    serves k consecutive trials (k parameter vectors of a sweep, the 2 P + 1 probes of a difference gradient), B = R k, and
+    the results always carry the batch axis; ``record_index`` (n,) picks and orders the records first (B = n k).  The
+    record is read from ONE copy in HBM: nothing is replicated."""
     torch = _torch()
     like_numpy = not _is_torch(ys)
     ys_d = dev(ys)
-    squeeze = ys_d.ndim == 1
-    if squeeze:
+    shared = trials_per_record is not None or record_index is not None
+    squeeze = ys_d.ndim == 1 and not shared
+    if ys_d.ndim == 1:
         ys_d = ys_d[None, :]
     if ys_d.ndim != 2:
         raise ValueError(f'ys must be (T,) or (B, T), got {tuple(ys_d.shape)}')
-    B, T = int(ys_d.shape[0]), int(ys_d.shape[1])
+    R, T = int(ys_d.shape[0]), int(ys_d.shape[1])
+    rep = 1 if trials_per_record is None else int(trials_per_record)
+    if rep < 1:
+        raise ValueError('trials_per_record must be >= 1')
+    idx_h = None
+    if record_index is not None:
+        idx_h = np.ascontiguousarray(np.asarray(record_index, dtype=np.int64).reshape(-1))
+        if idx_h.size and (idx_h.min() < 0 or idx_h.max() >= R):
+            raise ValueError(f'record_index outside 0..{R - 1}')
+    B = (R if idx_h is None else int(idx_h.size)) * rep
     d = int(spec.d)
     if d > MAX_D:
         raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
@@ -296,6 +312,10 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     with torch.cuda.device(ys_d.device):
         ctx = context(ys_d.device.index)
         keep = [ys_d]
+        idx_d = None
+        if idx_h is not None:
+            idx_d = torch.from_numpy(idx_h.astype(np.int32)).to(ys_d.device)
+            keep.append(idx_d)
         model = _model_struct(spec, gamma, B, keep)
         sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
         init = _init_struct(H, Xi, m0, P0, d, B, keep)
@@ -306,7 +326,8 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
         lib, st = load_library(), _stream()
         rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                                     C.byref(init), float(dt), _ptr(ys_d), B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
+                                                     C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
+                                                     _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
         _check(ctx, rc, 'cgp_filter')
         return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
 

@@ -146,12 +146,14 @@ const char* cgp_last_error(const cgp_ctx* ctx) {
 }
 
 int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
-               double dt, const double* ys, int64_t B, int64_t T, double* mfs, double* Pfs, double* nll,
-               uint32_t flags, void* stream) {
+               double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+               int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream) {
     if (!ctx) return CGP_E_ARG;
     if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
     if (B == 0 || T == 0) return CGP_OK;
     if (!ys) return fail(ctx, CGP_E_ARG, "ys is NULL");
+    if (ys_stride < 0) return fail(ctx, CGP_E_ARG, "ys_stride must be >= 0 (T for dense [B][T] records, 0 for one shared record)");
+    if (ys_repeat < 1) return fail(ctx, CGP_E_ARG, "ys_repeat must be >= 1");
     if (!init || !init->Xi || !init->m0 || !init->P0) return fail(ctx, CGP_E_ARG, "init.Xi / m0 / P0 must be set");
     if (method != CGP_F_EKF_KPT && !init->H) return fail(ctx, CGP_E_ARG, "init.H must be set");
     const bool sde = method == CGP_F_CD_EKF || method == CGP_F_CD_SGP;
@@ -168,7 +170,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.Xi = init->Xi; io.Xi_stride = init->Xi_stride;
     io.m0 = init->m0; io.m0_stride = init->m0_stride;
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
-    io.ys = ys; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
+    io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt, flags);
     const bool mfma_ekf = method == CGP_F_EKF && model->n_harm == 1 && !(flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_ONE_TRIAL_PER_WAVE)) &&
                           (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) ekf4_coop_kernel(FilterIO io, ModelArgs ma
     double P = coop4_load_sym_entry(P0p, li, lj);
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * 4 : nullptr;
     double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * 16 : nullptr;
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64) sgp4_coop_kernel(FilterIO io, ModelArgs ma
     double u0 = m0p[0], u1 = m0p[1], u2 = m0p[2], u3 = m0p[3];
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, li, lj);
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     Coop4FilterOut out;
     out.init(io, trial);
     const int ng = sg.groups();
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(64) cdsgp4_coop_kernel(FilterIO io, ModelArgs 
     u.v[0] = m0p[0]; u.v[1] = m0p[1]; u.v[2] = m0p[2]; u.v[3] = m0p[3];
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, li, lj);
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     Coop4FilterOut out;
     out.init(io, trial);
     const int ng = sg.groups();

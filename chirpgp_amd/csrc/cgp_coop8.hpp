@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     double P = entry ? ((i >= j) ? P0p[i * D + j] : P0p[j * D + i]) : 0.0;
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
     double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
     double P = entry ? ((i >= j) ? P0p[i * D + j] : P0p[j * D + i]) : 0.0;
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     OobWindow wP, wm;                                                    // which lanes store is an offset, not a branch
     wP.init(io.Pfs ? io.Pfs + trial * T * D * D : nullptr, T * (D * D * 8));
     wm.init(io.mfs ? io.mfs + trial * T * D : nullptr, T * (D * 8));

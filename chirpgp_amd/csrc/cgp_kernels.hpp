@@ -19,11 +19,22 @@ struct FilterIO {
     const double* __restrict__ m0; int64_t m0_stride;
     const double* __restrict__ P0; int64_t P0_stride;
     const double* __restrict__ ys;
+    int64_t ys_stride;                       // doubles between records (T for the dense [B][T] layout; 0 = one shared record)
+    int64_t ys_repeat;                       // >= 1: consecutive trials served by one record
+    const int32_t* __restrict__ ys_index;    // optional record number per group of ys_repeat trials
     int64_t B, T;
     double* __restrict__ mfs;
     double* __restrict__ Pfs;
     double* __restrict__ nll;
     uint32_t flags;
+    // The measurement record of a trial (include/chirpgp_hip.h, cgp_filter): trial b reads record ys_index[b / ys_repeat]
+    // (b / ys_repeat without an index) -- a parameter sweep or the 2 P + 1 probes of a difference gradient read ONE copy.
+    __device__ __forceinline__ const double* record(int64_t trial) const {
+        int64_t g = trial;
+        if (ys_repeat > 1) g = (int64_t)((uint64_t)trial / (uint64_t)ys_repeat);
+        if (ys_index) g = ys_index[g];
+        return ys + g * ys_stride;
+    }
 };
 
 struct SmootherIO {
@@ -185,7 +196,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
     load_sym<D>(io.P0 + trial * io.P0_stride, Pf);
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     double* __restrict__ mfs = io.mfs ? io.mfs + trial * T * D : nullptr;
     double* __restrict__ Pfs = io.Pfs ? io.Pfs + trial * T * D * D : nullptr;
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;

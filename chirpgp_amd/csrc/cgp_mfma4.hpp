@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     x.P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     OobWindow mfs, Pfs;
     mfs.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     Pfs.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
         wave_lds_fence();
         CGP_UNROLL for (int bb = 0; bb < 4; bb++) {
             const int64_t tr = first + (bb < ntr ? bb : ntr - 1);
-            ych[bb][lane] = (t0 + lane < T) ? io.ys[tr * T + t0 + lane] : 0.0;
+            ych[bb][lane] = (t0 + lane < T) ? io.record(tr)[t0 + lane] : 0.0;
         }
         wave_lds_fence();
         const Ekf4State x0 = x;

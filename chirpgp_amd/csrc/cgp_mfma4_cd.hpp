@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     double u = io.m0[trial * io.m0_stride + q];                          // the mean in column form
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     OobWindow wP, wm;
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64) cdekf4_mfma_kernel(FilterIO io, ModelArgs 
     double u = io.m0[trial * io.m0_stride + q];                          // the mean in column form
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     OobWindow wP, wm;
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
     double P = (r >= q) ? P0p[r * 4 + q] : P0p[q * 4 + r];
 
     const int64_t T = io.T;
-    const double* __restrict__ ys = io.ys + trial * T;
+    const double* __restrict__ ys = io.record(trial);
     OobWindow wP, wm;
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);

@@ -5,7 +5,7 @@ The reference minimises ``obj(theta) = filter(build_model(g(theta)), ys)[-1][-1]
 reverse-mode autodiff THROUGH the scan.  A HIP kernel is not JAX-differentiable; instead the engine's strengths are
 used: the filters take one parameter vector per trial and an NLL-only output mode, so the objective and its central
 finite-difference gradient -- 2 P + 1 filter passes over the same measurements -- are ONE kernel launch with a batch of
-2 P + 1 "trials" (13 for the chirp model's 6 parameters).  The optimiser itself stays SciPy's L-BFGS-B on the host,
+2 P + 1 "trials" (13 for the chirp model's 6 parameters) that all read the ONE copy of the record in HBM.  The optimiser itself stays SciPy's L-BFGS-B on the host,
 exactly the algorithm the reference uses.
 """
 import numpy as np
@@ -13,36 +13,42 @@ import numpy as np
 from chirpgp_amd import filters_smoothers as fs
 from chirpgp_amd import models as M
 
-__all__ = ['batched_nll', 'make_objective', 'fit', 'fit_many']
+__all__ = ['batched_nll', 'make_objective', 'fit', 'fit_many', 'grid_search']
 
 
-def batched_nll(method, build, thetas, ys, Xi, dt, sgps=None, **build_kw):
+def batched_nll(method, build, thetas, ys, Xi, dt, sgps=None, record_index=None, **build_kw):
     """Final cumulative NLL of ``method`` for every row of ``thetas`` (unconstrained parameters, g() maps them to the
-    positive model parameters as in the reference) on the SAME measurement record ``ys`` (T,), or on its own record
-    when ``ys`` is (G, T).
+    positive model parameters as in the reference).  ``ys`` is ONE record (T,) read by all G rows, or R records (R, T) of
+    which each serves G / R consecutive rows (``record_index`` (n,) first picks n of them: G / n rows each).  The records
+    are read in place through the C-ABI's shared-record addressing (include/chirpgp_hip.h, cgp_filter): nothing is
+    replicated, on the host or on the device.
 
-    method: 'ekf' | 'sgp_filter' | 'cd_ekf' | 'cd_sgp_filter';  build: e.g. models.build_chirp_model."""
+    method: 'ekf' | 'sgp_filter' | 'cd_ekf' | 'cd_sgp_filter' with a 6-tuple builder (models.build_chirp_model,
+    build_harmonic_chirp_model, build_lascala_model), or 'ekf_for_kpt' with models.build_kpt_chirp_model (pass ``fs=``,
+    ``num_harmonics=``): tetralith/jobs/kpt_mle.py:41-44."""
     thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
     G = thetas.shape[0]
-    drift, disp, disc, m0, P0, H = build(M.g(thetas), **build_kw)
-    if type(ys).__module__.startswith('torch'):                               # records already in HBM (fit_many)
-        ysb = ys if ys.ndim == 2 else ys[None, :].expand(G, -1)
+    n_rec = 1 if np.ndim(ys) == 1 else int(np.shape(ys)[0])
+    if record_index is not None:
+        n_rec = int(np.size(record_index))
+    if n_rec < 1 or G % n_rec:
+        raise ValueError(f'{G} parameter vectors cannot be shared out evenly over {n_rec} records')
+    kw = dict(nll_final_only=True, want=(False, False, True), trials_per_record=G // n_rec, record_index=record_index)
+    if method == 'ekf_for_kpt':
+        F, Sigma, m0, P0, h = build(M.g(thetas), **build_kw)
+        out = fs.ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw)
     else:
-        ys = np.asarray(ys, dtype=np.float64)
-        ysb = np.broadcast_to(ys, (G, ys.shape[-1])) if ys.ndim == 1 else ys  # one record for all rows, or one per row
-    if ysb.shape[0] != G:
-        raise ValueError(f'ys has {ysb.shape[0]} records for {G} parameter vectors')
-    kw = dict(nll_final_only=True, want=(False, False, True))
-    if method == 'ekf':
-        out = fs.ekf(disc, H, Xi, m0, P0, dt, ysb, **kw)
-    elif method == 'sgp_filter':
-        out = fs.sgp_filter(disc, sgps, H, Xi, m0, P0, dt, ysb, **kw)
-    elif method == 'cd_ekf':
-        out = fs.cd_ekf(drift, disp, H, Xi, m0, P0, dt, ysb, **kw)
-    elif method == 'cd_sgp_filter':
-        out = fs.cd_sgp_filter(drift, disp, sgps, H, Xi, m0, P0, dt, ysb, **kw)
-    else:
-        raise ValueError(method)
+        drift, disp, disc, m0, P0, H = build(M.g(thetas), **build_kw)
+        if method == 'ekf':
+            out = fs.ekf(disc, H, Xi, m0, P0, dt, ys, **kw)
+        elif method == 'sgp_filter':
+            out = fs.sgp_filter(disc, sgps, H, Xi, m0, P0, dt, ys, **kw)
+        elif method == 'cd_ekf':
+            out = fs.cd_ekf(drift, disp, H, Xi, m0, P0, dt, ys, **kw)
+        elif method == 'cd_sgp_filter':
+            out = fs.cd_sgp_filter(drift, disp, sgps, H, Xi, m0, P0, dt, ys, **kw)
+        else:
+            raise ValueError(method)
     nll = out[2]
     return nll.cpu().numpy() if type(nll).__module__.startswith('torch') else np.asarray(nll)
 
@@ -76,17 +82,16 @@ def fit(method, build, init_params, ys, Xi, dt, sgps=None, maxiter=200, **build_
     return M.g(res.x), res
 
 
-def _value_and_grad_many(method, build, thetas, yss, Xi, dt, sgps, rel_step, build_kw):
-    """NLL and central-difference gradient of R records at R parameter vectors: ONE launch of R (2 P + 1) trials."""
+def _value_and_grad_many(method, build, thetas, yss, Xi, dt, sgps, rel_step, build_kw, record_index=None):
+    """NLL and central-difference gradient of R records (the rows ``record_index`` of yss; all of them by default) at R
+    parameter vectors: ONE launch of R (2 P + 1) trials, each record read in place by its 2 P + 1 probes."""
     R, P = thetas.shape
     h = rel_step * (1.0 + np.abs(thetas))                                   # (R, P)
     batch = np.repeat(thetas[:, None, :], 2 * P + 1, axis=1)                # (R, 2P+1, P)
     idx = np.arange(P)
     batch[:, 1 + 2 * idx, idx] += h
     batch[:, 2 + 2 * idx, idx] -= h
-    # record r serves its 2P+1 rows; the records live in HBM, so the replication is a device-side copy
-    ys_rep = yss.repeat_interleave(2 * P + 1, dim=0) if type(yss).__module__.startswith('torch') else np.repeat(yss, 2 * P + 1, axis=0)
-    nll = batched_nll(method, build, batch.reshape(-1, P), ys_rep, Xi, dt, sgps, **build_kw).reshape(R, 2 * P + 1)
+    nll = batched_nll(method, build, batch.reshape(-1, P), yss, Xi, dt, sgps, record_index=record_index, **build_kw).reshape(R, 2 * P + 1)
     f = nll[:, 0].copy()
     grad = (nll[:, 1::2] - nll[:, 2::2]) / (2 * h)
     f[~np.isfinite(f)] = np.inf
@@ -103,7 +108,7 @@ def fit_many(method, build, init_params, yss, Xi, dt, sgps=None, maxiter=200, hi
 
     yss (R, T);  init_params (P,) or (R, P) positive model parameters  ->  (opt_params (R, P), info dict)."""
     from chirpgp_amd import _engine as E
-    yss = E.dev(yss)                                  # uploaded once; every probe replicates rows on the device
+    yss = E.dev(yss)                                  # uploaded once; every probe of every line search reads it in place
     if yss.ndim == 1:
         yss = yss[None, :]
     R = yss.shape[0]
@@ -144,7 +149,7 @@ def fit_many(method, build, init_params, yss, Xi, dt, sgps=None, maxiter=200, hi
                 break
             idx = np.flatnonzero(searching)
             xt = x[idx] + step[idx, None] * d[idx]
-            ft, gt = _value_and_grad_many(method, build, xt, yss[E.torch_index(idx, yss)], Xi, dt, sgps, rel_step, build_kw)
+            ft, gt = _value_and_grad_many(method, build, xt, yss, Xi, dt, sgps, rel_step, build_kw, record_index=idx)
             launches += 1
             ok = ft <= f[idx] + 1e-4 * step[idx] * gd[idx]
             acc = idx[ok]
@@ -163,3 +168,21 @@ def fit_many(method, build, init_params, yss, Xi, dt, sgps=None, maxiter=200, hi
         nit[moved] += 1
         done |= failed | (moved & (small | (np.abs(g).max(axis=1) <= gtol)))
     return M.g(x), dict(fun=f, grad=g, nit=nit, launches=launches, converged=done)
+
+
+def grid_search(method, build, grid, yss, Xi, dt, sgps=None, **build_kw):
+    """Parameter-grid MLE sweep (BASELINE config C5: "batch x param-grid MLE sweep"): the final NLL of ``method`` at every
+    grid point for every record, in ONE launch of R G trials -- G parameter vectors per record, each record read in place.
+
+    grid (G, P) positive model parameters; yss (R, T) or (T,)  ->  (best (R, P), nll (R, G), argmin (R,)).
+    A diverged grid point (NaN / inf NLL) never wins; a record whose every grid point diverges gets NaN parameters."""
+    grid = np.atleast_2d(np.asarray(grid, dtype=np.float64))
+    G = grid.shape[0]
+    R = 1 if np.ndim(yss) == 1 else int(np.shape(yss)[0])
+    thetas = np.tile(M.g_inv(grid), (R, 1))                     # record-major: the G rows of a record are consecutive trials
+    nll = batched_nll(method, build, thetas, yss, Xi, dt, sgps, **build_kw).reshape(R, G)
+    masked = np.where(np.isfinite(nll), nll, np.inf)
+    arg = np.argmin(masked, axis=1)
+    best = M.g(M.g_inv(grid))[arg]                              # the parameters the filter actually ran with
+    best[~np.isfinite(masked[np.arange(R), arg])] = np.nan
+    return best, nll, arg

@@ -159,8 +159,9 @@ def linear_cond_m_cov(F, Sigma):
     """Descriptor of ``lambda u, dt: (F @ u, Sigma)`` (the linear test model of test_filters_smoothers.py:56-58)."""
     F, Sigma = _f64(F), _f64(Sigma)
     d = F.shape[-1]
-    lead = F.shape[:-2]
-    params = np.concatenate([F.reshape(lead + (d * d,)), np.broadcast_to(Sigma, lead + (d, d)).reshape(lead + (d * d,))], axis=-1)
+    lead = np.broadcast_shapes(F.shape[:-2], Sigma.shape[:-2])          # either may carry the batch axis
+    params = np.concatenate([np.broadcast_to(F, lead + (d, d)).reshape(lead + (d * d,)),
+                             np.broadcast_to(Sigma, lead + (d, d)).reshape(lead + (d * d,))], axis=-1)
     return DiscreteModel(M_LINEAR, d, 0, params)
 
 
@@ -295,16 +296,14 @@ def build_lascala_model(params):
 
 
 def build_kpt_chirp_model(params, fs, num_harmonics=1):
-    """models.py:522-580 -> F, Sigma, m0, P0, h."""
-    q1, q2, p0, f0, a0 = [float(x) for x in params]
+    """models.py:522-580 -> F, Sigma, m0, P0, h.  params = q1, q2, p0, f0, a0 (optionally with a leading batch axis: Sigma,
+    m0 and P0 then carry it, F is shared)."""
+    q1, q2, p0, f0, a0 = _split(params, 5)
     n = int(num_harmonics)
     dim_x = n + 2
-    P0 = p0 * np.eye(dim_x)
-    m0 = np.array([2 * math.pi * f0 / fs] + [a0] * n + [0.])
+    P0 = _diag_rows([p0] * dim_x)
+    m0 = _stack(2 * math.pi * f0 / fs, *([a0] * n), 0.)
     F = np.eye(dim_x)
     F[-1, 0] = 1.
-    Sigma = np.zeros((dim_x, dim_x))
-    Sigma[0, 0] = (2 * math.pi * q1 / fs) ** 2
-    for k in range(1, n + 1):
-        Sigma[k, k] = q2
+    Sigma = _diag_rows([(2 * math.pi * q1 / fs) ** 2] + [q2] * n + [0.])
     return F, Sigma, m0, P0, MeasurementKPT(n)

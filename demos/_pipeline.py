@@ -14,14 +14,22 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from chirpgp_amd import filters_smoothers as fs, mle, results                       # noqa: E402
-from chirpgp_amd.models import g, build_chirp_model, build_harmonic_chirp_model     # noqa: E402
+from chirpgp_amd.models import (g, build_chirp_model, build_harmonic_chirp_model, build_lascala_model,     # noqa: E402
+                                build_kpt_chirp_model)
 from chirpgp_amd.quadratures import gaussian_expectation                            # noqa: E402
 from chirpgp_amd.toymodels import (gen_chirp, gen_harmonic_chirp, meow_freq, constant_mag, damped_exp_mag,   # noqa: E402
                                    random_ou_mag)
 from chirpgp_amd.tools import rmse                                                  # noqa: E402
 
 INIT_PARAMS = [0.1, 0.1, 0.1, 1., 1., 7.]       # lam, b, delta, ell, sigma, m0_1 (demos/ekfs_mle.py:39)
-FILTER_OF = {'ekfs': 'ekf', 'ghfs': 'sgp_filter', 'cd_ekfs': 'cd_ekf', 'cd_ghfs': 'cd_sgp_filter'}
+FILTER_OF = {'ekfs': 'ekf', 'ghfs': 'sgp_filter', 'cd_ekfs': 'cd_ekf', 'cd_ghfs': 'cd_sgp_filter', 'kpt': 'ekf_for_kpt'}
+# model families of the reference's jobs: builder, MLE start point (positive parameters)
+FAMILIES = {
+    'chirp': (build_chirp_model, INIT_PARAMS),                          # tetralith/jobs/ekfs_mle.py:37
+    'harmonic': (build_harmonic_chirp_model, INIT_PARAMS),              # tetralith/jobs/harmonic_ekfs_mle.py:40
+    'lascala': (build_lascala_model, [0.1, 1., 1., 7.]),                # tetralith/jobs/lascala_ekfs_mle.py:37: delta, ell, sigma, m0_1
+    'kpt': (build_kpt_chirp_model, [0.02, 1e-5, 1e-5, 8., 1.]),         # tetralith/jobs/kpt_mle.py:38: q1, q2, p0, f0, a0
+}
 
 
 def magnitudes(rng):
@@ -29,14 +37,30 @@ def magnitudes(rng):
     return (('const', constant_mag(1.)), ('damped', damped_exp_mag(0.3)), ('ou', random_ou_mag(1., 1., rng)))
 
 
-def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=INIT_PARAMS):
-    """MLE -> filter -> smoother -> E[g(V)] on one measurement record.  method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs'.
+def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
+    """MLE -> filter -> smoother -> E[g(V)] on one measurement record.
+    method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs' | 'kpt';  family: 'chirp' | 'harmonic' | 'lascala' | 'kpt'
+    (default: 'kpt' for method 'kpt', else 'harmonic' when num_harmonics > 0, else 'chirp').
     Returns a dict with opt_params, the scipy result, nll0 (objective at the start), the smoothing results and est_freq."""
-    build = build_chirp_model if num_harmonics == 0 else build_harmonic_chirp_model
-    build_kw = {} if num_harmonics == 0 else dict(num_harmonics=num_harmonics)
+    if family is None:
+        family = 'kpt' if method == 'kpt' else ('harmonic' if num_harmonics else 'chirp')
+    build, init_default = FAMILIES[family]
+    init = init_default if init is None else init
+    build_kw = {}
+    if family == 'harmonic':
+        build_kw = dict(num_harmonics=num_harmonics)
+    elif family == 'kpt':
+        build_kw = dict(fs=1. / dt, num_harmonics=max(num_harmonics, 1))
     filt = FILTER_OF[method]
     nll0 = float(mle.batched_nll(filt, build, np.log(np.expm1(np.asarray(init, dtype=np.float64))), ys, Xi, dt, sgps, **build_kw)[0])
     opt_params, res = mle.fit(filt, build, init, ys, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
+    if method == 'kpt':      # tetralith/jobs/kpt_mle.py:54-76: ekf_for_kpt, then the LINEAR smoother; frequency = g(x_0) fs / 2 pi
+        F, Sigma, m0, P0, h = build(opt_params, **build_kw)
+        mfs, Pfs, _ = fs.ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys)
+        mss, Pss = fs.rts(F, Sigma, mfs, Pfs)
+        scale = 1. / dt / 2 / math.pi
+        est = gaussian_expectation(ms=mss[:, 0] * scale, chol_Ps=np.sqrt(Pss[:, 0, 0]) * scale, func=g, force_shape=True)[:, 0]
+        return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
     drift, dispersion, m_and_cov, m0, P0, H = build(opt_params, **build_kw)
     if method == 'ekfs':
         mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
@@ -55,8 +79,13 @@ def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init
     return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
 
 
-def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001, maxiter=200, save_dir=None, mags=None, quiet=False):
-    """One run per magnitude law, as the reference's demo scripts do; returns [(name, rmse, nll0, nll_opt), ...]."""
+def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001, maxiter=200, save_dir=None, mags=None, quiet=False,
+         family=None, signal_harmonics=None, result_name=None, mc=None):
+    """One run per magnitude law, as the reference's demo scripts do; returns [(name, rmse, nll0, nll_opt), ...].
+    ``signal_harmonics``: harmonics of the SIGNAL (default: those of the model); ``result_name``: file stem of the saved
+    results (the reference's jobs: 'kpt_mle', 'lascala_ekfs_mle', ...; default: the method name), numbered ``mc`` (default: the
+    position of the magnitude law, as the demos have a single run)."""
+    sig_h = num_harmonics if signal_harmonics is None else signal_harmonics
     ts = np.linspace(dt, dt * T, T)
     rng = np.random.default_rng(seed)
     true_freq_func, true_phase_func = meow_freq(offset=8.)
@@ -64,13 +93,13 @@ def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001,
     for k, (name, mag) in enumerate(magnitudes(rng)):
         if mags is not None and name not in mags:
             continue
-        clean = gen_chirp(ts, mag, true_phase_func) if num_harmonics == 0 else gen_harmonic_chirp(ts, [mag] * num_harmonics, true_phase_func)
+        clean = gen_chirp(ts, mag, true_phase_func) if sig_h == 0 else gen_harmonic_chirp(ts, [mag] * sig_h, true_phase_func)
         ys = clean + math.sqrt(Xi) * rng.standard_normal(T)
         t0 = time.time()
-        r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter)
+        r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter, family=family)
         err = float(rmse(true_freq_func(ts), r['est_freq'])) if r['res'].success or np.isfinite(r['res'].fun) else float('nan')
         if save_dir:       # tetralith/jobs/ekfs_mle.py:75-81: NaN results for a diverged run
-            results.save_result(save_dir, method, name, k, r['mss'], r['Pss'], err)
+            results.save_result(save_dir, result_name or method, name, k if mc is None else mc, r['mss'], r['Pss'], err)
         if not quiet:
             print(f'{method:8s} {name:7s} params {np.array2string(r["opt_params"], precision=3)}  nll {r["nll0"]:.2f} -> {r["res"].fun:.2f}  '
                   f'iters {r["res"].nit} ({r["res"].nfev} launches)  RMSE {err:.3f} Hz  [{time.time() - t0:.2f} s]')

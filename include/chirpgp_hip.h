@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 100          /* 0.1.0 */
+#define CGP_VERSION 110          /* 0.1.1: measurement records may be shared between trials (cgp_filter) */
 #define CGP_MAX_D   8            /* largest state dimension compiled in */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -161,10 +161,20 @@ void        cgp_destroy(cgp_ctx* ctx);
  * device and restores the calling thread's current device before it returns. */
 const char* cgp_last_error(const cgp_ctx* ctx);
 
-/* Filters: reads ys, writes mfs / Pfs / nll (any of the three may be NULL = not wanted). */
+/* Filters: reads ys, writes mfs / Pfs / nll (any of the three may be NULL = not wanted).
+ *
+ * Measurement records.  The reference's drivers run MANY filters over ONE record: the MLE objective under value_and_grad
+ * (demos/ekfs_mle.py:43-48), a parameter-grid sweep (BASELINE config C5, demos/ghfs_harmonics_mle.py:50-64).  The trials of
+ * a call therefore need not own a record each:
+ *     trial b reads the T doubles at  ys + rec(b) * ys_stride,   rec(b) = ys_index ? ys_index[b / ys_repeat] : b / ys_repeat
+ *   ys_stride   doubles between consecutive records: T for the dense [B][T] layout of jax.vmap over ys; 0 = one record
+ *               shared by every trial; any value >= 0 is legal (records are only read, they may overlap)
+ *   ys_repeat   >= 1; consecutive trials served by the same record (G grid points or 2 P + 1 gradient probes per record)
+ *   ys_index    NULL, or a DEVICE array of ceil(B / ys_repeat) record numbers (a subset / permutation of the records)
+ * The dense batched call is (ys_stride, ys_repeat, ys_index) = (T, 1, NULL). */
 int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
-               double dt, const double* ys, int64_t B, int64_t T,
-               double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
+               double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+               int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
 
 /* Smoothers: reads mfs / Pfs, writes mss / Pss (row T-1 is the filtering row T-1). */
 int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,

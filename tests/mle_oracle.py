@@ -8,7 +8,8 @@ import numpy as np
 
 from oracle import port
 
-METHOD = {'ekf': port.F_EKF, 'sgp_filter': port.F_SGP, 'cd_ekf': port.F_CD_EKF, 'cd_sgp_filter': port.F_CD_SGP}
+METHOD = {'ekf': port.F_EKF, 'sgp_filter': port.F_SGP, 'cd_ekf': port.F_CD_EKF, 'cd_sgp_filter': port.F_CD_SGP,
+          'ekf_for_kpt': port.F_EKF_KPT}
 
 
 def g(x):
@@ -22,8 +23,15 @@ def g_inv(x):
 def nll(method, build, thetas, ys, Xi, dt, sgps=None, **build_kw):
     """Final NLL for every row of `thetas` on the same record: one batched call of the C port (per-trial parameters)."""
     thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
-    drift, disp, disc, m0, P0, H = build(g(thetas), **build_kw)
     ysb = np.broadcast_to(np.asarray(ys, dtype=np.float64), (thetas.shape[0], len(ys)))
+    if method == 'ekf_for_kpt':        # tetralith/jobs/kpt_mle.py:41-44: build -> (F, Sigma, m0, P0, h); the port takes a linear
+        F, Sigma, m0, P0, h = build(g(thetas), **build_kw)      # descriptor re-labelled as the KPT model, like the engine
+        import copy as _copy
+        from chirpgp_amd import models as pm                    # descriptor classes only (no device code behind them)
+        spec = _copy.copy(pm.linear_cond_m_cov(F, Sigma))
+        spec.model_id, spec.n_harm = port.M_KPT, h.n_harm
+        return port.filter(port.F_EKF_KPT, spec, None, None, Xi, m0, P0, dt, ysb, nll_final_only=True)[2]
+    drift, disp, disc, m0, P0, H = build(g(thetas), **build_kw)
     if method in ('ekf', 'sgp_filter'):
         model = disc
     else:

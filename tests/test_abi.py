@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     assert set(names) == set(eng.EXPORTS), (names, eng.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in chirpgp_hip.h but not exported'
-    assert lib.cgp_version() == 100
+    assert lib.cgp_version() == 110
 
 
 def test_struct_layouts_match_header():
@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
 
 def test_null_context_is_rejected_without_gpu():
     lib, _ = _lib()
-    assert lib.cgp_filter(None, 0, None, None, None, 0.0, None, 1, 1, None, None, None, 0, None) == -1
+    assert lib.cgp_filter(None, 0, None, None, None, 0.0, None, 1, 1, None, 1, 1, None, None, None, 0, None) == -1
     assert lib.cgp_smoother(None, 0, None, None, 0.0, None, None, 1, 1, None, None, 0, None) == -1
 
 

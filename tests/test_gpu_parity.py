@@ -435,7 +435,7 @@ def test_c_abi_argument_errors():
     buf = torch.zeros(64, dtype=torch.float64, device='cuda')
     model = E.CgpModel(E.M_HARMONIC_LCD, d, 1, 5, params.data_ptr(), 0, None, 0)
     init = E.CgpInit(buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0)
-    args = (C.byref(init), 0.1, buf.data_ptr(), 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
+    args = (C.byref(init), 0.1, buf.data_ptr(), 4, 1, None, 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
     assert lib.cgp_filter(ctx, E.F_CD_EKF, C.byref(model), None, *args) == -1            # SDE method, discrete model
     assert b'SDE model' in lib.cgp_last_error(ctx)
     assert lib.cgp_filter(ctx, E.F_SGP, C.byref(model), None, *args) == -1               # sigma method without points
@@ -445,7 +445,7 @@ def test_c_abi_argument_errors():
     lin9 = E.CgpModel(E.M_LINEAR, 9, 0, 162, params.data_ptr(), 0, None, 0)
     assert lib.cgp_filter(ctx, E.F_EKF, C.byref(lin9), None, *args) == -2                # not compiled in
     assert b'dimension' in lib.cgp_last_error(ctx)
-    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(model), None, C.byref(init), 0.1, buf.data_ptr(), 0, 4, None, None, None, 0, None) == 0   # B = 0
+    assert lib.cgp_filter(ctx, E.F_EKF, C.byref(model), None, C.byref(init), 0.1, buf.data_ptr(), 4, 1, None, 0, 4, None, None, None, 0, None) == 0   # B = 0
     from chirpgp_amd import filters_smoothers as fs
     with pytest.raises(NotImplementedError):
         fs.kf(np.eye(9), np.eye(9), np.ones(9), 0.1, np.zeros(9), np.eye(9), np.zeros(5))
@@ -641,7 +641,7 @@ def test_last_error_is_per_thread():
     params = torch.zeros(200, dtype=torch.float64, device='cuda')
     buf = torch.zeros(64, dtype=torch.float64, device='cuda')
     init = E.CgpInit(buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0, buf.data_ptr(), 0)
-    args = (C.byref(init), 0.1, buf.data_ptr(), 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
+    args = (C.byref(init), 0.1, buf.data_ptr(), 4, 1, None, 1, 4, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 0, None)
     lcd = E.CgpModel(E.M_HARMONIC_LCD, 4, 1, 5, params.data_ptr(), 0, None, 0)
     lin9 = E.CgpModel(E.M_LINEAR, 9, 0, 162, params.data_ptr(), 0, None, 0)
     seen, barrier = {}, threading.Barrier(2)
