@@ -5,7 +5,8 @@ A "step" is one pass of the hot path over one batch of synthetic input: the filt
 the smoother launch (mfs, Pfs -> mss, Pss), inputs already resident in HBM.  Default workload = BASELINE config C2:
 discrete EKF + EKS of the demos' chirp model (demos/ekfs_mle.py), d = 4, T = 10 000, B = 1000 Monte-Carlo trials per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ekf|sgp|cd_sgp|cd_ekf|harmonic] [--batch B] [--T T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kf|ekf|sgp|cd_sgp|cd_ekf|harmonic] [--batch B] [--T T]
+                    [--force-dist] [--no-other-configs] [--no-cpu-baseline]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run as a child
 process, one rank per GPU over RCCL; the parent never touches the GPU); under an external torchrun it checks that
@@ -13,6 +14,12 @@ WORLD_SIZE == N.  Trials shard across ranks with no data-path collective; one al
 happens after the timed region and is reported as gather_ms.  Scaling: C2 (`ekf`) is weak by default (B = 1000 per
 rank) and also reports the strong figure (B = 1000 in total) under "strong"; C3 / C5 (`sgp`, `harmonic`) are strong
 by default ("batch=1000 sharded 8 GPUs", BASELINE.json); `--scaling weak|strong` overrides.  Rank 0 prints ONE JSON line.
+
+After the timed loop of the default workload (C2) the same process runs a few passes of the OTHER BASELINE configurations
+(C1 kf + rts, C3 sgp, C4 cd_sgp at 512 x 50 000 per GPU, C5 harmonic) and attaches their kernel times, throughput and
+roofline fractions under "other_configs" -- `value` stays C2's.  `--force-dist` takes the RCCL path (init_process_group
+('nccl'), barrier, all_reduce, all_gather on device tensors) even with one rank.  The host-CPU baseline (the oracle's C port
+built with -march=native and the state dimension fixed, one core AND all cores, best of 3) is reported by rank 0 for every N.
 """
 import argparse
 import json
@@ -30,6 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
 PMC_PROFILE = 'profiles/r02_ekf_pmc.json'
+ISSUE_TABLE = 'profiles/r02_issue_table.json'
 
 
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0):
@@ -56,6 +64,8 @@ def make_workload(B, T, seed=0, kind='ekf'):
     from chirpgp_amd.quadratures import SigmaPoints
     params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
     wl = dict(kind=kind, dt=1e-3, Xi=0.1, B=B, T=T)
+    if kind == 'kf':
+        wl['F'], wl['Sigma'] = frozen_frequency_linear_model(params, wl['dt'])
     if kind in ('harmonic', 'harmonic_ekf'):
         drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, 3)
         wl.update(ys=chirp_batch(B, T, seed, num_harmonics=3), sgps=SigmaPoints.cubature(8), d=8)
@@ -88,7 +98,7 @@ def bytes_per_trial_step(d):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
-    (profiles/r01_v17_ekf_eks_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
+    (PMC_PROFILE: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
     FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
     path = os.path.join(ROOT, PMC_PROFILE)
     try:
@@ -116,49 +126,83 @@ def pmc_issue(kernel_key, units):
     return None
 
 
-def cpu_baseline(wl, target_seconds=12.0):
-    """The oracle's C port (oracle/c/port.c, OpenMP over trials) timed on the host cores on a bounded sample of the
-    SAME workload: as many trials (full T) as fit ~target_seconds, at least one per thread."""
+def cpu_baseline(wl, target_seconds=10.0):
+    """The oracle's C port timed on the host cores on a bounded sample of the SAME workload: the timed build
+    (oracle/port.py: build_native -- `gcc -O3 -march=native -DFIXED_D=d -ffp-contract=fast` of oracle/c/port.c, compiled on this
+    machine; the checker build is a different object) on ONE core and on ALL cores, best of 3 after a calibration run each."""
     from oracle import port
     import copy
     k = wl['kind']
-    threads = port.num_threads()
-    T = wl['T']
-    ys = wl['ys']
-    n = min(ys.shape[0], max(threads, 8))
+    T, d, ys = wl['T'], wl['d'], wl['ys']
+    nat = port.native(d)
+    all_threads = port.num_threads(nat)
     drift_g = copy.copy(wl['drift'])
     drift_g.gamma = wl['disp'].outer()
-    label = {'ekf': 'EKF+EKS', 'harmonic_ekf': 'EKF+EKS (d=8)', 'sgp': 'sgp_filter+sgp_smoother', 'harmonic': 'sgp_filter+sgp_smoother (cubature, d=8)',
-             'cd_sgp': 'cd_sgp_filter+cd_sgp_smoother', 'cd_ekf': 'cd_ekf+cd_eks'}[k]
+    label = {'kf': 'kf+rts', 'ekf': 'EKF+EKS', 'harmonic_ekf': 'EKF+EKS (d=8)', 'sgp': 'sgp_filter+sgp_smoother',
+             'harmonic': 'sgp_filter+sgp_smoother (cubature, d=8)', 'cd_sgp': 'cd_sgp_filter+cd_sgp_smoother', 'cd_ekf': 'cd_ekf+cd_eks'}[k]
 
-    def once(nn):
-        t0 = time.perf_counter()
-        a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys[:nn])
-        if k in ('ekf', 'harmonic_ekf'):
-            f = port.filter(port.F_EKF, wl['disc'], None, *a)
-            port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], f[0], f[1])
+    bufs = {}
+
+    def once(n, steps, reps=1):
+        """`reps` back-to-back filter + smoother passes over n trials x steps, into buffers that are allocated and touched once
+        per shape (a fresh np.empty per call would time the kernel's first-touch page faults: 3.4 GB per 1000 x 10 000 pass)."""
+        y = np.ascontiguousarray(ys[:n, :steps])
+        if (n, steps) not in bufs:
+            bufs.clear()
+            bufs[(n, steps)] = [np.zeros((n, steps, d)), np.zeros((n, steps, d, d)), np.zeros((n, steps)),
+                                np.zeros((n, steps, d)), np.zeros((n, steps, d, d))]
+        mfs, Pfs, nl, mss, Pss = bufs[(n, steps)]
+        a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], y)
+        if k == 'kf':
+            from chirpgp_amd import models as pm
+            model, sg, fm, sm = pm.linear_cond_m_cov(wl['F'], wl['Sigma']), None, port.F_EKF, port.S_EKS
+        elif k in ('ekf', 'harmonic_ekf'):
+            model, sg, fm, sm = wl['disc'], None, port.F_EKF, port.S_EKS
         elif k in ('sgp', 'harmonic'):
-            f = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a)
-            port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], f[0], f[1])
+            model, sg, fm, sm = wl['disc'], wl['sgps'], port.F_SGP, port.S_SGP
         elif k == 'cd_sgp':
-            f = port.filter(port.F_CD_SGP, drift_g, wl['sgps'], *a)
-            port.smoother(port.S_CD_SGP, drift_g, wl['sgps'], wl['dt'], f[0], f[1])
+            model, sg, fm, sm = drift_g, wl['sgps'], port.F_CD_SGP, port.S_CD_SGP
         else:
-            f = port.filter(port.F_CD_EKF, drift_g, None, *a)
-            port.smoother(port.S_CD_EKS, drift_g, None, wl['dt'], f[0], f[1])
+            model, sg, fm, sm = drift_g, None, port.F_CD_EKF, port.S_CD_EKS
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            port.filter(fm, model, sg, *a, use=nat, out=(mfs, Pfs, nl))
+            port.smoother(sm, model, sg, wl['dt'], mfs, Pfs, use=nat, out=(mss, Pss))
         return time.perf_counter() - t0
-    t = once(n)                                   # warm-up + calibration
-    per_trial = t / n
-    n2 = int(min(ys.shape[0], max(n, target_seconds / max(per_trial, 1e-9))))
-    n2 = max(threads, (n2 // threads) * threads)
-    n2 = min(n2, ys.shape[0])
-    best = min(once(n2) for _ in range(2))
-    return {"value": n2 * T / best, "unit": "trial-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n2} of {ys.shape[0]} trials x T={T} ({label}, oracle/c/port.c, OpenMP, best of 2, {best:.2f} s)"}
+
+    def timed(threads):
+        """best of 3 on `threads` cores; the sample is sized from a calibration run to ~target_seconds / 6 per repetition"""
+        port.set_num_threads(threads, nat)
+        n0 = min(ys.shape[0], threads)
+        t_cal = min(T, 2000)
+        once(n0, t_cal)                                                # allocates and touches the buffers
+        per_unit = once(n0, t_cal) / (n0 * t_cal)                      # seconds per trial-step at this thread count
+        budget = (target_seconds / 6.0) / max(per_unit, 1e-12)         # trial-steps per repetition
+        reps = 1
+        if budget >= n0 * T:                                           # whole records: as many trials as fit, full T,
+            n = int(min(ys.shape[0], max(n0, (int(budget / T) // threads) * threads)))
+            steps = T
+            reps = max(1, int(budget / (n * T)))                       # and the whole sample again while the budget lasts
+        else:                                                          # a record is longer than the budget: its first steps
+            n, steps = n0, max(64, int(budget / n0))
+        once(n, steps)
+        best = min(once(n, steps, reps) for _ in range(3))
+        return n * steps * reps / best, (f"{n} of {ys.shape[0]} trials x {steps} of T={T} steps" + (f" x {reps} passes" if reps > 1 else "")
+                                          + f", best of 3 ({best:.2f} s)")
+
+    v1, s1 = timed(1)
+    va, sa = timed(all_threads)
+    port.set_num_threads(all_threads, nat)
+    return {"value": va, "unit": "trial-steps/s", "cores": all_threads, "kind": "port",
+            "sample": f"{label}, oracle/c/port.c: {sa}",
+            "one_core": {"value": v1, "unit": "trial-steps/s", "cores": 1, "sample": s1},
+            "build": "gcc " + " ".join(port.NATIVE_FLAGS) + f" -DFIXED_D={d} (timed build; the checker build is -march=x86-64-v3, runtime d)",
+            "best_of": 3}
 
 
 WORKLOADS = {
     # kind: (label, default trials, default T, default scaling, which roof bounds it in the large-batch limit)
+    'kf': ("C1: linear KF+RTS, frozen-frequency chirp (plumbing)", 1, 1000, 'weak', 'hbm'),
     'ekf': ("C2: discrete EKF+EKS (demos/ekfs_mle.py model)", 1000, 10000, 'weak', 'hbm'),
     'sgp': ("C3: Gauss-Hermite order-3 sgp_filter+sgp_smoother", 1000, 10000, 'strong', 'valu_f64'),
     'cd_sgp': ("C4: cd_sgp_filter+cd_sgp_smoother RK4", 512, 50000, 'weak', 'valu_f64'),
@@ -170,6 +214,11 @@ WORKLOADS = {
 # 4 cycles: measured 4.0 cycles per independent instruction, one wave per SIMD, tools/ubench/f64_issue.hip)
 F64_VALU_PEAK_TFLOPS = 78.6
 N_SIMDS = 1024
+# ALGORITHMIC float64 flop per trial-step of filter + smoother (transcendental ~ 30 flop-equivalents), counted
+# op by op on the reference's formulas -- what a non-redundant evaluation has to do.  The executed-FLOP figure of the
+# valu_f64 roofline counts all 64 lanes of every instruction, i.e. also the work replicated across lanes / MFMA blocks.
+ALGORITHMIC_FLOP = {'kf': 1.2e3, 'ekf': 1.5e3, 'sgp': 25e3, 'cd_sgp': 110e3, 'harmonic': 25e3}
+OTHER_CONFIGS = (('C1', 'kf'), ('C3', 'sgp'), ('C4', 'cd_sgp'), ('C5', 'harmonic'))
 
 
 def parse_args(argv=None):
@@ -182,6 +231,12 @@ def parse_args(argv=None):
                     help='trials: per GPU under weak scaling, in total under strong scaling (default: BASELINE config)')
     ap.add_argument('--T', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the passes of the other BASELINE configurations that follow the timed loop of the default workload')
+    ap.add_argument('--other-steps', type=int, default=3, help='timed passes of each other configuration')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='take the RCCL path even with one rank: init_process_group("nccl"), barrier, all_reduce and the final '
+                         'all_gather on device tensors at world size 1')
     ap.add_argument('--flags', type=int, default=0, help='CGP_* flag bits forwarded to the engine (e.g. 2 = wave per trial)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default=None,
                     help='weak: --batch trials per rank; strong: --batch trials in total, sharded (default per workload: '
@@ -208,16 +263,56 @@ def free_port():
 
 def valu_issue(workload, kernel, units, ms):
     """Executed float64 vector work of one launch from the committed PMC profile of this workload
-    (profiles/r02_issue_table.json, written by tools/issue_table.py from rocprofv3 --pmc passes): wave-instructions by
+    (ISSUE_TABLE, written by tools/issue_table.py from rocprofv3 --pmc passes): wave-instructions by
     class per trial-step, hence executed FLOP (all 64 lanes counted, FMA = 2) and the share of VALU issue slots used."""
     try:
-        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_issue_table.json')))[workload][kernel]
+        tab = json.load(open(os.path.join(ROOT, ISSUE_TABLE)))[workload][kernel]
     except (OSError, KeyError):
         return None
     flop_per_step = 64 * (2 * tab['fma_f64'] + tab['mul_f64'] + tab['add_f64']) + 2 * 256 * tab.get('mfma_f64', 0)
     return {"executed_tflops": flop_per_step * units / (ms * 1e-3) / 1e12, "valu_per_step": tab['valu'],
             "f64_per_step": tab['fma_f64'] + tab['mul_f64'] + tab['add_f64'], "cycles_per_step": tab.get('cycles'),
-            "source": tab.get('source', 'profiles/r02_issue_table.json')}
+            "source": tab.get('source', ISSUE_TABLE)}
+
+
+def roofline_of(kind, B, T, d, filt_ms, smooth_ms, bench_shape=False):
+    """The roofline object of one workload from rank 0's own kernel times (HIP events around the C-ABI calls)."""
+    label, _, _, _, bound = WORKLOADS[kind]
+    bf, bs = bytes_per_trial_step(d)
+    units = B * T
+    dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)
+    achieved = dom[2] * units / (dom[1] * 1e-3) / 1e9 if dom[1] else None
+    traffic = pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'walk4_smoother') if bench_shape else None
+    hbm = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+           "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                              "committed; not re-measured by this run)") if traffic is not None else None,
+           "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1],
+           # one wavefront per trial below ~2.5 trials per SIMD (cgp_api.hip:choose_wave): occupancy of the 1024 SIMDs
+           "waves_per_simd": round(B / N_SIMDS, 3) if B < 2560 else None}
+    # useful work of the whole pass against the float64 vector peak (SURVEY.md 8d's op counts), next to any executed figure
+    algo = ALGORITHMIC_FLOP.get(kind)
+    pass_ms = filt_ms + smooth_ms
+    algo_tflops = algo * units / (pass_ms * 1e-3) / 1e12 if (algo and pass_ms) else None
+    hbm["algorithmic_tflops"] = algo_tflops
+    hbm["algorithmic_frac"] = algo_tflops / F64_VALU_PEAK_TFLOPS if algo_tflops is not None else None
+    if bound != 'valu_f64':
+        return hbm
+    # sigma-point / RK4 workloads: 80-220 flop per byte against a machine balance of ~10 (SURVEY.md 8d), so the
+    # float64 vector pipe is the roof; the HBM fraction stays beside it.  `frac` = EXECUTED flop (all 64 lanes of every
+    # instruction: issue occupancy, replicated work included); `algorithmic_frac` = useful flop of SURVEY.md 8d.
+    iss = valu_issue(kind, dom[0], units, dom[1]) if dom[1] else None
+    return {"bound": "valu_f64", "kernel": dom[0],
+            "achieved": iss["executed_tflops"] if iss else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": iss["executed_tflops"] / F64_VALU_PEAK_TFLOPS if iss else None,
+            "frac_counts": "executed wave-instructions x 64 lanes (replicated lanes included): issue occupancy, not useful work",
+            "algorithmic_tflops": algo_tflops, "algorithmic_frac": hbm["algorithmic_frac"],
+            "algorithmic_flop_per_trial_step": algo,
+            "executed_flop_source": iss["source"] if iss else None,
+            "valu_per_step": iss["valu_per_step"] if iss else None, "f64_per_step": iss["f64_per_step"] if iss else None,
+            "cycles_per_step": iss["cycles_per_step"] if iss else None,
+            "waves_per_simd": hbm["waves_per_simd"], "avg_launch_ms": dom[1], "traffic": None, "traffic_source": None,
+            "hbm": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}}
 
 
 def main():
@@ -247,12 +342,18 @@ def main():
     if args.rehearse:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:                                            # --force-dist: a one-rank group on the loopback
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.rehearse:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if use_dist else 1
 
     def coll(t):
         """Tensor as the process group wants it: HBM for RCCL, a host copy for the gloo rehearsal."""
@@ -262,33 +363,30 @@ def main():
     from chirpgp_amd import _engine
     from chirpgp_amd.parallel import shard_bounds
 
-    label, B_default, T_default, scaling_default, bound = WORKLOADS[args.workload]
-    scaling = 'strong' if args.strong else (args.scaling or scaling_default)
-    batch = args.batch or B_default
-    T = args.T or T_default
-    kw = dict(flags=args.flags) if args.flags else {}
-
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(mode):
-        """W warm-up and K timed passes of the workload under `mode` scaling -> measurements of this rank (times are the
-        maximum over ranks)."""
+    def measure(kind, mode, batch, T, steps, warmup, kw):
+        """`warmup` untimed and `steps` timed passes of workload `kind` under `mode` scaling -> measurements (wall time and
+        kernel times are the maximum over ranks)."""
         if mode == 'strong':                          # contiguous shard of the total batch (SURVEY.md 8e)
             lo, hi = shard_bounds(batch, rank, world)
             B, B_total = hi - lo, batch
         else:
             B, B_total = batch, batch * world
-        wl = make_workload(max(B, 1), T, seed=1000003 * rank, kind=args.workload)
+        wl = make_workload(max(B, 1), T, seed=1000003 * rank, kind=kind)
         if B == 0:                                    # more ranks than trials: this rank idles through the barriers
             wl['ys'] = wl['ys'][:0]
         ys_dev = torch.from_numpy(wl['ys']).cuda()
 
         def step():
             k = wl['kind']
-            if k in ('ekf', 'harmonic_ekf'):
+            if k == 'kf':
+                f = fs.kf(wl['F'], wl['Sigma'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], ys_dev, **kw)
+                s = fs.rts(wl['F'], wl['Sigma'], f[0], f[1], **kw)
+            elif k in ('ekf', 'harmonic_ekf'):
                 f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev, **kw)
                 s = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
             elif k in ('sgp', 'harmonic'):
@@ -302,32 +400,35 @@ def main():
                 s = fs.cd_eks(wl['drift'], wl['disp'], f[0], f[1], wl['dt'], **kw)
             return f, s
 
-        # Allocator priming (untimed, before the W warm-up steps): the timed loop keeps one result alive while the next
+        # Allocator priming (untimed, before the warm-up steps): the timed loop keeps one result alive while the next
         # step allocates its outputs, so it alternates between two sets of output buffers; two passes whose results are
         # held together make PyTorch's caching allocator own both sets, and no hipMalloc of GB-sized buffers lands in the
         # timed region whatever --warmup is.  Device memory management is not part of the path being measured.
         prime = [step(), step()]
         torch.cuda.synchronize()
         del prime
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         sync()
         # HIP events on the launch stream, recorded immediately around each C-ABI call (kernel duration, not host time)
         events = _engine.kernel_events = []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             f, s = step()
         sync()
         elapsed = time.perf_counter() - t0
         _engine.kernel_events = None
-        tmax = coll(torch.tensor([elapsed], dtype=torch.float64, device='cuda'))
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
+        smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
+        mine = [elapsed, float(np.mean(filt)) if filt else 0.0, float(np.mean(smooth)) if smooth else 0.0]
+        tmax = coll(torch.tensor(mine, dtype=torch.float64, device='cuda'))
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # wall and kernel times: the slowest rank's
+        elapsed, filt_max, smooth_max = (float(x) for x in tmax.tolist())
 
         # the single collective of the path: gather the per-trial final NLL -- after the timed region
         gather_ms = None
-        if world > 1:
+        if use_dist:
             from chirpgp_amd import parallel
             last = coll(f[2][:, -1].contiguous())
             torch.cuda.synchronize()
@@ -336,14 +437,31 @@ def main():
             torch.cuda.synchronize()
             gather_ms = (time.perf_counter() - g0) * 1e3
             assert out.shape[0] == B_total
-        filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
-        smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
-        return dict(wl=wl, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
-                    filt_ms=float(np.mean(filt)) if filt else 0.0, smooth_ms=float(np.mean(smooth)) if smooth else 0.0)
+        del f, s, ys_dev
+        torch.cuda.empty_cache()
+        return dict(wl=wl, kind=kind, T=T, steps=steps, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
+                    filt_ms=mine[1], smooth_ms=mine[2], filt_ms_max=filt_max, smooth_ms_max=smooth_max)
 
-    m = measure(scaling)
+    label, B_default, T_default, scaling_default, bound = WORKLOADS[args.workload]
+    scaling = 'strong' if args.strong else (args.scaling or scaling_default)
+    batch = args.batch or B_default
+    T = args.T or T_default
+    kw = dict(flags=args.flags) if args.flags else {}
+
+    m = measure(args.workload, scaling, batch, T, args.steps, args.warmup, kw)
     # C2's north star also asks for the strong figure (1000 trials in total): measured right after, reported beside
-    other = measure('strong') if (world > 1 and scaling == 'weak' and args.workload == 'ekf') else None
+    other = measure(args.workload, 'strong', batch, T, args.steps, args.warmup, kw) if (world > 1 and scaling == 'weak' and args.workload == 'ekf') else None
+    # The other BASELINE configurations under the same clock: a few passes each after the headline loop, their own default
+    # sizes and scaling (C3 / C5: 1000 trials sharded; C4: 512 x 50 000 per GPU; C1: one record per rank).
+    others = {}
+    default_shape = args.workload == 'ekf' and args.batch is None and args.T is None and not args.flags
+    if default_shape and not args.no_other_configs:
+        for tag, kind in OTHER_CONFIGS:
+            _, Bo, To, mode_o, _ = WORKLOADS[kind]
+            others[tag] = measure(kind, mode_o, Bo, To, args.other_steps, 1, {})
+
+    if use_dist:
+        dist.destroy_process_group()       # ranks other than 0 are done: rank 0 times the host CPU with nobody spinning beside it
 
     if rank == 0:
         wl, B, B_total, elapsed = m['wl'], m['B'], m['B_total'], m['elapsed']
@@ -351,32 +469,10 @@ def main():
         filt_ms, smooth_ms = m['filt_ms'], m['smooth_ms']
         bf, bs = bytes_per_trial_step(d)
         units = B * T                                   # rank 0's own share (kernel figures are rank 0's)
-        dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)
-        achieved = dom[2] * units / (dom[1] * 1e-3) / 1e9
         total_units = B_total * T                       # all ranks
         total_gbs = (bf + bs) * total_units / (elapsed / args.steps) / 1e9
         bench_shape = args.workload == 'ekf' and B == 1000 and T == 10000 and not args.flags
-        traffic = pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother') if bench_shape else None
-        hbm = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-               "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                  "committed; not re-measured by this run)") if traffic is not None else None,
-               "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1],
-               # one wavefront per trial below ~2.5 trials per SIMD (cgp_api.hip:choose_wave): occupancy of the 1024 SIMDs
-               "waves_per_simd": round(B / N_SIMDS, 3) if B < 2560 else None}
-        roofline = hbm
-        if bound == 'valu_f64':
-            # sigma-point / RK4 workloads: 80-220 flop per byte against a machine balance of ~10, so the
-            # float64 vector pipe is the roof; the HBM fraction stays beside it
-            iss = valu_issue(args.workload, dom[0], units, dom[1])
-            roofline = {"bound": "valu_f64", "kernel": dom[0],
-                        "achieved": iss["executed_tflops"] if iss else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": iss["executed_tflops"] / F64_VALU_PEAK_TFLOPS if iss else None,
-                        "executed_flop_source": iss["source"] if iss else None,
-                        "valu_per_step": iss["valu_per_step"] if iss else None, "f64_per_step": iss["f64_per_step"] if iss else None,
-                        "cycles_per_step": iss["cycles_per_step"] if iss else None,
-                        "waves_per_simd": hbm["waves_per_simd"], "avg_launch_ms": dom[1], "traffic": None, "traffic_source": None,
-                        "hbm": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}}
+        roofline = roofline_of(args.workload, B, T, d, filt_ms, smooth_ms, bench_shape)
         result = {
             "metric": "filter+smoother trial-steps/s (batch x T / wall)",
             "value": total_units * args.steps / elapsed,
@@ -387,10 +483,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "d": d, "T": T, "batch_per_gpu": B, "global_batch": B_total,
                        "parallelism": f"trials sharded x{world}",
-                       "sigma_points": int(wl['sgps'].n_points) if args.workload not in ('ekf', 'cd_ekf', 'harmonic_ekf') else None},
+                       "sigma_points": int(wl['sgps'].n_points) if args.workload not in ('kf', 'ekf', 'cd_ekf', 'harmonic_ekf') else None},
+            "collectives": ("rccl" if not args.rehearse else "gloo (rehearsal)") if use_dist else None,
             "hbm_gbs_total": total_gbs, "hbm_frac_of_peak_total": total_gbs / (HBM_PEAK_GBS * world),
+            "hbm_frac_per_gpu": total_gbs / world / HBM_PEAK_GBS,
             "roofline": roofline,
             "kernels": {"filter_ms": filt_ms, "smoother_ms": smooth_ms,
+                        "filter_ms_max_over_ranks": m['filt_ms_max'], "smoother_ms_max_over_ranks": m['smooth_ms_max'],
                         "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
                         "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9 if smooth_ms else None},
             "gather_ms": m['gather_ms'],
@@ -399,16 +498,29 @@ def main():
             result["strong"] = {"value": other['B_total'] * T * args.steps / other['elapsed'], "unit": "trial-steps/s",
                                 "global_batch": other['B_total'], "batch_per_gpu": other['B'],
                                 "ms_per_step": other['elapsed'] / args.steps * 1e3, "gather_ms": other['gather_ms'],
-                                "filter_ms": other['filt_ms'], "smoother_ms": other['smooth_ms']}
+                                "filter_ms": other['filt_ms_max'], "smoother_ms": other['smooth_ms_max']}
         if bench_shape:
-            result["issue_profile"] = pmc_issue('ekf4_mfma' if dom[0] == 'filter' else 'tp_smoother', units)
-        if world == 1 and not args.no_cpu_baseline:
+            result["issue_profile"] = pmc_issue('ekf4_mfma' if filt_ms >= smooth_ms else 'walk4_smoother', units)
+        if others:
+            oc = {}
+            for tag, o in others.items():
+                lab, _, _, mode_o, _ = WORKLOADS[o['kind']]
+                do = o['wl']['d']
+                bfo, bso = bytes_per_trial_step(do)
+                tot = o['B_total'] * o['T']
+                per_pass = o['elapsed'] / o['steps']
+                oc[tag] = {"workload": lab, "d": do, "T": o['T'], "batch_per_gpu": o['B'], "global_batch": o['B_total'], "scaling": mode_o,
+                           "steps": o['steps'], "filter_ms": o['filt_ms_max'], "smoother_ms": o['smooth_ms_max'],
+                           "ms_per_pass": per_pass * 1e3, "value": tot / per_pass, "unit": "trial-steps/s",
+                           "hbm_frac_per_gpu": (bfo + bso) * tot / per_pass / 1e9 / world / HBM_PEAK_GBS,
+                           "roofline": roofline_of(o['kind'], o['B'], o['T'], do, o['filt_ms'], o['smooth_ms'])}
+            result["other_configs"] = oc
+        if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
             if result["cpu_baseline"]:
                 result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+                result["gpu_over_cpu_one_core"] = result["value"] / result["cpu_baseline"]["one_core"]["value"]
         print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -20,6 +20,16 @@
 #define MAXD 16
 #define TWO_PI 6.283185307179586476925286766559
 
+/* The checker build keeps the state dimension a run-time value.  The TIMED build of bench.py's cpu_baseline
+ * (oracle/port.py: build_native) is compiled with -DFIXED_D=<d> -march=native so that every d-loop has a constant trip
+ * count and is unrolled / vectorised -- a fair host-CPU number instead of generic runtime-d loops.  Same source, same
+ * arithmetic; only the rounding differs when the compiler is allowed to contract a*b+c (tests/test_oracle_port.py). */
+#ifdef FIXED_D
+#define DIM(x) (FIXED_D)
+#else
+#define DIM(x) (x)
+#endif
+
 typedef struct {
     int id, d, nh;
     /* LINEAR / KPT / LINEAR_SDE */
@@ -45,7 +55,7 @@ static void m32_solution(double ell, double sigma, double dt, double *M, double 
 static void model_setup(model_t *m, const cgp_model *cm, int64_t trial, double dt)
 {
     const double *p = cm->params + trial * cm->param_stride;
-    int d = cm->d;
+    int d = DIM(cm->d);
     memset(m, 0, sizeof(*m));
     m->id = cm->model_id; m->d = d; m->nh = cm->n_harm;
     m->gamma = cm->gamma ? cm->gamma + trial * cm->gamma_stride : NULL;
@@ -72,7 +82,7 @@ static void model_setup(model_t *m, const cgp_model *cm, int64_t trial, double d
 /* Discrete model: conditional mean f(u), its Jacobian J (row-major d*d) and covariance Sigma.  md:264-311, 332-386. */
 static void disc_eval(const model_t *m, const double *u, double dt, double *f, double *J, double *Sig)
 {
-    int d = m->d;
+    int d = DIM(m->d);
     if (m->id == CGP_M_LINEAR || m->id == CGP_M_KPT) {
         for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += m->F[i * d + j] * u[j]; f[i] = s; }
         if (J) memcpy(J, m->F, sizeof(double) * d * d);
@@ -106,7 +116,7 @@ static void disc_eval(const model_t *m, const double *u, double dt, double *f, d
 /* SDE drift a(u) and its Jacobian.  md:104-110, 164-168. */
 static void sde_eval(const model_t *m, const double *u, double *a, double *Ja)
 {
-    int d = m->d;
+    int d = DIM(m->d);
     if (m->id == CGP_M_LINEAR_SDE) {
         for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += m->A[i * d + j] * u[j]; a[i] = s; }
         if (Ja) memcpy(Ja, m->A, sizeof(double) * d * d);
@@ -132,16 +142,19 @@ static void sde_eval(const model_t *m, const double *u, double *a, double *Ja)
 
 static void matmul(int d, const double *A, const double *B, double *C)          /* C = A B   */
 {
+    d = DIM(d);
     for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) { double s = 0; for (int k = 0; k < d; k++) s += A[i * d + k] * B[k * d + j]; C[i * d + j] = s; }
 }
 static void matmul_nt(int d, const double *A, const double *B, double *C)       /* C = A B^T */
 {
+    d = DIM(d);
     for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) { double s = 0; for (int k = 0; k < d; k++) s += A[i * d + k] * B[j * d + k]; C[i * d + j] = s; }
 }
 /* Lower Cholesky; an all-NaN factor on failure (JAX semantics; LAPACK potrf fails on a pivot <= 0 or NaN). */
 static void chol_lower(int d, const double *P, double *L)
 {
     int bad = 0;
+    d = DIM(d);
     memset(L, 0, sizeof(double) * d * d);
     for (int j = 0; j < d && !bad; j++) {
         double s = P[j * d + j];
@@ -161,6 +174,7 @@ static void chol_lower(int d, const double *P, double *L)
 static void cho_solve(int d, const double *P, const double *R, int n, double *X)
 {
     double L[MAXD * MAXD];
+    d = DIM(d);
     chol_lower(d, P, L);
     for (int c = 0; c < n; c++) {
         double y[MAXD];
@@ -174,6 +188,7 @@ static double linear_update(int d, const double *mp, const double *Pp, const dou
                             int use_override, double *mf, double *Pf)
 {
     double PH[MAXD], S = 0, pred = 0;
+    d = DIM(d);
     for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += Pp[i * d + j] * H[j]; PH[i] = s; }
     for (int i = 0; i < d; i++) { S += H[i] * PH[i]; pred += H[i] * mp[i]; }
     S += Xi;
@@ -191,6 +206,7 @@ static void smoother_common(int d, const double *DT, const double *mf, const dou
                             double *ms, double *Ps)
 {
     double X[MAXD * MAXD], G[MAXD * MAXD], dm[MAXD], dP[MAXD * MAXD], T1[MAXD * MAXD], T2[MAXD * MAXD];
+    d = DIM(d);
     cho_solve(d, Pp, DT, d, X);
     for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) G[i * d + j] = X[j * d + i];
     for (int i = 0; i < d; i++) dm[i] = ms[i] - mp[i];
@@ -205,7 +221,7 @@ static void smoother_common(int d, const double *DT, const double *mf, const dou
 static void sgp_prediction(const model_t *m, const cgp_sigma *sg, double dt, const double *mf, const double *Pf,
                            double *mp, double *Pp, double *DT)
 {
-    int d = m->d, s = sg->s;
+    int d = DIM(m->d), s = sg->s;
     double L[MAXD * MAXD], Sig[MAXD * MAXD], chi[MAXD], f[MAXD], second[MAXD * MAXD], cross[MAXD * MAXD];
     chol_lower(d, Pf, L);
     memset(second, 0, sizeof(second)); memset(cross, 0, sizeof(cross));
@@ -228,7 +244,7 @@ static void sgp_prediction(const model_t *m, const cgp_sigma *sg, double dt, con
 /* fs:124-137. */
 static void cd_sgp_common(const model_t *m, const cgp_sigma *sg, const double *mm, const double *P, double *dm, double *dP)
 {
-    int d = m->d, s = sg->s;
+    int d = DIM(m->d), s = sg->s;
     double L[MAXD * MAXD], chi[MAXD], a[MAXD], acc[MAXD * MAXD];
     chol_lower(d, P, L);
     memset(acc, 0, sizeof(acc));
@@ -250,7 +266,7 @@ typedef struct { const model_t *m; const cgp_sigma *sg; int kind; const double *
 
 static void ode_rhs(const ode_t *o, const double *mm, const double *P, double *dm, double *dP)
 {
-    const model_t *m = o->m; int d = m->d;
+    const model_t *m = o->m; int d = DIM(m->d);
     double J[MAXD * MAXD], T1[MAXD * MAXD], T2[MAXD * MAXD];
     if (o->kind == 0) {
         sde_eval(m, mm, dm, J);
@@ -285,7 +301,7 @@ static void ode_rhs(const ode_t *o, const double *mm, const double *P, double *d
 /* qd:34-54 / 57-81 */
 static void rk4(const ode_t *o, double *mm, double *P, double dt)
 {
-    int d = o->m->d, n = d * d;
+    int d = DIM(o->m->d), n = d * d;
     double k1m[MAXD], k2m[MAXD], k3m[MAXD], k4m[MAXD], tm[MAXD];
     double k1P[MAXD * MAXD], k2P[MAXD * MAXD], k3P[MAXD * MAXD], k4P[MAXD * MAXD], tP[MAXD * MAXD];
     ode_rhs(o, mm, P, k1m, k1P);
@@ -321,8 +337,8 @@ static double kpt_h(int d, int nh, const double *x, double *H)
 int port_filter(int method, const cgp_model *cm, const cgp_sigma *sg, const cgp_init *in, double dt,
                 const double *ys, int64_t B, int64_t T, double *mfs, double *Pfs, double *nll, uint32_t flags)
 {
-    int d = cm->d;
-    if (d > MAXD) return CGP_E_UNSUPPORTED;
+    int d = DIM(cm->d);
+    if (d > MAXD || d != cm->d) return CGP_E_UNSUPPORTED;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t b = 0; b < B; b++) {
         model_t m; model_setup(&m, cm, b, dt);
@@ -371,9 +387,9 @@ int port_filter(int method, const cgp_model *cm, const cgp_sigma *sg, const cgp_
 int port_smoother(int method, const cgp_model *cm, const cgp_sigma *sg, double dt,
                   const double *mfs, const double *Pfs, int64_t B, int64_t T, double *mss, double *Pss, uint32_t flags)
 {
-    int d = cm->d;
+    int d = DIM(cm->d);
     (void)flags;
-    if (d > MAXD) return CGP_E_UNSUPPORTED;
+    if (d > MAXD || d != cm->d) return CGP_E_UNSUPPORTED;
     if (T <= 0) return CGP_OK;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t b = 0; b < B; b++) {
@@ -417,6 +433,24 @@ int port_gaussian_expectation(const double *ms, const double *sd, int64_t n, int
         out[i] = acc;
     }
     return CGP_OK;
+}
+
+void port_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int port_fixed_d(void)
+{
+#ifdef FIXED_D
+    return FIXED_D;
+#else
+    return 0;
+#endif
 }
 
 int port_num_threads(void)

@@ -45,20 +45,62 @@ def build():
 _lib = None
 
 
+def _declare(_lib):
+    _lib.port_filter.restype = C.c_int
+    _lib.port_filter.argtypes = [C.c_int, C.POINTER(_Model), C.POINTER(_Sigma), C.POINTER(_Init), C.c_double,
+                                 _dp, C.c_int64, C.c_int64, _dp, _dp, _dp, C.c_uint32]
+    _lib.port_smoother.restype = C.c_int
+    _lib.port_smoother.argtypes = [C.c_int, C.POINTER(_Model), C.POINTER(_Sigma), C.c_double,
+                                   _dp, _dp, C.c_int64, C.c_int64, _dp, _dp, C.c_uint32]
+    _lib.port_gaussian_expectation.restype = C.c_int
+    _lib.port_gaussian_expectation.argtypes = [_dp, _dp, C.c_int64, C.c_int64, _dp, _dp, C.c_int32, _dp]
+    _lib.port_num_threads.restype = C.c_int
+    _lib.port_set_num_threads.restype = None
+    _lib.port_set_num_threads.argtypes = [C.c_int]
+    _lib.port_fixed_d.restype = C.c_int
+    return _lib
+
+
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.port_filter.restype = C.c_int
-        _lib.port_filter.argtypes = [C.c_int, C.POINTER(_Model), C.POINTER(_Sigma), C.POINTER(_Init), C.c_double,
-                                     _dp, C.c_int64, C.c_int64, _dp, _dp, _dp, C.c_uint32]
-        _lib.port_smoother.restype = C.c_int
-        _lib.port_smoother.argtypes = [C.c_int, C.POINTER(_Model), C.POINTER(_Sigma), C.c_double,
-                                       _dp, _dp, C.c_int64, C.c_int64, _dp, _dp, C.c_uint32]
-        _lib.port_gaussian_expectation.restype = C.c_int
-        _lib.port_gaussian_expectation.argtypes = [_dp, _dp, C.c_int64, C.c_int64, _dp, _dp, C.c_int32, _dp]
-        _lib.port_num_threads.restype = C.c_int
+        _lib = _declare(C.CDLL(build()))
     return _lib
+
+
+NATIVE_FLAGS = ['-O3', '-march=native', '-fopenmp', '-fPIC', '-std=gnu99', '-fno-fast-math', '-ffp-contract=fast']
+_native = {}
+
+
+def _host_tag():
+    """Short hash of this machine's CPU model and ISA flags: a -march=native object must never run on another host
+    (gpurun ships built .so files to the GPU box, whose CPU differs from the build container's)."""
+    import hashlib
+    try:
+        txt = open('/proc/cpuinfo').read()
+        keep = sorted({ln for ln in txt.splitlines() if ln.startswith(('model name', 'flags'))})
+    except OSError:
+        keep = []
+    return hashlib.sha1('\n'.join(keep).encode()).hexdigest()[:10]
+
+
+def build_native(d):
+    """The TIMED build of the same source for bench.py's cpu_baseline: state dimension fixed at compile time, -march=native,
+    contraction allowed (`gcc -O3 -march=native -DFIXED_D=d -ffp-contract=fast`), compiled on the machine that runs it.
+    The checker build (build()) is unchanged.  -> path of the shared object."""
+    so = os.path.join(_HERE, 'c', f'libcgp_port_native_d{int(d)}_{_host_tag()}.so')
+    src = os.path.join(_HERE, 'c', 'port.c')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get('CC', 'gcc'), *NATIVE_FLAGS, f'-DFIXED_D={int(d)}', '-shared', '-o', so, src, '-lm'])
+    return so
+
+
+def native(d):
+    """ctypes handle of the timed build for dimension d (pass it as ``use=`` to filter / smoother)."""
+    if d not in _native:
+        _native[d] = _declare(C.CDLL(build_native(d)))
+        assert _native[d].port_fixed_d() == int(d)
+    return _native[d]
 
 
 def _arr(x):
@@ -95,8 +137,10 @@ def _strided(x, base_ndim, keep):
     return _p(a), (per if a.ndim > base_ndim else 0)
 
 
-def filter(method, model, sigma, H, Xi, m0, P0, dt, ys, nll_final_only=False):
-    """-> (mfs (B,T,d), Pfs (B,T,d,d), nll (B,T) or (B,)); a 1-D ys gives un-batched outputs."""
+def filter(method, model, sigma, H, Xi, m0, P0, dt, ys, nll_final_only=False, use=None, out=None):
+    """-> (mfs (B,T,d), Pfs (B,T,d,d), nll (B,T) or (B,)); a 1-D ys gives un-batched outputs.
+    ``out``: preallocated (mfs, Pfs, nll) to write into (the timed baseline reuses touched buffers instead of paying
+    first-touch page faults for GBs of fresh memory in every call)."""
     ys = _arr(ys)
     single = ys.ndim == 1
     ys2 = ys[None, :] if single else ys
@@ -113,16 +157,21 @@ def filter(method, model, sigma, H, Xi, m0, P0, dt, ys, nll_final_only=False):
     init.Xi, init.Xi_stride = _p(xi_arr), (1 if xi_arr.size > 1 else 0)
     init.m0, init.m0_stride = _strided(m0, 1, keep)
     init.P0, init.P0_stride = _strided(P0, 2, keep)
-    mfs, Pfs = np.empty((B, T, d)), np.empty((B, T, d, d))
-    nll = np.empty((B,) if nll_final_only else (B, T))
-    rc = lib().port_filter(method, C.byref(ms), C.byref(sg) if sg is not None else None, C.byref(init), float(dt),
+    if out is not None:
+        mfs, Pfs, nll = out
+        assert mfs.shape == (B, T, d) and Pfs.shape == (B, T, d, d) and nll.shape == ((B,) if nll_final_only else (B, T))
+        assert all(a.flags.c_contiguous and a.dtype == np.float64 for a in out)
+    else:
+        mfs, Pfs = np.empty((B, T, d)), np.empty((B, T, d, d))
+        nll = np.empty((B,) if nll_final_only else (B, T))
+    rc = (use or lib()).port_filter(method, C.byref(ms), C.byref(sg) if sg is not None else None, C.byref(init), float(dt),
                            _p(ys2), B, T, _p(mfs), _p(Pfs), _p(nll), NLL_FINAL_ONLY if nll_final_only else 0)
     if rc != 0:
         raise RuntimeError(f'port_filter failed: {rc}')
     return (mfs[0], Pfs[0], nll[0]) if single else (mfs, Pfs, nll)
 
 
-def smoother(method, model, sigma, dt, mfs, Pfs):
+def smoother(method, model, sigma, dt, mfs, Pfs, use=None, out=None):
     """-> (mss, Pss) with the shapes of (mfs, Pfs)."""
     mfs, Pfs = _arr(mfs), _arr(Pfs)
     single = mfs.ndim == 2
@@ -132,8 +181,12 @@ def smoother(method, model, sigma, dt, mfs, Pfs):
     keep = []
     ms = _model_struct(model, keep)
     sg = _sigma_struct(sigma, keep)
-    mss, Pss = np.empty_like(m3), np.empty_like(P4)
-    rc = lib().port_smoother(method, C.byref(ms), C.byref(sg) if sg is not None else None, float(dt),
+    if out is not None:
+        mss, Pss = out
+        assert mss.shape == m3.shape and Pss.shape == P4.shape and mss.flags.c_contiguous and Pss.flags.c_contiguous
+    else:
+        mss, Pss = np.empty_like(m3), np.empty_like(P4)
+    rc = (use or lib()).port_smoother(method, C.byref(ms), C.byref(sg) if sg is not None else None, float(dt),
                              _p(m3), _p(P4), B, T, _p(mss), _p(Pss), 0)
     if rc != 0:
         raise RuntimeError(f'port_smoother failed: {rc}')
@@ -147,5 +200,9 @@ def gaussian_expectation(ms, sd, xi, w):
     return out
 
 
-def num_threads():
-    return int(lib().port_num_threads())
+def num_threads(use=None):
+    return int((use or lib()).port_num_threads())
+
+
+def set_num_threads(n, use=None):
+    (use or lib()).port_set_num_threads(int(n))

@@ -37,5 +37,38 @@ def test_strong_default_for_the_sigma_point_configs():
 def test_single_gpu_line_carries_roofline_and_cpu_baseline():
     r = _run('--batch', '64', '--T', '500', '--steps', '2', '--warmup', '1')
     assert r['n_gpus'] == 1 and r['roofline']['bound'] == 'hbm' and r['roofline']['frac'] > 0
-    assert 'traffic_source' in r['roofline']
-    assert r['cpu_baseline']['kind'] == 'port' and r['cpu_baseline']['value'] > 0
+    assert 'traffic_source' in r['roofline'] and r['roofline']['algorithmic_frac'] > 0
+    cb = r['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['best_of'] == 3
+    assert cb['one_core']['cores'] == 1 and 0 < cb['one_core']['value'] <= cb['value'] * 1.5
+    assert '-march=native' in cb['build'] and '-DFIXED_D=4' in cb['build']
+    assert 'other_configs' not in r                       # a non-default shape runs the named workload only
+
+
+def test_world_one_rccl_path():
+    """--force-dist: the never-otherwise-exercised RCCL branch (init_process_group('nccl', device_id), barrier, all_reduce(MAX),
+    all_gather_into_tensor on DEVICE tensors, destroy) at world size 1 -- all the RCCL coverage a one-GPU box allows."""
+    r = _run('--force-dist', '--batch', '32', '--T', '400', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
+    assert r['n_gpus'] == 1 and r['ranks_seen'] == 1 and r['collectives'] == 'rccl'
+    assert r['gather_ms'] is not None and r['gather_ms'] >= 0 and r['value'] > 0
+    k = r['kernels']
+    assert k['filter_ms_max_over_ranks'] == pytest.approx(k['filter_ms']) and k['smoother_ms_max_over_ranks'] == pytest.approx(k['smoother_ms'])
+
+
+def test_default_line_carries_the_other_baseline_configs():
+    """The driver's command (default workload and sizes, fewer steps): C1, C3, C4, C5 ride on the same JSON line, each with its
+    kernel times, throughput and both roofline fractions (executed and algorithmic) for the float64-bound ones."""
+    r = _run('--steps', '3', '--warmup', '1', '--other-steps', '1', '--no-cpu-baseline')
+    assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000 and r['roofline']['traffic'] is not None
+    oc = r['other_configs']
+    assert set(oc) == {'C1', 'C3', 'C4', 'C5'}
+    assert (oc['C1']['batch_per_gpu'], oc['C1']['T'], oc['C1']['d']) == (1, 1000, 4)
+    assert (oc['C3']['batch_per_gpu'], oc['C3']['T']) == (1000, 10000) and oc['C3']['scaling'] == 'strong'
+    assert (oc['C4']['batch_per_gpu'], oc['C4']['T']) == (512, 50000)
+    assert (oc['C5']['batch_per_gpu'], oc['C5']['T'], oc['C5']['d']) == (1000, 10000, 8)
+    for tag in ('C3', 'C4', 'C5'):
+        rf = oc[tag]['roofline']
+        assert rf['bound'] == 'valu_f64' and 0 < rf['algorithmic_frac'] < 1 and oc[tag]['value'] > 0
+        assert oc[tag]['filter_ms'] > 0 and oc[tag]['smoother_ms'] > 0
+        if rf['frac'] is not None:
+            assert rf['algorithmic_frac'] <= rf['frac'] * 1.05       # useful work cannot exceed what was executed

@@ -124,3 +124,26 @@ def test_port_nan_semantics():
     want = nf.sgp_filter(lambda u, dt: (F @ u, Sigma), cs.osig(sg), np.array([1., 0.]), 0.1, np.zeros(2), P0, 0.1, np.ones(5))
     for g, w in zip(got, want):
         assert np.array_equal(np.isnan(g), np.isnan(w)) and np.all(np.isnan(g))
+
+
+def test_native_timed_build_agrees_with_the_checker_build():
+    """bench.py's cpu_baseline times `gcc -O3 -march=native -DFIXED_D=d -ffp-contract=fast` of the SAME source
+    (oracle/port.py: build_native); only the rounding may differ from the checker build (contracted multiply-adds)."""
+    from tests import backends as bk
+    c = cs.chirp_case(T=400, seed=21)
+    nat = port.native(4)
+    assert nat.port_fixed_d() == 4
+    got = bk.run_pairs('port', c, cd_T=120)
+    dg = bk._with_gamma(c.drift, c.disp.outer())
+    f = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys, use=nat)
+    s = port.smoother(port.S_EKS, c.disc, None, c.dt, f[0], f[1], use=nat)
+    f2 = port.filter(port.F_CD_SGP, dg, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys[:120], use=nat)
+    for a, b in zip(f + s + f2, got['ekf'] + got['eks'] + got['cd_sgp_filter']):
+        cs.assert_close(a, b, 1e-9, 'native build')
+    # a fixed-dimension build refuses other dimensions instead of mis-indexing
+    h = cs.harmonic_case(T=20)
+    with pytest.raises(RuntimeError):
+        port.filter(port.F_EKF, h.disc, None, h.H, h.Xi, h.m0, h.P0, h.dt, h.ys, use=nat)
+    port.set_num_threads(1, nat)
+    assert port.num_threads(nat) == 1
+    port.set_num_threads(port.num_threads(), nat)
