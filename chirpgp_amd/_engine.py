@@ -18,6 +18,7 @@ S_EKS, S_SGP, S_CD_EKS, S_CD_SGP = range(4)
 M_LINEAR, M_HARMONIC_LCD, M_LASCALA_LCD, M_LINEAR_SDE, M_HARMONIC_SDE, M_KPT = range(6)
 NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNEL, SIM_FIXED_X0 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 LITERAL_SIGMA_SUM, DPP_KERNEL, FOUR_TRIALS_PER_WAVE, ONE_TRIAL_PER_WAVE = 0x40, 0x80, 0x200, 0x400
+TIME_SPLIT, NO_TIME_SPLIT = 0x800, 0x1000
 SIGMA_STANDARD = 0x1
 MAX_D = 8
 

@@ -44,6 +44,13 @@ struct SmootherIO {
     double* __restrict__ mss;
     double* __restrict__ Pss;
     uint32_t flags;
+    // time-split discrete smoothers (cgp_walk4.hpp, cgp_coop8.hpp): `segs` wavefronts per trial, each walking `tiles_per_seg`
+    // 64-step tiles; the segments' composed maps (A, c, C) live in `ws` between the two passes.  segs <= 1: one wave per trial.
+    int segs = 1;                 // as handed to a launcher: 0 = choose from (B, T, num_cus); 1 = off; > 1 = this many at most
+    int min_tiles = 4;            // per segment (1 when the caller forces the time-split form)
+    int num_cus = 256;
+    int tiles_per_seg = 0;
+    double* __restrict__ ws = nullptr;
 };
 
 // Dynamic LDS (sized by the launch): the staged sigma-point set.  The static LDS in front of it (the 17 152-byte

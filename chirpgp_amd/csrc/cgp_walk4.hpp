@@ -1,47 +1,90 @@
 // cgp_walk4.hpp -- discrete smoothers (rts / eks / sgp_smoother, filters_smoothers.py:187-219, 317-349, 493-531) for d = 4:
-// gains built lane-parallel, the recursion walked by the wavefront on the float64 matrix cores.
+// per-step affine maps built lane-parallel, composed and applied by the wavefront on the float64 matrix cores, FOUR time steps
+// per matrix instruction.
 //
-// The time-parallel smoother of cgp_kernels.hpp (tp_smoother_kernel) turns the backward recursion into a scan of affine maps:
-// every lane composes 4 x 4 maps nine times per tile (three for its own four steps, six scan rounds) and applies five.  Here,
-// as in the d = 6 / 8 kernel of cgp_coop8.hpp, the lanes still do the expensive, independent part of their own steps in
-// parallel -- prediction (model / sigma fan) at (mf, Pf), Cholesky of Pp, the gain G = (Pp^{-1} D^T)^T: 64 chains, one per
-// lane -- but nothing is composed: (G, -Pp G^T, Pf, mf - G mp) of the tile's 64 steps go to LDS (53 doubles a step, 27 KB: four
-// workgroups a CU) and the wavefront walks the tile backwards COOPERATIVELY with the reference's own recursion
-// (filters_smoothers.py:83-84),
-//     X = Ps' - Pp,   W = X G^T,   Ps = G W + Pf,      ms = G (ms' - mp) + mf,
-// the carry held in the output layout of v_mfma_f64_4x4x4_4b_f64 (lane (r, b, q): Ps[r][q]; ms in row form, lane (r, b, q):
-// ms[r]).  With g = G[q][r] per lane -- which is both the B operand "G^T[k][q']" and the A operand "G[r'][k]" -- a step is
-//     W  = mfma(Ps', g, N)        sum_k Ps'[k][r] G[q][k] + N,   N = -Pp G^T        (Ps' symmetric)
-//     Ps = mfma(g, W, Pf)         sum_k G[r][k] W[k][q] + Pf
-//     ms = mfma(g, ms', v)        sum_k G[r][k] ms'[k] + v,      v = mf - G mp
-// three matrix instructions and nothing else: the two subtractions of the recursion are taken out of the serial chain by the
-// lanes that build the gains (N and v are per-step constants).  The dependent chain from Ps' to Ps is two matrix instructions
-// (tools/ubench/mfma_chain.hip).  What surrounds the chain is arranged not to stall it:
-//   * the four LDS operands of a step are read three steps ahead (an LDS read is longer than a step);
-//   * the results of FOUR steps leave in one store instruction each for Ps and ms -- the instruction's four blocks of 16
-//     lanes carry the four steps' rows, 512 contiguous bytes -- because a wavefront may have only 63 memory instructions in
-//     flight and two stores per step used that up (0.63 against 0.47 ms for the walk of the bench configuration);
-//   * a lane's own filtering row for the NEXT tile is requested before the walk starts;
-//   * for the EKS of the chirp model the gains of the next tile are built during the walk (see the kernel).
-// HBM is read once and written once (320 B a step).
+// The backward recursion (filters_smoothers.py:83-84) is an affine map of the carry whose coefficients depend on the filtering
+// results only:   ms_t = G_t ms_{t+1} + c_t,   Ps_t = G_t Ps_{t+1} G_t^T + C_t,   c_t = mf_t - G_t mp_t,   C_t = Pf_t - G_t Pp_t G_t^T.
+// A tile is 64 consecutive steps of one trial:
+//   phase G  every lane builds the map of ITS step -- prediction (model / sigma fan) at (mf, Pf), Cholesky of Pp, the gain
+//            G = (Pp^{-1} D^T)^T, then c and C: 64 independent chains on the vector ALU -- and parks (G, C, c) in LDS
+//            (36 doubles a step, 18.9 KB a tile: eight workgroups a CU);
+//   phase S  the wavefront replaces the maps of every quad of steps (4 Q .. 4 Q + 3) by their SUFFIX compositions -- step
+//            4 Q + j gets f_j o f_{j+1} o .. o f_3, the map from the carry ENTERING the quad to that step -- three rounds of
+//            four matrix instructions for sixteen quads at a time: v_mfma_f64_4x4x4_4b_f64 multiplies four independent
+//            4 x 4 blocks, one quad per block, so this part is throughput-bound, not a dependent chain;
+//   phase W  the wavefront walks the tile backwards one QUAD at a time: block b of the instruction applies the composed map of
+//            step 4 Q + b to the same carry,
+//                W  = mfma(Ps'', g, 0)     Ps'' M_b^T             (g = M_b[q][r]: serves as B operand "M^T" and as A operand "M")
+//                Ps = mfma(g, W, C_b)      M_b W + C_b
+//                ms = mfma(g, ms'', c_b)   M_b ms'' + c_b
+//            -- three matrix instructions for FOUR steps (the step-by-step walk of round 2 needed twelve), whose four blocks
+//            are the four consecutive output rows: one 512-byte store for Ps and one for ms per quad, no re-arrangement.
+//            Block 0 (the earliest step) is the next quad's carry: two bank-masked DPP broadcasts (the instruction's
+//            CBSZ / ABID block broadcast is ignored for the float64 4x4x4 shape on gfx950: tools/ubench/mfma_bcast.hip).
+// The dependent chain is two matrix instructions and a broadcast per FOUR steps.  LDS operands are read ahead of their use,
+// a lane's filtering rows are requested one (EKS of the chirp model: two) tiles ahead, and for that model the next tile's
+// gains are straight-line code (gain_spec) in the walk's basic block.  HBM is read once and written once (320 B a step).
+//
+// Small batches: the time-split form.  With B << 1024 trials one wavefront per trial leaves most SIMDs idle while every
+// trial walks its T steps alone.  The maps compose exactly, so a record can be cut into `segs` segments handled by different
+// wavefronts (nothing is approximated):
+//   pass 1 (MODE = kWalkCompose)  phases G and S as above, then the QUAD maps (step 4 Q's suffix composition = the whole quad)
+//                                 are chained into the segment's map (A, c, C) -- 36 doubles to the workspace; no stores;
+//   pass 2 (MODE = kWalkApply)    every wave applies the maps of the later segments to the record's last filtering row --
+//                                 its own carry-in, a handful of matrix instructions -- and walks its segment as above.
+// A trial then takes 2 T / segs steps instead of T; at B = 125 (BASELINE C3 / C5 sharded over 8 GPUs) segs = 16.
 #pragma once
+#ifndef CGP_WALK_ABLATE
+#define CGP_WALK_ABLATE 0
+#endif
 #include "cgp_coop8.hpp"
 
 namespace cgp {
 
-constexpr int kWalkRec = 53;                      // G 16 | N = -Pp G^T 16 | Pf 16 | v = mf - G mp 4 | pad: odd, conflict-free lane stride
-constexpr int kWalkG = 0, kWalkN = 16, kWalkPf = 32, kWalkV = 48;
-constexpr int kWalkAhead = 3;                     // steps between an operand's LDS read and its use
+constexpr int kWalkRec = 37;                      // G 16 (row-major) | C 16 (full) | c 4 | pad: odd, conflict-free lane stride
+constexpr int kWalkG = 0, kWalkC = 16, kWalkc = 32;
+constexpr int kWalkAhead = 2;                     // quads between an operand's LDS read and its use
+constexpr int kWalkMapDoubles = 40;               // a segment's composed map in the workspace: A 16 | C 16 | c 4 | pad
+enum { kWalkWhole = 0, kWalkCompose = 1, kWalkApply = 2 };
 
-struct Walk4Operands { double g, N, Pf, v; };
+struct Walk4Operands { double g, C, c; };
 
-template <class Elem>
+// block 0's value in all four blocks (same r, q): blocks move inside a DPP row with row rotations and bank masks
+CGP_DEV double blk_bcast0(double x) {
+    return dpp_banks_f64<kRowRor12, 0x8>(dpp_banks_f64<kRowRor8, 0x4>(dpp_banks_f64<kRowRor4, 0x2>(x, x), x), x);
+}
+
+// (c, C) of a step's map from its gain and prediction: c = mf - G mp, C = Pf - G Pp G^T (the second half of
+// affine_from_prediction, cgp_steps.hpp)
+CGP_DEV void walk4_affine(const Vec<4>& mf, const Sym<4>& Pf, const Vec<4>& mp, const Sym<4>& Pp, const Mat<4>& G, Vec<4>& c, Sym<4>& C) {
+    CGP_UNROLL for (int i = 0; i < 4; i++) {
+        double s = mf.v[i];
+        CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(-G.a[i][k], mp.v[k], s);
+        c.v[i] = s;
+    }
+    CGP_UNROLL for (int i = 0; i < 4; i++) {
+        double t[4];
+        CGP_UNROLL for (int j = 0; j < 4; j++) {
+            double s = G.a[i][0] * Pp(0, j);
+            CGP_UNROLL for (int k = 1; k < 4; k++) s = fma(G.a[i][k], Pp(k, j), s);
+            t[j] = s;
+        }
+        CGP_UNROLL for (int j = 0; j <= i; j++) {
+            double s = Pf(i, j);
+            CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(-t[k], G.a[j][k], s);
+            C(i, j) = s;
+        }
+    }
+}
+
+template <class Elem, int MODE = kWalkWhole>
 __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(Elem::D == 4, "d = 4 kernel");
     __shared__ double recs[64 * kWalkRec];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    const int64_t trial = (MODE == kWalkWhole) ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / (unsigned)io.segs);
+    const int seg = (MODE == kWalkWhole) ? 0 : (int)(blockIdx.x % (unsigned)io.segs);
     if (trial >= io.B) return;
 
     Elem elem;
@@ -53,18 +96,37 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     double* __restrict__ mss = io.mss + trial * T * 4;
     double* __restrict__ Pss = io.Pss + trial * T * 16;
     OobWindow wPs, wms;                               // which lanes store is an offset, not a branch (cgp_coop4.hpp)
-    wPs.init(Pss, T * 128); wms.init(mss, T * 32);
-    // a store covers the four steps s .. s + 3: block b carries step s + b
+    wPs.init(MODE == kWalkCompose ? nullptr : Pss, T * 128); wms.init(MODE == kWalkCompose ? nullptr : mss, T * 32);   // pass 1 stores nothing
+    // the segment's tiles: tile j covers the steps T - 2 - 64 j - 63 .. T - 2 - 64 j (segment 0 is the LAST in time)
+    const int64_t hi_first = (MODE == kWalkWhole) ? T - 2 : T - 2 - 64 * (int64_t)seg * io.tiles_per_seg;
+    const int64_t hi_stop = (MODE == kWalkWhole) ? 0 : max((int64_t)0, hi_first - 64 * (int64_t)io.tiles_per_seg + 1);   // tiles with hi >= hi_stop
+    if (hi_first < 0 && MODE != kWalkWhole) return;   // (more segments than tiles: nothing to do, nothing to compose)
+    // a quad's store covers the four steps 4 Q .. 4 Q + 3: block b carries step 4 Q + b
     const unsigned offP = (unsigned)b * 128u + (unsigned)(4 * r + q) * 8u;
     const unsigned offm = (q == 0) ? (unsigned)b * 32u + (unsigned)r * 8u : kOobOffset;
-    // the lane's operands inside a step's record
-    const int oG = kWalkG + q * 4 + r, oN = kWalkN + r * 4 + q, oPf = kWalkPf + r * 4 + q, oV = kWalkV + r;
+    // the lane's operands inside a step's record: M as A operand / as B^T (g = M[q][r]), M, C as B operand ([r][q]), c in row form
+    const int oGa = kWalkG + q * 4 + r, oGb = kWalkG + r * 4 + q, oC = kWalkC + r * 4 + q, oc = kWalkc + r;
 
-    // carry; the last row is copied verbatim (filters_smoothers.py:140-142)
+    // carry (the same in the four blocks); the last row is copied verbatim (filters_smoothers.py:140-142)
     double Ps = Pfs[(T - 1) * 16 + ((r >= q) ? r * 4 + q : q * 4 + r)];              // the lower triangle, like the other kernels
     double ms = mfs[(T - 1) * 4 + r];
-    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
-    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    double Acc = (r == q) ? 1.0 : 0.0;                // pass 1: the composed linear part, A <- M A
+    if constexpr (MODE == kWalkCompose) { Ps = 0.0; ms = 0.0; }
+    if (MODE != kWalkCompose && seg == 0) {
+        if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
+        if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    }
+    if constexpr (MODE == kWalkApply) {
+        // carry-in of this segment: the maps of the segments later in time, applied in order to the last filtering row
+        const double* __restrict__ maps = io.ws + trial * io.segs * kWalkMapDoubles;
+        for (int s2 = 0; s2 < seg; s2++) {
+            const double* __restrict__ mp_ = maps + s2 * kWalkMapDoubles;
+            const double gA = mp_[q * 4 + r], Cs = mp_[16 + r * 4 + q], cs = mp_[32 + r];
+            const double Wc = mfma4x4(Ps, gA, 0.0);
+            ms = mfma4x4(gA, ms, cs);
+            Ps = mfma4x4(gA, Wc, Cs);
+        }
+    }
 
     // the lane's row of a tile (a row before the start of the record is clamped and not used)
     auto request = [&](int64_t base, Vec<4>& mf, Sym<4>& Pf) {
@@ -72,115 +134,179 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
         load_vec<4>(mfs + (t >= 0 ? t : 0) * 4, mf);
         load_sym<4>(Pfs + (t >= 0 ? t : 0) * 16, Pf);
     };
-    // the lane's record: G, N = -Pp G^T, Pf, v = mf - G mp; all zero for a step before the start of the record
-    auto write_record = [&](bool valid, Mat<4>& G, Vec<4>& mp, Sym<4>& Pp, Vec<4>& mf, Sym<4>& Pf) {
-        if (!valid) {
-            CGP_UNROLL for (int a = 0; a < 4; a++) { mp.v[a] = 0.0; mf.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < 4; c++) G.a[a][c] = 0.0; }
-            CGP_UNROLL for (int a = 0; a < Sym<4>::N; a++) { Pp.a[a] = 0.0; Pf.a[a] = 0.0; }
-        }
+    // the lane's record: (G, C, c) of its step; all zero for a step before the start of the record
+    auto write_record = [&](bool valid, const Mat<4>& G, const Vec<4>& c, const Sym<4>& C) {
         double* mine = recs + lane * kWalkRec;
         CGP_UNROLL for (int a = 0; a < 4; a++) {
-            double v = mf.v[a];
-            CGP_UNROLL for (int c = 0; c < 4; c++) {
-                double n = 0.0;                                             // -(Pp G^T)[a][c] = -sum_k Pp[a][k] G[c][k]
-                CGP_UNROLL for (int k = 0; k < 4; k++) n = fma(-Pp(a, k), G.a[c][k], n);
-                mine[kWalkG + a * 4 + c] = G.a[a][c];
-                mine[kWalkN + a * 4 + c] = n;
-                mine[kWalkPf + a * 4 + c] = Pf(a, c);                       // Sym::operator() is symmetric in its arguments
-                v = fma(-G.a[a][c], mp.v[c], v);                            // mf - G mp
+            CGP_UNROLL for (int k = 0; k < 4; k++) {
+                mine[kWalkG + a * 4 + k] = valid ? G.a[a][k] : 0.0;
+                mine[kWalkC + a * 4 + k] = valid ? C(a, k) : 0.0;           // Sym::operator() is symmetric in its arguments
             }
-            mine[kWalkV + a] = v;
+            mine[kWalkc + a] = valid ? c.v[a] : 0.0;
         }
     };
-    // the wavefront walks the tile in LDS from its last step to its first.  Steps before the start of the record (last tile)
-    // are walked too: their records are zero and their stores fall outside the windows (the step index wraps).
+    // phase S: in every quad, step 4 Q + j <- f_j o f_{j+1} o .. o f_3; block b of group i handles quad 4 i + b
+    auto scan = [&]() {
+        CGP_UNROLL for (int i = 3; i >= 0; i--) {                          // (the walk starts with the last quads)
+            const double* p3 = recs + (16 * i + 4 * b + 3) * kWalkRec;
+            double M = p3[oGb], C = p3[oC], c = p3[oc];
+            CGP_UNROLL for (int j = 2; j >= 0; j--) {
+                double* pj = recs + (16 * i + 4 * b + j) * kWalkRec;
+                const double g = pj[oGa], Cj = pj[oC], cj = pj[oc];
+                M = mfma4x4(g, M, 0.0);                                    // G_j M
+                c = mfma4x4(g, c, cj);                                     // G_j c + c_j                 (row form)
+                const double Tt = mfma4x4(C, g, 0.0);                      // C G_j^T = (G_j C)^T         (C symmetric)
+                C = mfma4x4(Tt, g, Cj);                                    // (G_j C) G_j^T + C_j
+                pj[oGb] = M; pj[oC] = C; pj[oc] = c;                       // (the four lanes q of a row write the same c)
+            }
+        }
+    };
+    // phase W: the tile in LDS from its last quad to its first.  Steps before the start of the record (last tile) are walked
+    // too: their records are zero and their stores fall outside the windows (the step index wraps).
     auto walk = [&](int64_t base) {
-        auto fetch = [&](int s, Walk4Operands& o) {
-            const double* p = recs + (s & 63) * kWalkRec;
-            o.g = p[oG]; o.N = p[oN]; o.Pf = p[oPf]; o.v = p[oV];
+        auto fetch = [&](int Q, Walk4Operands& o) {
+            const double* p = recs + ((4 * Q + (MODE == kWalkCompose ? 0 : b)) & 63) * kWalkRec;
+            o.g = p[oGa]; o.C = p[oC]; o.c = p[oc];
         };
         Walk4Operands ring[kWalkAhead + 1];
-        CGP_UNROLL for (int a = 0; a < kWalkAhead; a++) fetch(63 - a, ring[a]);
-        double P4[4], m4[4];                                               // the results of the four steps of a store
-        CGP_UNROLL for (int s = 63; s >= 0; s--) {                         // fully unrolled: the ring is register renaming
-            fetch(s - kWalkAhead, ring[(63 - s + kWalkAhead) % (kWalkAhead + 1)]);       // (the records fetched past the tile's first step are not used)
-            const Walk4Operands& cur = ring[(63 - s) % (kWalkAhead + 1)];
-            const double W = mfma4x4(Ps, cur.g, cur.N);                    // (Ps' - Pp) G^T
-            ms = mfma4x4(cur.g, ms, cur.v);                                // G (ms' - mp) + mf
-            Ps = mfma4x4(cur.g, W, cur.Pf);                                // G W + Pf
-            P4[s & 3] = Ps; m4[s & 3] = ms;
-            if ((s & 3) == 0) {
-                // block b takes step s + b: bank-masked moves (a DPP bank is a block), which -- unlike a select on b -- the
-                // compiler cannot turn into divergent branches that would cut the walk into sixteen basic blocks
-                constexpr int kSame = 0xE4;                                 // quad_perm:[0,1,2,3]
-                const double Pv = dpp_banks_f64<kSame, 0x8>(dpp_banks_f64<kSame, 0x4>(dpp_banks_f64<kSame, 0x2>(P4[0], P4[1]), P4[2]), P4[3]);
-                const double mv = dpp_banks_f64<kSame, 0x8>(dpp_banks_f64<kSame, 0x4>(dpp_banks_f64<kSame, 0x2>(m4[0], m4[1]), m4[2]), m4[3]);
-                const unsigned step = (unsigned)(base + s);
-                wPs.store(Pv, offP + step * 128u);
-                wms.store(mv, offm + step * 32u);
+        CGP_UNROLL for (int a = 0; a < kWalkAhead; a++) fetch(15 - a, ring[a]);
+        CGP_UNROLL for (int Q = 15; Q >= 0; Q--) {                         // fully unrolled: the ring is register renaming
+            fetch(Q - kWalkAhead, ring[(15 - Q + kWalkAhead) % (kWalkAhead + 1)]);       // (the records fetched past the tile's first quad are not used)
+            const Walk4Operands& cur = ring[(15 - Q) % (kWalkAhead + 1)];
+            if constexpr (MODE == kWalkCompose) {
+                // the quad's whole map (step 4 Q) onto the segment's: every block does the same
+                Acc = mfma4x4(cur.g, Acc, 0.0);
+                ms = mfma4x4(cur.g, ms, cur.c);
+                const double Tt = mfma4x4(Ps, cur.g, 0.0);
+                Ps = mfma4x4(cur.g, Tt, cur.C);
+            } else {
+                const double W = mfma4x4(Ps, cur.g, 0.0);                  // Ps'' M_b^T
+                const double msn = mfma4x4(cur.g, ms, cur.c);              // M_b ms'' + c_b
+                const double Psn = mfma4x4(cur.g, W, cur.C);               // M_b W + C_b
+                const unsigned step = (unsigned)(base + 4 * Q);
+                wPs.store(Psn, offP + step * 128u);
+                wms.store(msn, offm + step * 32u);
+                Ps = blk_bcast0(Psn);                                      // block 0 = step 4 Q: the next quad's carry
+                ms = blk_bcast0(msn);
             }
         }
     };
 
     Vec<4> mf; Sym<4> Pf;
     if constexpr (Elem::HAS_SPEC) {
-        // The gains of tile n + 1 are built in the same basic block as the walk of tile n: as straight-line code without regime
-        // branches (gain_spec) they are free to move around the walk's serial chain of matrix instructions (the compiler puts
-        // the prediction and the factorisation in front of it and the solves behind it; a finer interleaving spelt out with
-        // sched_group_barrier was not taken up).  A lane outside the regime (rare) has its gain rebuilt by the checked form
-        // after the walk.  Rows are requested two tiles ahead.  0.79 -> 0.73 ms on the bench configuration.
+        // The maps of tile n + 1 are built in the same basic block as phases S and W of tile n: as straight-line code without
+        // regime branches (gain_spec) they are free to move around the matrix instructions.  A lane outside the regime
+        // (rare) has its gain rebuilt by the checked form afterwards.  Rows are requested two tiles ahead.
         {
-            Mat<4> G; Vec<4> mp; Sym<4> Pp;
-            request(T - 2 - 63, mf, Pf);
-            const bool valid = T - 2 - 63 + lane >= 0;
-            if (valid) elem.gain(mf, Pf, G, mp, Pp);
-            write_record(valid, G, mp, Pp, mf, Pf);
+            Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C;
+            request(hi_first - 63, mf, Pf);
+            const bool valid = hi_first - 63 + lane >= 0;
+            if (valid) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+            write_record(valid, G, c, C);
             wave_lds_fence();
-            request(T - 2 - 127, mf, Pf);
+            request(hi_first - 127, mf, Pf);
         }
-        for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+        for (int64_t hi = hi_first; hi >= hi_stop; hi -= 64) {
             const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
             Vec<4> mf2; Sym<4> Pf2;
             request(base - 128, mf2, Pf2);                                 // two tiles ahead: used at the end of the next iteration
-            Mat<4> G; Vec<4> mp; Sym<4> Pp; bool ok;
+            Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C; bool ok;
+#if !(CGP_WALK_ABLATE & 4)
             elem.gain_spec(mf, Pf, G, mp, Pp, ok);                         // tile n + 1 (on the clamped row where it does not exist)
-            walk(base);                                                    // tile n
+            walk4_affine(mf, Pf, mp, Pp, G, c, C);
+#else
+            ok = true; CGP_UNROLL for (int a_ = 0; a_ < 4; a_++) { c.v[a_] = mf.v[a_]; CGP_UNROLL for (int k_ = 0; k_ < 4; k_++) G.a[a_][k_] = 0.1 * Pf(a_, k_); } C = Pf;
+#endif
+#if !(CGP_WALK_ABLATE & 1)
+            scan();                                                        // tile n
+#endif
             wave_lds_fence();
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) elem.gain(mf, Pf, G, mp, Pp);
-            write_record(base - 64 + lane >= 0, G, mp, Pp, mf, Pf);
+#if !(CGP_WALK_ABLATE & 2)
+            walk(base);
+#endif
+            wave_lds_fence();
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+            write_record(base - 64 + lane >= 0, G, c, C);
             wave_lds_fence();
             mf = mf2; Pf = Pf2;
         }
     } else {
-        request(T - 2 - 63, mf, Pf);
-        for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
+        request(hi_first - 63, mf, Pf);
+        for (int64_t hi = hi_first; hi >= hi_stop; hi -= 64) {
             const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
-            // ---- every lane: prediction and gain of its own step, then its record
+            // ---- every lane: the map of its own step, then its record
             {
-                Mat<4> G; Vec<4> mp; Sym<4> Pp;
+                Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C;
                 const bool valid = base + lane >= 0;
-                if (valid) elem.gain(mf, Pf, G, mp, Pp);
-                write_record(valid, G, mp, Pp, mf, Pf);
+                if (valid) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+                write_record(valid, G, c, C);
             }
             wave_lds_fence();
             request(base - 64, mf, Pf);                                    // the NEXT (earlier) tile's row: requested now, used after the walk
+            scan();
+            wave_lds_fence();
             walk(base);
             wave_lds_fence();
         }
     }
+    if constexpr (MODE == kWalkCompose) {
+        double* __restrict__ out = io.ws + (trial * io.segs + seg) * kWalkMapDoubles;
+        if (b == 0) {
+            out[r * 4 + q] = Acc;
+            out[16 + r * 4 + q] = Ps;
+            if (q == 0) out[32 + r] = ms;
+        }
+    }
 }
 
-// One workgroup holds 64 records (27 136 B) beside the staged sigma-point set; four of them have to share a CU's 160 KB.
+// One workgroup holds 64 records (18 944 B) beside the staged sigma-point set; at least four of them have to share a CU's 160 KB.
 inline bool walk4_smoother_ok(int64_t T, const ModelArgs& ma) {
     return T * 128 <= kOobMaxBytes && sigma_lds_bytes(ma, 4) + sizeof(double) * 64 * kWalkRec + 64 <= 40 * 1024;
 }
+// Wavefronts per trial for the time-split form: as many as keep every workgroup resident at once (what the occupancy query
+// says a CU holds of this kernel: registers, 18.9 KB of records plus the staged sigma-point set), each with at least four
+// tiles; 1 = one wave per trial.
+inline int walk_segments(const SmootherIO& io, int blocks_per_cu) {
+    if (io.segs == 1) return 1;
+    const int64_t tiles = (io.T - 1 + 63) / 64;
+    int64_t per_cu = blocks_per_cu > 0 ? blocks_per_cu : 4;                  // what the kernel's registers and LDS let a CU hold
+    if (per_cu > 8) per_cu = 8;
+    int64_t segs = ((int64_t)io.num_cus * per_cu) / (io.B > 0 ? io.B : 1);
+    if (io.segs > 1 && segs > io.segs) segs = io.segs;
+    const int64_t min_tiles = io.min_tiles > 0 ? io.min_tiles : 1;
+    if (segs > tiles / min_tiles) segs = tiles / min_tiles;
+    if (segs > 64) segs = 64;
+    return segs < 2 ? 1 : (int)segs;
+}
+
 template <class Elem>
-inline hipError_t launch_walk4_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
-    if (io.B <= 0 || io.T <= 0) return hipSuccess;
-    if (!walk4_smoother_ok(io.T, ma)) return hipErrorInvalidValue;
+inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs& ma, hipStream_t stream) {
+    if (io_in.B <= 0 || io_in.T <= 0) return hipSuccess;
+    if (!walk4_smoother_ok(io_in.T, ma)) return hipErrorInvalidValue;
     const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, 4) : 0;
-    hipLaunchKernelGGL((walk4_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
-    return hipGetLastError();
+    int per_cu = 0;
+    if (io_in.segs != 1 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, walk4_smoother_kernel<Elem, kWalkApply>, 64, dyn) != hipSuccess) per_cu = 4;
+    const int segs = walk_segments(io_in, per_cu);
+    if (segs <= 1) {
+        hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+        return hipGetLastError();
+    }
+    // time-split: two passes with the segments' maps in a stream-ordered scratch allocation (nothing the caller sees)
+    SmootherIO io = io_in;
+    io.segs = segs;
+    const int64_t tiles = (io.T - 1 + 63) / 64;
+    io.tiles_per_seg = (int)((tiles + io.segs - 1) / io.segs);
+    io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, sizeof(double) * kWalkMapDoubles * (size_t)io.B * io.segs, stream);
+    if (e != hipSuccess) return e;
+    io.ws = (double*)ws;
+    const unsigned grid = (unsigned)(io.B * io.segs);
+    hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace cgp

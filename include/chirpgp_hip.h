@@ -145,6 +145,10 @@ typedef struct cgp_init {
                                         the DPP / LDS-reduced cooperative kernels instead of the matrix-core (MFMA) ones       */
 #define CGP_FOUR_TRIALS_PER_WAVE 0x200u /* d = 4 matrix-core EKF: four trials per wavefront whatever the batch (default above 1024) */
 #define CGP_ONE_TRIAL_PER_WAVE   0x400u /* ... one trial per wavefront whatever the batch                                      */
+#define CGP_TIME_SPLIT        0x800u  /* discrete smoothers (rts, eks, sgp_smoother), one wavefront per trial: cut every record into segments
+                                        walked by different wavefronts (two passes: compose the segments' affine maps, then walk with the
+                                        right carry) whatever the batch -- default when the batch leaves two thirds of the SIMDs idle    */
+#define CGP_NO_TIME_SPLIT     0x1000u /* ... never                                                                                      */
 #define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
 
 /* ---- error codes ---------------------------------------------------------------------------------------- */

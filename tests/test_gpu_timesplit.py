@@ -1,0 +1,141 @@
+"""Time-split discrete smoothers (CGP_TIME_SPLIT; default for small batches): every record cut into segments walked by
+different wavefronts -- pass 1 composes each segment's affine map, pass 2 walks with the right carry (cgp_walk4.hpp,
+cgp_coop8.hpp).  Exact by construction (the gain depends on the filtering results only: filters_smoothers.py:83-84, 212-215,
+342-345, 524-527); checked against oracle/c/port.c on identical filtering inputs and against the one-wave-per-trial form."""
+import numpy as np
+import pytest
+
+from tests import cases as cs
+
+pytestmark = pytest.mark.gpu
+
+WAVE, TIME_SPLIT, NO_TIME_SPLIT = 0x2, 0x800, 0x1000
+SPLIT = dict(flags=WAVE | TIME_SPLIT)
+WHOLE = dict(flags=WAVE | NO_TIME_SPLIT)
+
+
+def _filter_inputs(c, B, seed, nan_trial=None):
+    """Filtering results of B noisy copies of the case's record from the port (the smoothers are compared on identical inputs);
+    ``nan_trial`` gets ONE poisoned filtering covariance in the middle of its record."""
+    from oracle import port
+    rng = np.random.default_rng(seed)
+    ys = c.ys[None, :] + 0.05 * rng.standard_normal((B, c.ys.size))
+    f = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    if nan_trial is not None:
+        f[1][nan_trial, c.ys.size // 2, 1, 1] = np.nan
+    return f
+
+
+@pytest.mark.parametrize('T', [66, 130, 449, 450, 1000, 2049, 4161])
+def test_eks_time_split_against_the_port_and_the_whole_record_walk(T):
+    """Ragged T: one tile, segments of unequal length, a wrapped last tile; one trial with a NaN measurement in the middle."""
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    c = cs.chirp_case(T=T, seed=41)
+    f = _filter_inputs(c, 5, T, nan_trial=3)
+    want = port.smoother(port.S_EKS, c.disc, None, c.dt, f[0], f[1])
+    got = fs.eks(c.disc, f[0], f[1], c.dt, **SPLIT)
+    whole = fs.eks(c.disc, f[0], f[1], c.dt, **WHOLE)
+    for g, w, o, n in zip(got, want, whole, ('mss', 'Pss')):
+        cs.assert_close(g, w, 1e-9, f'eks split {n}')
+        cs.assert_close(g, o, 1e-11, f'eks split vs whole {n}')
+    assert np.isnan(got[0][3, :T // 2 + 1]).all() and np.isfinite(got[0][3, T // 2 + 1:]).all()  # NaN flows backwards in time only
+
+
+@pytest.mark.parametrize('method', ['rts', 'sgp_smoother', 'sgp_smoother_literal', 'lascala_eks'])
+def test_other_d4_smoothers_time_split(method):
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    T, B = 1500, 6
+    if method == 'rts':
+        c = cs.chirp_case(T=T, seed=43)
+        import bench
+        F, Sigma = bench.frozen_frequency_linear_model(np.array([0.1, 0.1, 0.1, 1., 1., 7.]), c.dt)
+        from chirpgp_amd import models as pm
+        lin = pm.linear_cond_m_cov(F, Sigma)
+        ys = c.ys[None, :] + 0.05 * np.random.default_rng(1).standard_normal((B, T))
+        f = port.filter(port.F_EKF, lin, None, c.H, c.Xi, c.m0, c.P0, 0., ys)
+        want = port.smoother(port.S_EKS, lin, None, 0., f[0], f[1])
+        got = fs.rts(F, Sigma, f[0], f[1], **SPLIT)
+        whole = fs.rts(F, Sigma, f[0], f[1], **WHOLE)
+    elif method == 'lascala_eks':
+        c = cs.lascala_case(T=T, seed=44)
+        f = _filter_inputs(c, B, 2)
+        want = port.smoother(port.S_EKS, c.disc, None, c.dt, f[0], f[1])
+        got = fs.eks(c.disc, f[0], f[1], c.dt, **SPLIT)
+        whole = fs.eks(c.disc, f[0], f[1], c.dt, **WHOLE)
+    else:
+        c = cs.chirp_case(T=T, seed=45)
+        f = _filter_inputs(c, B, 3, nan_trial=1)
+        want = port.smoother(port.S_SGP, c.disc, c.sgps, c.dt, f[0], f[1])
+        kw = dict(flags=SPLIT['flags'] | (0x40 if method.endswith('literal') else 0))
+        got = fs.sgp_smoother(c.disc, c.sgps, f[0], f[1], c.dt, **kw)
+        whole = fs.sgp_smoother(c.disc, c.sgps, f[0], f[1], c.dt, flags=kw['flags'] ^ TIME_SPLIT ^ NO_TIME_SPLIT)
+    # exactness of the split: against the one-wave-per-trial form of the same kernel; accuracy: against the port (the elements
+    # evaluate the models with the lean in-kernel functions, 1e-11 .. 1e-10 of the port, as in test_gpu_parity.py)
+    for g, w, o, n in zip(got, want, whole, ('mss', 'Pss')):
+        cs.assert_close(g, o, 1e-11, f'{method} split vs whole {n}')
+        cs.assert_close(g, w, 1e-8 if 'sgp' not in method else 1e-7, f'{method} split {n}')
+
+
+@pytest.mark.parametrize('nh,method', [(3, 'eks'), (3, 'sgp_smoother'), (2, 'sgp_smoother'), (3, 'rts')])
+def test_d6_d8_smoothers_time_split(nh, method):
+    """The tile-layout smoothers (5 <= d <= 8) in the time-split form: BASELINE C5's smoother at its 8-GPU shard size."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from oracle import port
+    T, B = 1700, 4
+    c = cs.harmonic_case(T=T, seed=46, nh=nh)
+    rng = np.random.default_rng(4)
+    ys = c.ys[None, :] + 0.05 * rng.standard_normal((B, T))
+    if method == 'rts':
+        d = 2 * nh + 2
+        F = np.eye(d) * 0.99 + 0.01 * rng.standard_normal((d, d))
+        Sigma = np.eye(d) * 0.01
+        lin = pm.linear_cond_m_cov(F, Sigma)
+        f = port.filter(port.F_EKF, lin, None, c.H, c.Xi, c.m0, c.P0, 0., ys)
+        f[1][2, T // 3, 0, 0] = np.nan
+        want = port.smoother(port.S_EKS, lin, None, 0., f[0], f[1])
+        got = fs.rts(F, Sigma, f[0], f[1], **SPLIT)
+        whole = fs.rts(F, Sigma, f[0], f[1], **WHOLE)
+    elif method == 'eks':
+        f = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        f[1][2, T // 3, 0, 0] = np.nan
+        want = port.smoother(port.S_EKS, c.disc, None, c.dt, f[0], f[1])
+        got = fs.eks(c.disc, f[0], f[1], c.dt, **SPLIT)
+        whole = fs.eks(c.disc, f[0], f[1], c.dt, **WHOLE)
+    else:
+        f = port.filter(port.F_SGP, c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        f[1][2, T // 3, 0, 0] = np.nan
+        want = port.smoother(port.S_SGP, c.disc, c.sgps, c.dt, f[0], f[1])
+        got = fs.sgp_smoother(c.disc, c.sgps, f[0], f[1], c.dt, **SPLIT)
+        whole = fs.sgp_smoother(c.disc, c.sgps, f[0], f[1], c.dt, **WHOLE)
+    for g, w, o, n in zip(got, want, whole, ('mss', 'Pss')):
+        cs.assert_close(g, w, 1e-8, f'd{2 * nh + 2} {method} split {n}')
+        cs.assert_close(g, o, 1e-10, f'd{2 * nh + 2} {method} split vs whole {n}')
+
+
+def test_small_batch_takes_the_time_split_form_by_default_and_is_faster():
+    """B = 125, T = 10 000 (BASELINE C3's shard on one of 8 GPUs): the default call is the time-split form -- same results as the
+    whole-record walk to rounding, and at least twice as fast (measured ~4x; the bound is loose on purpose)."""
+    import torch
+    import bench
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    wl = bench.make_workload(125, 10000, kind='ekf')
+    ys = torch.from_numpy(wl['ys']).cuda()
+    f = fs.ekf(wl['disc'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys)
+
+    def timed(**kw):
+        out = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
+        torch.cuda.synchronize()
+        ev = _engine.kernel_events = []
+        for _ in range(5):
+            out = fs.eks(wl['disc'], f[0], f[1], wl['dt'], **kw)
+        torch.cuda.synchronize()
+        _engine.kernel_events = None
+        return out, min(a.elapsed_time(b) for _, a, b in ev)
+    auto, t_auto = timed()
+    whole, t_whole = timed(flags=NO_TIME_SPLIT)
+    print(f'eks B=125 T=10000: default {t_auto:.3f} ms, one wave per trial {t_whole:.3f} ms')
+    for a, b in zip(auto, whole):
+        cs.assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-11, 'auto vs whole')
+    assert t_auto < 0.5 * t_whole, (t_auto, t_whole)
