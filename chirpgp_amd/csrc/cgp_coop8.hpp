@@ -417,24 +417,56 @@ inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
 // ====================================================================================================================
 // Discrete smoothers (rts / eks / sgp_smoother, filters_smoothers.py:187-219, 317-349, 493-531) for 5 <= d <= 8.
 //
-// The time-parallel smoother of cgp_kernels.hpp composes the affine maps of 64 steps with a six-round suffix scan in
-// which EVERY lane multiplies 8 x 8 matrices every round: 10 000 of its 25 000 wave-instructions per tile at d = 8, with
-// two maps live per lane (register spills).  Here the lanes still do the expensive, independent part of their own steps
-// in parallel -- prediction (model / sigma fan) at (mf, Pf), Cholesky of Pp, the gain G = (Pp^{-1} D^T)^T: 64 chains,
-// one per lane -- but nothing is composed: (G, mp, Pp) of the steps go to LDS and the wavefront walks the tile backwards
-// COOPERATIVELY, carrying (ms, Ps) in the tile layout and applying the reference's own recursion on the matrix cores,
-//     X = Ps' - Pp,   W = X G^T,   Ps = G W + Pf,      ms = G (ms' - mp) + mf          (filters_smoothers.py:83-84)
+// The backward recursion (filters_smoothers.py:83-84) is an affine map of the carry whose coefficients depend on the filtering
+// results only:   ms_t = G_t ms_{t+1} + c_t,   Ps_t = G_t Ps_{t+1} G_t^T + C_t,   c_t = mf_t - G_t mp_t,   C_t = Pf_t - G_t Pp_t G_t^T.
+// The time-parallel smoother of cgp_kernels.hpp composes these maps with a six-round suffix scan in which EVERY lane
+// multiplies 8 x 8 matrices every round: 10 000 of its 25 000 wave-instructions per tile at d = 8, with two maps live per lane
+// (register spills).  Here the lanes still do the expensive, independent part of their own steps in parallel -- prediction
+// (model / sigma fan) at (mf, Pf), Cholesky of Pp, the gain G = (Pp^{-1} D^T)^T, then c and C: 64 chains, one per lane -- but
+// nothing is composed: (G, C, c) of the steps go to LDS (108 doubles a step) and the wavefront walks the tile backwards
+// COOPERATIVELY, carrying (ms, Ps) in the tile layout and applying the recursion on the matrix cores,
+//     W = Ps' G^T,   Ps = G W + C,      ms = G ms' + c
 // two 8 x 8 x 8 products = four v_mfma_f64_4x4x4 (the G operands come from LDS already arranged per block, the carry is
-// re-arranged between blocks with bank-masked DPP moves; Pf and mf are read from the input arrays in the tile layout).
-// A step of the walk is a ~150-cycle dependent chain; the next step's operands are fetched while the current one is applied.
-constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | Pp (packed lower, 36) | mp (8) | one zero; odd: conflict-free lane stride
+// re-arranged between blocks with bank-masked DPP moves).  Two record forms:
+//   * one wavefront per trial (coop8_smoother_kernel): records (G, Pp, mp); the walk does X = Ps' - Pp, W = X G^T,
+//     Ps = G W + Pf, ms = G (ms' - mp) + mf with (Pf, mf) of its step read a SECOND time from the input arrays, requested a
+//     batch of eight steps ahead (1.5 x the algorithmic traffic, but the kernel is bound by the lanes' vector work, not by HBM);
+//   * the affine form (coop8_split_kernel): records (G, C, c) with the step's constants folded by the lanes that build the
+//     gains, so the walk reads nothing from HBM and has no subtraction on its chain -- every filtering row is read ONCE.  As
+//     the whole-record kernel it measured SLOWER (BASELINE C5's smoother 5.11 against 4.75 ms, EKS 3.9 against 3.5: the 860
+//     extra multiply-adds a lane-step for C = Pf - G Pp G^T cost more than the second read, which was hidden), so it serves
+//     the time-split passes, where the maps must compose.
+//
+// Small batches: the time-split form (see cgp_walk4.hpp) -- pass 1 (kWalkCompose) walks every segment with the carry (0, 0)
+// and one more product a step, A <- G A, and leaves the segment's composed map (A, C, c) in the workspace in the layout of a
+// step record; pass 2 (kWalkApply) applies the later segments' maps to the record's last filtering row (one "walk step"
+// each, operands straight from the workspace) and walks its segment.
+constexpr int kElemDoubles = 109;                 // G (8 x 8, pitch 8) | C (packed lower, 36) | c (8) | one zero; odd: conflict-free lane stride
 constexpr int kElemC = 64, kElemc = 100, kElemZero = 108;
+constexpr int kMap8Doubles = 112;                 // a segment's map in the workspace: the same layout, padded to 16-byte multiples
+enum { kWalkWhole = 0, kWalkCompose = 1, kWalkApply = 2 };
 
+// Wavefronts per trial for the time-split form: as many as keep every workgroup resident at once (what the occupancy query
+// says a CU holds of the kernel: registers, the LDS records plus the staged sigma-point set), each with at least
+// io.min_tiles tiles; 1 = one wave per trial.
+inline int walk_segments(const SmootherIO& io, int blocks_per_cu) {
+    if (io.segs == 1) return 1;
+    const int64_t tiles = (io.T - 1 + 63) / 64;
+    int64_t per_cu = blocks_per_cu > 0 ? blocks_per_cu : 4;
+    if (per_cu > 8) per_cu = 8;
+    int64_t segs = ((int64_t)io.num_cus * per_cu) / (io.B > 0 ? io.B : 1);
+    if (io.segs > 1 && segs > io.segs) segs = io.segs;
+    const int64_t min_tiles = io.min_tiles > 0 ? io.min_tiles : 1;
+    if (segs > tiles / min_tiles) segs = tiles / min_tiles;
+    if (segs > 64) segs = 64;
+    return segs < 2 ? 1 : (int)segs;
+}
 
-struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc; };
+// ---- one wavefront per trial: records (G, Pp, mp), the walk reads (Pf, mf) of its step from the input arrays
+struct Elem8WalkOperands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc; };
 
 template <class Elem>
-__global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {
+__global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {      // one wavefront per trial, the whole record
     constexpr int D = Elem::D;
     static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
     __shared__ double elems[32 * kElemDoubles];
@@ -508,7 +540,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
             // filtering rows (Pf, mf) of a batch are requested one batch ahead -- by then the lines a lane read for its own
             // gain have long left L2, and a miss costs three walk steps -- the LDS operands one step ahead.  Steps before the
             // start of the record (last tile) are walked too: their loads return 0 and their stores are dropped.
-            auto fetch = [&](int s, Elem8Operands& o) {
+            auto fetch = [&](int s, Elem8WalkOperands& o) {
                 const double* p = elems + (s & 31) * kElemDoubles;
                 o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Ppv = p[oP]; o.mpc = p[om];
             };
@@ -521,7 +553,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
             };
             double pf_cur[8], mf_cur[8], pf_nxt[8], mf_nxt[8];
             request(32 * half + 31, pf_cur, mf_cur);
-            Elem8Operands cur, nxt;
+            Elem8WalkOperands cur, nxt;
             fetch(32 * half + 31, cur);
 #pragma unroll 1
             for (int batch = 0; batch < 4; batch++) {
@@ -551,13 +583,173 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     }
 }
 
+// ---- the affine form: records (G, C, c); the time-split passes, and the whole record with CGP_TIME_SPLIT-style maps
+struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Cv, cr; };
+
+template <class Elem, int MODE>
+__global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArgs ma) {
+    constexpr int D = Elem::D;
+    static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
+    __shared__ double elems[32 * kElemDoubles];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const int I = b >> 1, J = b & 1;
+    const int i = 4 * I + r, j = 4 * J + q;
+    const int64_t trial = (MODE == kWalkWhole) ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / (unsigned)io.segs);
+    const int seg = (MODE == kWalkWhole) ? 0 : (int)(blockIdx.x % (unsigned)io.segs);
+    if (trial >= io.B) return;
+
+    Elem elem;
+    elem.setup(ma, trial);
+    for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / C and the zero slot stay zero
+    if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * D;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
+    double* __restrict__ mss = io.mss + trial * T * D;
+    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+    const bool entry = i < D && j < D;
+    const bool mean_lane = (J == 0 && q == 0 && i < D);
+    // the segment's tiles: tile n covers the steps T - 2 - 64 n - 63 .. T - 2 - 64 n (segment 0 is the LAST in time)
+    const int64_t hi_first = (MODE == kWalkWhole) ? T - 2 : T - 2 - 64 * (int64_t)seg * io.tiles_per_seg;
+    const int64_t hi_stop = (MODE == kWalkWhole) ? 0 : max((int64_t)0, hi_first - 64 * (int64_t)io.tiles_per_seg + 1);
+    if (hi_first < 0 && MODE != kWalkWhole) return;
+
+    // per-lane offsets (doubles) of the operands of one step inside its record (LDS, or a segment's map in the workspace)
+    const int oA = (4 * I + q) * 8 + r;              // G[4 I + q'][4 K + r'] at + 4 K
+    const int oB = (4 * J + q) * 8 + r;              // G[4 J + q'][4 K + r'] at + 4 K
+    const int oM = (4 * I + q) * 8 + 4 * J + r;      // G[4 I + q'][4 J + r']
+    const int oC = entry ? kElemC + Sym<8>::idx(i, j) : kElemZero;
+    const int oc = (i < D) ? kElemc + i : kElemZero;                          // c[4 I + r]
+    // The walk addresses the output rows through buffer windows with per-lane byte offsets: a lane that has nothing to write
+    // carries an out-of-range offset (dropped), so no store sits behind an exec-mask branch.
+    const unsigned bS = entry ? 8u * (unsigned)(i * D + j) : kOobOffset;
+    const unsigned bms = mean_lane ? 8u * (unsigned)i : kOobOffset;
+    OobWindow wPs, wms;
+    wPs.init(MODE == kWalkCompose ? nullptr : Pss, T * D * D * 8); wms.init(MODE == kWalkCompose ? nullptr : mss, T * D * 8);
+
+    // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
+    double Ps = entry ? Pfs[(T - 1) * D * D + ((i >= j) ? i * D + j : j * D + i)] : 0.0;
+    double xc = (4 * J + r < D) ? mfs[(T - 1) * D + 4 * J + r] : 0.0;
+    double Acc = (entry && i == j) ? 1.0 : 0.0;      // pass 1: the composed linear part, A <- G A
+    if constexpr (MODE == kWalkCompose) { Ps = 0.0; xc = 0.0; }
+    if (MODE != kWalkCompose && seg == 0) {
+        if (entry) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
+        if (mean_lane) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+    }
+    // one step of the recursion with the operands o: W = Ps' G^T, Ps = G W + C, ms = G ms' + c
+    auto step = [&](const Elem8Operands& o, double& ym) {
+        const double W = mfma4x4(blk_rows_of_k1(Ps), o.gB1, mfma4x4(blk_rows_of_k0(Ps), o.gB0, 0.0));
+        // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] ms'[4 J + k] + c
+        ym = mfma4x4(o.gM, xc, 0.0);
+        ym = (ym + blk_xor1(ym)) + o.cr;
+        if constexpr (MODE == kWalkCompose) Acc = mfma4x4(o.gA1, blk_cols_of_k1(Acc), mfma4x4(o.gA0, blk_cols_of_k0(Acc), 0.0));      // G A
+        Ps = mfma4x4(o.gA1, blk_cols_of_k1(W), mfma4x4(o.gA0, blk_cols_of_k0(W), o.Cv));
+        xc = blk_swap12(ym);
+    };
+    if constexpr (MODE == kWalkApply) {
+        // carry-in of this segment: the maps of the segments later in time, applied in order to the last filtering row
+        const double* __restrict__ maps = io.ws + trial * io.segs * kMap8Doubles;
+        for (int s2 = 0; s2 < seg; s2++) {
+            const double* __restrict__ p = maps + s2 * kMap8Doubles;
+            Elem8Operands o;
+            o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Cv = p[oC]; o.cr = p[oc];
+            double ym;
+            step(o, ym);
+        }
+    }
+
+    for (int64_t hi = hi_first; hi >= hi_stop; hi -= 64) {
+        const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
+        // ---- every lane: the map of its own step
+        const int64_t mystep = base + lane;
+        Mat<D> G; Vec<D> c; Sym<D> C;
+        if (mystep >= 0) {
+            Vec<D> mf; Sym<D> Pf;
+            load_vec<D>(mfs + mystep * D, mf);
+            load_sym<D>(Pfs + mystep * D * D, Pf);
+            elem.map(mf, Pf, G, c, C);
+        } else {
+            CGP_UNROLL for (int a = 0; a < D; a++) { c.v[a] = 0.0; CGP_UNROLL for (int k = 0; k < D; k++) G.a[a][k] = 0.0; }
+            CGP_UNROLL for (int a = 0; a < Sym<D>::N; a++) C.a[a] = 0.0;
+        }
+        // The records go to LDS in two halves of 32 (27.9 KB: five workgroups fit a CU; all 64 at once would be 55.8 KB, two
+        // workgroups per CU, and a batch of 1000 trials would run in two rounds): lanes 32..63, the later steps, first; lanes
+        // 0..31 keep theirs in registers until the first half has been walked.
+        CGP_UNROLL for (int half = 1; half >= 0; half--) {
+            if ((lane >> 5) == half) {
+                double* mine = elems + (lane & 31) * kElemDoubles;
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int k = 0; k < D; k++) mine[a * 8 + k] = G.a[a][k];
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int k = 0; k <= a; k++) mine[kElemC + Sym<8>::idx(a, k)] = C(a, k);
+                CGP_UNROLL for (int a = 0; a < D; a++) mine[kElemc + a] = c.v[a];
+            }
+            wave_lds_fence();
+            // ---- the wavefront walks the half from its last step to its first; the LDS operands are fetched one step ahead.
+            // Steps before the start of the record (last tile) are walked too: their records are zero and their stores fall
+            // outside the windows (the step index wraps).
+            auto fetch = [&](int s, Elem8Operands& o) {
+                const double* p = elems + (s & 31) * kElemDoubles;
+                o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Cv = p[oC]; o.cr = p[oc];
+            };
+            Elem8Operands cur, nxt;
+            fetch(31, cur);
+#pragma unroll 8
+            for (int u = 0; u < 32; u++) {
+                const int s = 32 * half + 31 - u;
+                fetch((s - 1) & 31, nxt);                                  // (the record fetched after the half's last step is not used)
+                double ym;
+                step(cur, ym);
+                if constexpr (MODE != kWalkCompose) {
+                    const unsigned st = (unsigned)(base + s);
+                    wPs.store(Ps, bS + st * (unsigned)(D * D * 8));
+                    wms.store(ym, bms + st * (unsigned)(D * 8));
+                }
+                cur = nxt;
+            }
+            wave_lds_fence();
+        }
+    }
+    if constexpr (MODE == kWalkCompose) {
+        // the segment's map in the layout of a step record: A (pitch 8), C (packed lower), c
+        double* __restrict__ out = io.ws + (trial * io.segs + seg) * kMap8Doubles;
+        if (entry) {
+            out[i * 8 + j] = Acc;
+            if (i >= j) out[kElemC + Sym<8>::idx(i, j)] = Ps;
+        } else out[(4 * I + r) * 8 + 4 * J + q] = 0.0;                     // the pads of A (d < 8)
+        if (I == 0 && q == 0 && 4 * J + r < D) out[kElemc + 4 * J + r] = xc;
+        if (lane < kMap8Doubles - kElemc && lane >= D) out[kElemc + lane] = 0.0;      // c's pads and the zero slot
+        if (lane < 36) { int a_ = 0, k_ = lane; while (k_ > a_) { k_ -= a_ + 1; a_++; } if (a_ >= D) out[kElemC + lane] = 0.0; }   // C's pads (d < 8)
+    }
+}
+
 template <class Elem>
-inline hipError_t launch_coop8_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
-    if (io.B <= 0 || io.T <= 0) return hipSuccess;
-    if (io.T * Elem::D * Elem::D * 8 > kOobMaxBytes) return hipErrorInvalidValue;      // 2 GiB buffer windows (callers check coop8_smoother_ok)
+inline hipError_t launch_coop8_smoother(const SmootherIO& io_in, const ModelArgs& ma, hipStream_t stream) {
+    if (io_in.B <= 0 || io_in.T <= 0) return hipSuccess;
+    if (io_in.T * Elem::D * Elem::D * 8 > kOobMaxBytes) return hipErrorInvalidValue;      // 2 GiB buffer windows (callers check coop8_smoother_ok)
     const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
-    hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io.B), dim3(64), dyn, stream, io, ma);
-    return hipGetLastError();
+    int per_cu = 0;
+    if (io_in.segs != 1 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, coop8_split_kernel<Elem, kWalkApply>, 64, dyn) != hipSuccess) per_cu = 4;
+    const int segs = walk_segments(io_in, per_cu);
+    if (segs <= 1) {
+        hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+        return hipGetLastError();
+    }
+    // time-split: two passes with the segments' maps in a stream-ordered scratch allocation (nothing the caller sees)
+    SmootherIO io = io_in;
+    io.segs = segs;
+    const int64_t tiles = (io.T - 1 + 63) / 64;
+    io.tiles_per_seg = (int)((tiles + io.segs - 1) / io.segs);
+    io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, sizeof(double) * kMap8Doubles * (size_t)io.B * io.segs, stream);
+    if (e != hipSuccess) return e;
+    io.ws = (double*)ws;
+    const unsigned grid = (unsigned)(io.B * io.segs);
+    hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace cgp

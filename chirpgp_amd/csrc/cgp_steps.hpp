@@ -830,6 +830,42 @@ CGP_DEV void gain_from_prediction(const Sym<D>& Pp, const Mat<D>& DT, Mat<D>& G)
     }
 }
 
+// (c, C) of a step's affine map from its gain: c = mf - G mp, C = Pf - G Pp G^T.  With G = (Pp^{-1} D^T)^T the product G Pp is
+// the cross-covariance D itself, which the prediction has just produced (DT = D^T), so C = Pf - G D^T costs one triangular
+// product (d^2 (d + 1) / 2 multiply-adds) instead of two full ones -- the same quantity up to the rounding of the solves.
+// For d > 4 that would keep the d x d matrix D^T alive across the factorisation and the solves (measured at d = 8: spills,
+// 3.9 -> 4.6 ms for the EKS of BASELINE C5's model), so there C is formed from Pp row by row as affine_from_prediction does.
+template <int D>
+CGP_DEV void map_from_gain(const Vec<D>& mf, const Sym<D>& Pf, const Vec<D>& mp, const Sym<D>& Pp, const Mat<D>& DT, const Mat<D>& G, Vec<D>& c, Sym<D>& C) {
+    CGP_UNROLL for (int i = 0; i < D; i++) {
+        double s = mf.v[i];
+        CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-G.a[i][k], mp.v[k], s);
+        c.v[i] = s;
+    }
+    if constexpr (D <= 4) {
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j <= i; j++) {
+                double s = Pf(i, j);
+                CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-G.a[i][k], DT.a[k][j], s);
+                C(i, j) = s;
+            }
+    } else {
+        CGP_UNROLL for (int i = 0; i < D; i++) {
+            double t[D];
+            CGP_UNROLL for (int j = 0; j < D; j++) {
+                double s = G.a[i][0] * Pp(0, j);
+                CGP_UNROLL for (int k = 1; k < D; k++) s = fma(G.a[i][k], Pp(k, j), s);
+                t[j] = s;
+            }
+            CGP_UNROLL for (int j = 0; j <= i; j++) {
+                double s = Pf(i, j);
+                CGP_UNROLL for (int k = 0; k < D; k++) s = fma(-t[k], G.a[j][k], s);
+                C(i, j) = s;
+            }
+        }
+    }
+}
+
 // Applies a map to a state, row by row.
 template <int D>
 CGP_DEV void affine_apply(const Affine<D>& e, const Vec<D>& ms, const Sym<D>& Ps, Vec<D>& xm, Sym<D>& xP) {
@@ -869,6 +905,20 @@ template <class DM> struct EksElement {
         model.propagate(mf, Pf, mp, DT, Pp);
         gain_from_prediction<D>(Pp, DT, G);
     }
+    // the step's affine map (G, c, C) for the cooperative walks (cgp_walk4.hpp, cgp_coop8.hpp)
+    CGP_DEV void map(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& c, Sym<D>& C) const {
+        Mat<D> DT; Vec<D> mp; Sym<D> Pp;
+        model.propagate(mf, Pf, mp, DT, Pp);
+        gain_from_prediction<D>(Pp, DT, G);
+        map_from_gain<D>(mf, Pf, mp, Pp, DT, G, c, C);
+    }
+    CGP_DEV void map_spec(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& c, Sym<D>& C, bool& ok) const {
+        Mat<D> DT; Vec<D> mp; Sym<D> Pp;
+        if constexpr (HAS_SPEC) model.propagate_spec(mf, Pf, mp, DT, Pp, ok);
+        else { model.propagate(mf, Pf, mp, DT, Pp); ok = true; }
+        gain_from_prediction<D>(Pp, DT, G);
+        map_from_gain<D>(mf, Pf, mp, Pp, DT, G, c, C);
+    }
     // gain() as straight-line code where the model has a branch-free form (cgp_models.hpp:propagate_spec): ok = false where
     // gain() would have taken a regime fallback
     static constexpr bool HAS_SPEC = std::is_same<DM, HarmonicLCD<1>>::value;
@@ -894,6 +944,12 @@ template <class DM, bool COLL = false> struct SgpsElement {
         Mat<D> DT;
         sgp_prediction<DM, false, true, true, COLL>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
         gain_from_prediction<D>(Pp, DT, G);
+    }
+    CGP_DEV void map(const Vec<D>& mf, const Sym<D>& Pf, Mat<D>& G, Vec<D>& c, Sym<D>& C) const {
+        Mat<D> DT; Vec<D> mp; Sym<D> Pp;
+        sgp_prediction<DM, false, true, true, COLL>(model, sg, 0, nullptr, mf, Pf, mp, Pp, DT);
+        gain_from_prediction<D>(Pp, DT, G);
+        map_from_gain<D>(mf, Pf, mp, Pp, DT, G, c, C);
     }
 };
 

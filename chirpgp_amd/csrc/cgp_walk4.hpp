@@ -34,9 +34,6 @@
 //                                 its own carry-in, a handful of matrix instructions -- and walks its segment as above.
 // A trial then takes 2 T / segs steps instead of T; at B = 125 (BASELINE C3 / C5 sharded over 8 GPUs) segs = 16.
 #pragma once
-#ifndef CGP_WALK_ABLATE
-#define CGP_WALK_ABLATE 0
-#endif
 #include "cgp_coop8.hpp"
 
 namespace cgp {
@@ -45,36 +42,11 @@ constexpr int kWalkRec = 37;                      // G 16 (row-major) | C 16 (fu
 constexpr int kWalkG = 0, kWalkC = 16, kWalkc = 32;
 constexpr int kWalkAhead = 2;                     // quads between an operand's LDS read and its use
 constexpr int kWalkMapDoubles = 40;               // a segment's composed map in the workspace: A 16 | C 16 | c 4 | pad
-enum { kWalkWhole = 0, kWalkCompose = 1, kWalkApply = 2 };
-
 struct Walk4Operands { double g, C, c; };
 
 // block 0's value in all four blocks (same r, q): blocks move inside a DPP row with row rotations and bank masks
 CGP_DEV double blk_bcast0(double x) {
     return dpp_banks_f64<kRowRor12, 0x8>(dpp_banks_f64<kRowRor8, 0x4>(dpp_banks_f64<kRowRor4, 0x2>(x, x), x), x);
-}
-
-// (c, C) of a step's map from its gain and prediction: c = mf - G mp, C = Pf - G Pp G^T (the second half of
-// affine_from_prediction, cgp_steps.hpp)
-CGP_DEV void walk4_affine(const Vec<4>& mf, const Sym<4>& Pf, const Vec<4>& mp, const Sym<4>& Pp, const Mat<4>& G, Vec<4>& c, Sym<4>& C) {
-    CGP_UNROLL for (int i = 0; i < 4; i++) {
-        double s = mf.v[i];
-        CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(-G.a[i][k], mp.v[k], s);
-        c.v[i] = s;
-    }
-    CGP_UNROLL for (int i = 0; i < 4; i++) {
-        double t[4];
-        CGP_UNROLL for (int j = 0; j < 4; j++) {
-            double s = G.a[i][0] * Pp(0, j);
-            CGP_UNROLL for (int k = 1; k < 4; k++) s = fma(G.a[i][k], Pp(k, j), s);
-            t[j] = s;
-        }
-        CGP_UNROLL for (int j = 0; j <= i; j++) {
-            double s = Pf(i, j);
-            CGP_UNROLL for (int k = 0; k < 4; k++) s = fma(-t[k], G.a[j][k], s);
-            C(i, j) = s;
-        }
-    }
 }
 
 template <class Elem, int MODE = kWalkWhole>
@@ -198,10 +170,10 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
         // regime branches (gain_spec) they are free to move around the matrix instructions.  A lane outside the regime
         // (rare) has its gain rebuilt by the checked form afterwards.  Rows are requested two tiles ahead.
         {
-            Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C;
+            Mat<4> G; Vec<4> c; Sym<4> C;
             request(hi_first - 63, mf, Pf);
             const bool valid = hi_first - 63 + lane >= 0;
-            if (valid) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+            if (valid) elem.map(mf, Pf, G, c, C);
             write_record(valid, G, c, C);
             wave_lds_fence();
             request(hi_first - 127, mf, Pf);
@@ -210,22 +182,13 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
             Vec<4> mf2; Sym<4> Pf2;
             request(base - 128, mf2, Pf2);                                 // two tiles ahead: used at the end of the next iteration
-            Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C; bool ok;
-#if !(CGP_WALK_ABLATE & 4)
-            elem.gain_spec(mf, Pf, G, mp, Pp, ok);                         // tile n + 1 (on the clamped row where it does not exist)
-            walk4_affine(mf, Pf, mp, Pp, G, c, C);
-#else
-            ok = true; CGP_UNROLL for (int a_ = 0; a_ < 4; a_++) { c.v[a_] = mf.v[a_]; CGP_UNROLL for (int k_ = 0; k_ < 4; k_++) G.a[a_][k_] = 0.1 * Pf(a_, k_); } C = Pf;
-#endif
-#if !(CGP_WALK_ABLATE & 1)
+            Mat<4> G; Vec<4> c; Sym<4> C; bool ok;
+            elem.map_spec(mf, Pf, G, c, C, ok);                            // tile n + 1 (on the clamped row where it does not exist)
             scan();                                                        // tile n
-#endif
             wave_lds_fence();
-#if !(CGP_WALK_ABLATE & 2)
             walk(base);
-#endif
             wave_lds_fence();
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) elem.map(mf, Pf, G, c, C);
             write_record(base - 64 + lane >= 0, G, c, C);
             wave_lds_fence();
             mf = mf2; Pf = Pf2;
@@ -236,9 +199,9 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             const int64_t base = hi - 63;                                  // step of lane 0 (may be negative in the last tile)
             // ---- every lane: the map of its own step, then its record
             {
-                Mat<4> G; Vec<4> mp, c; Sym<4> Pp, C;
+                Mat<4> G; Vec<4> c; Sym<4> C;
                 const bool valid = base + lane >= 0;
-                if (valid) { elem.gain(mf, Pf, G, mp, Pp); walk4_affine(mf, Pf, mp, Pp, G, c, C); }
+                if (valid) elem.map(mf, Pf, G, c, C);
                 write_record(valid, G, c, C);
             }
             wave_lds_fence();
@@ -263,22 +226,6 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
 inline bool walk4_smoother_ok(int64_t T, const ModelArgs& ma) {
     return T * 128 <= kOobMaxBytes && sigma_lds_bytes(ma, 4) + sizeof(double) * 64 * kWalkRec + 64 <= 40 * 1024;
 }
-// Wavefronts per trial for the time-split form: as many as keep every workgroup resident at once (what the occupancy query
-// says a CU holds of this kernel: registers, 18.9 KB of records plus the staged sigma-point set), each with at least four
-// tiles; 1 = one wave per trial.
-inline int walk_segments(const SmootherIO& io, int blocks_per_cu) {
-    if (io.segs == 1) return 1;
-    const int64_t tiles = (io.T - 1 + 63) / 64;
-    int64_t per_cu = blocks_per_cu > 0 ? blocks_per_cu : 4;                  // what the kernel's registers and LDS let a CU hold
-    if (per_cu > 8) per_cu = 8;
-    int64_t segs = ((int64_t)io.num_cus * per_cu) / (io.B > 0 ? io.B : 1);
-    if (io.segs > 1 && segs > io.segs) segs = io.segs;
-    const int64_t min_tiles = io.min_tiles > 0 ? io.min_tiles : 1;
-    if (segs > tiles / min_tiles) segs = tiles / min_tiles;
-    if (segs > 64) segs = 64;
-    return segs < 2 ? 1 : (int)segs;
-}
-
 template <class Elem>
 inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs& ma, hipStream_t stream) {
     if (io_in.B <= 0 || io_in.T <= 0) return hipSuccess;
