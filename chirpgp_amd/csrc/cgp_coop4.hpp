@@ -109,6 +109,12 @@ struct OobWindow {
         u32x2_t d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
         __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)off, 0, 0);
     }
+    // the same with a wave-uniform part of the offset in the instruction's SCALAR offset (not part of the range check: a lane
+    // is dropped by its vector offset alone, so `soff` must keep in-range lanes inside the window)
+    CGP_DEV void store_s(double v, unsigned off, unsigned soff) const {
+        u32x2_t d; d.x = (unsigned)__double2loint(v); d.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)off, (int)soff, 0);
+    }
     CGP_DEV void store2(double a, double b, unsigned off) const {
         u32x4_t d; d.x = (unsigned)__double2loint(a); d.y = (unsigned)__double2hiint(a);
         d.z = (unsigned)__double2loint(b); d.w = (unsigned)__double2hiint(b);

@@ -1,0 +1,9 @@
+// The d = 4 matrix-core EKF (cgp_mfma4.hpp: BASELINE C2's filter, the bench kernel) in its own translation unit: VGPR-form MFMA
+// results like the other matrix-core kernels, but the DEFAULT scheduling strategy -- with four steps per loop iteration the
+// max-ILP strategy measured slower on it (2.72 against 2.65 ms; Makefile).
+#define CGP_COOP4_HELPERS_ONLY
+#define CGP_EKF4_KERNELS
+#include "cgp_mfma4.hpp"
+namespace cgp {
+int dispatch_filter_mfma4(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_ekf4_mfma(io, ma, st); }
+}  // namespace cgp

@@ -1,12 +1,11 @@
-// The matrix-core d = 4 kernels -- EKF (cgp_mfma4.hpp), sigma-point filter (cgp_mfma4_sigma.hpp), the continuous-discrete
-// filters and smoothers (cgp_mfma4_cd.hpp) -- in their own translation unit: it is compiled with the max-ILP scheduling strategy and VGPR-form MFMA results (Makefile), which suit
+// The matrix-core d = 4 kernels -- sigma-point filter (cgp_mfma4_sigma.hpp), the continuous-discrete filters and smoothers
+// (cgp_mfma4_cd.hpp); the EKF of cgp_mfma4.hpp is instantiated in cgp_inst_ekf4.hip -- in their own translation unit: it is compiled with the max-ILP scheduling strategy and VGPR-form MFMA results (Makefile), which suit
 // their single long dependent chain and not the other kernels.
 #define CGP_COOP4_HELPERS_ONLY
 #include "cgp_mfma4.hpp"
 #include "cgp_mfma4_sigma.hpp"
 #include "cgp_mfma4_cd.hpp"
 namespace cgp {
-int dispatch_filter_mfma4(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_ekf4_mfma(io, ma, st); }
 int dispatch_filter_mfma4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_sgp4_mfma<HarmonicLCD<1>>(io, ma, st); }
 int dispatch_filter_mfma4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgp4_mfma<HarmonicSDE<1>>(io, ma, st); }
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgps4_mfma<HarmonicSDE<1>>(io, ma, st); }

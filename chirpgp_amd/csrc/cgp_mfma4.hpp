@@ -42,6 +42,8 @@ struct Ekf4MfmaConst {
     double M0, M1, M2, M3, rho, ang;           // M32 block, exp(-lam dt), dt 2 pi fs
     double Hr, Xi, Sig;
     double kc, ks, kj, kk;                     // J[q][r] = kc c + ks s + kk + kj dth f[q ^ 1]  (kj = -1 at (0, 2), +1 at (1, 2))
+    double kcr, ksr, kja;                      // kc rho, ks rho, kj ang: the damping and the angle scale ride in the per-lane coefficients
+    CGP_DEV void fold() { kcr = kc * rho; ksr = ks * rho; kja = kj * ang; }
 };
 // The mean is distributed like the covariance: ur = u[r] (row layout) and uq = u[q] (column layout) at lane (r, q); the
 // frequency state u[2] every lane needs is one quad broadcast of uq.
@@ -58,10 +60,9 @@ struct Ekf4State {
 // so the per-lane scalar copies of u0..u3 and f0..f3, the quad broadcasts of PH and the FMA chains for f and H . f are
 // gone; the Jacobian column d f / d u2 = dth (-f1, f0) is a quad swap of f by column times a per-lane sign.
 CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
-    const double c = c1 * K.rho, s = s1 * K.rho;
-    const double J0T = fma(K.kc, c, fma(K.ks, s, K.kk));
+    const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
     const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
-    const double kjd = K.kj * (K.ang * dsp);
+    const double kjd = K.kja * dsp;
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
     // ---- predict: Pp = J P J^T + Sigma
     const double Q = mfma4(x.P, RJT, 0.0);
@@ -128,6 +129,42 @@ CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, doub
     ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
 }
 
+// The one-trial-per-wave kernel's form of the speculative step (round 3), five vector instructions shorter:
+//   * the increment's sine and cosine to d^3 / d^4 only: while |d| <= 2^-7 the dropped terms are below d^5 / 120 = 2.4e-13
+//     relative and d^6 / 720 = 3e-16 (the bench records' largest increment, 2.7e-3, gives 1.2e-15), and the pair is re-anchored
+//     every 64 steps;
+//   * the regime verdicts as WAVE MASKS: one integer range compare of u2's high word (NaN, inf, negative and out-of-range
+//     values fall outside [1.5, 700) as unsigned offsets) and one |d| compare, each a v_cmp into a scalar register pair ORed
+//     into a 64-bit scalar accumulator -- three vector instructions instead of six, and the chunk's verdict is a scalar
+//     compare (no readfirstlane).
+CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
+                                  double& innov, unsigned long long* uncommon) {
+    const double u2 = x.u2();
+    const double t = exp_neg_lean(R, u2);
+    const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
+    double qa, dsp;
+    softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
+    const double d = fma(qa, t, lin);
+    const double d2 = d * d, d4 = d2 * d2;
+    const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
+    const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
+    const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
+    const unsigned hx = (unsigned)__double2hiint(u2) - 0x3FF80000u;                  // 1.5 -> 0, 700 -> 0x008DDFFF
+    *uncommon |= __builtin_amdgcn_ballot_w64(hx > 0x008DDFFFu) | __builtin_amdgcn_ballot_w64(!(fabs(d) <= 0x1p-7));
+    a.th += d; a.c1 = c1; a.s1 = s1;
+    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+}
+
+// Tried with it and dropped (all measured on the bench configuration, same box, A/B): the step's measurement through LDS
+// (one broadcast ds_read a step ahead instead of two v_readlane: 2.69 against 2.65 ms), the max-ILP scheduling strategy for
+// this kernel once it is unrolled (2.72 against 2.65 ms; the other matrix-core kernels keep it), unrolling by 2 / 3 / 8 / 16
+// (2.70 / 2.70 / 2.65 / 2.68 ms).  What the instruction count alone buys is small -- the same step with 19 fewer vector
+// instructions but the old loop skeleton ran at 2.94 ms, as before: a step is the dependent chain softplus -> rotation ->
+// five matrix instructions -> 1 / S, and what matters is which instructions the scheduler can put into its bubbles.
+// Four steps per loop iteration let one step's trailing work (verdicts, stores, parking) overlap the next step's head.
+constexpr int kEkf4Unroll = 4;
+
+#ifdef CGP_EKF4_KERNELS      // the kernels are instantiated by cgp_inst_ekf4.hip alone; other units take the step functions
 __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3;
@@ -152,6 +189,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
     K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
     K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
+    K.fold();
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     Ekf4State x;
@@ -166,52 +204,63 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
-    const bool p_writer = ((lane >> 2) & 3) == 0;                        // block 0: lanes 16 r + q
-    const unsigned p_off = 8u * (4 * r + q);
+    // Output rows leave through buffer windows: the per-lane byte offset is a CONSTANT (block 0 stores the 16 entries of Pf,
+    // lanes 0..3 the mean; every other lane carries an out-of-range offset and is dropped by the hardware), the step's
+    // row offset t * 128 / t * 32 rides in the instruction's scalar offset -- no vector instruction per step for addressing.
+    const unsigned p_off = (((lane >> 2) & 3) == 0) ? 8u * (4 * r + q) : kOobOffset;
+    const unsigned m_off = (lane < 4) ? 8u * lane : kOobOffset;
 
     SpecRegs R;
     R.init(K.ang);
     // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
-    __shared__ double2 park[64];
+    constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
+    __shared__ double2 park[64 * kParkStride];
     double cum = 0.0;
     int checked_left = 0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        wave_lds_fence();                                                   // the previous chunk's NLL flush has read its slots
+        // 64 measurements with one coalesced 512-B load.  The empty asm consumes the loaded register here, so the compiler's
+        // s_waitcnt vmcnt(0) for it sits in this outer loop and not in front of every step's v_readlane
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         const Ekf4State x0 = x;
-        unsigned uncommon = 0;
+        unsigned long long uncommon = 0;
         if (checked_left == 0) {
             Ekf4Anchor anchor;
             ekf4_anchor(K, x.u2(), anchor);
-            for (int slot = 0; slot < nsteps; slot++) {
+            auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
-                park[slot] = make_double2(S, innov);
+                ekf4_mfma_step_spec1(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
+                park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
-                mfs.store(x.uq, lane < 4 ? t * 32u + 8u * lane : kOobOffset);
+                Pfs.store_s(x.P, p_off, t * 128u);
+                mfs.store_s(x.uq, m_off, t * 32u);
+            };
+            int slot = 0;
+            for (; slot + kEkf4Unroll <= nsteps; slot += kEkf4Unroll) {
+                CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
             }
+            for (; slot < nsteps; slot++) one(slot);
         }
-        const bool redo = __builtin_amdgcn_readfirstlane((int)uncommon) != 0;      // identical in every lane
+        const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
             if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_checked(K, readlane_f64(ychunk, slot), x, S, innov);
-                park[slot] = make_double2(S, innov);
+                park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store(x.P, p_writer ? t * 128u + p_off : kOobOffset);
-                mfs.store(x.uq, lane < 4 ? t * 32u + 8u * lane : kOobOffset);
+                Pfs.store_s(x.P, p_off, t * 128u);
+                mfs.store_s(x.uq, m_off, t * 32u);
             }
             checked_left--;
         }
         if (want_nll) {
             wave_lds_fence();
-            const double2 si = park[lane < nsteps ? lane : 0];
+            const double2 si = park[(lane < nsteps ? lane : 0) * kParkStride];
             cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
-            wave_lds_fence();
         }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
@@ -268,6 +317,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
     K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
     K.kk = (q == 2) ? (r == 2 ? K.M0 : (r == 3 ? K.M1 : 0.0)) : ((q == 3) ? (r == 2 ? K.M2 : (r == 3 ? K.M3 : 0.0)) : 0.0);
+    K.fold();
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     Ekf4State x;
@@ -357,5 +407,7 @@ inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t
         hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
+
+#endif  // CGP_EKF4_KERNELS
 
 }  // namespace cgp
