@@ -43,6 +43,7 @@ struct Ekf4MfmaConst {
     double Hr, Xi, Sig;
     double kc, ks, kj, kk;                     // J[q][r] = kc c + ks s + kk + kj dth f[q ^ 1]  (kj = -1 at (0, 2), +1 at (1, 2))
     double kcr, ksr, kja;                      // kc rho, ks rho, kj ang: the damping and the angle scale ride in the per-lane coefficients
+    double SigHr, SigHq, c0;                   // H = e_1 form of the update: Sigma[r][1], Sigma[1][q], Sigma[1][1] + Xi
     CGP_DEV void fold() { kcr = kc * rho; ksr = ks * rho; kja = kj * ang; }
 };
 // The mean is distributed like the covariance: ur = u[r] (row layout) and uq = u[q] (column layout) at lane (r, q); the
@@ -59,19 +60,41 @@ struct Ekf4State {
 //     mf = f + PH g   one FMA per layout with PH by row / by column (which the covariance update needs anyway)
 // so the per-lane scalar copies of u0..u3 and f0..f3, the quad broadcasts of PH and the FMA chains for f and H . f are
 // gone; the Jacobian column d f / d u2 = dth (-f1, f0) is a quad swap of f by column times a per-lane sign.
+//
+// E1 = true (round 3): the measurement vector is the unit vector e_1 -- every chirp / La Scala model of the reference has
+// H = [0, 1, 0, 0] (models.py:118) -- and the update leaves the dependent chain two matrix instructions earlier.  With
+// a = J^T H = row 1 of J (one quad broadcast of RJT):
+//     P a                       mfma(A = P,   B = a by row)                      in parallel with Q = P J^T
+//     S  = a . (P a) + c0       mfma(A = a,   B = P a, C = Sigma_11 + Xi)         in parallel with Pp = J Q + Sigma
+//     Pp H = J (P a) + Sigma H  mfma(A = RJT, B = P a, C = Sigma[r][1]) by row,  mfma(A = P a, B = RJT, C = Sigma[1][q]) by column
+// -- the same eight matrix instructions (H . f is a quad broadcast of f by column), but S waits for TWO of them behind the
+// Jacobian instead of four (Q, Pp, Pp H, S); Pp itself is only needed by the covariance update at the end of the step.
+template <bool E1 = false>
 CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
     const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
     const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
     const double kjd = K.kja * dsp;
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
-    // ---- predict: Pp = J P J^T + Sigma
-    const double Q = mfma4(x.P, RJT, 0.0);
-    const double Pp = mfma4(RJT, Q, K.Sig);
-    // ---- update (filters_smoothers.py:55-68)
-    const double PHr = mfma4(Pp, K.Hr, 0.0);
-    const double PHq = mfma4(K.Hr, Pp, 0.0);
-    S = mfma4(K.Hr, PHr, K.Xi);
-    innov = y - mfma4(K.Hr, f_r, 0.0);
+    double Pp, PHr, PHq;
+    if constexpr (E1) {
+        const double a = dpp_f64<kQuadBcast1>(RJT);                    // a[r] = J[1][r], the same in the four lanes of a quad
+        const double Pa = mfma4(x.P, a, 0.0);                          // (P a)[r]
+        const double Q = mfma4(x.P, RJT, 0.0);
+        S = mfma4(a, Pa, K.c0);                                        // a . (P a) + Sigma_11 + Xi = H Pp H^T + Xi
+        PHr = mfma4(RJT, Pa, K.SigHr);                                 // (J P a)[r] + Sigma[r][1]
+        PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q]
+        Pp = mfma4(RJT, Q, K.Sig);
+        innov = y - dpp_f64<kQuadBcast1>(f_q);                         // H . f = f[1]
+    } else {
+        // ---- predict: Pp = J P J^T + Sigma
+        const double Q = mfma4(x.P, RJT, 0.0);
+        Pp = mfma4(RJT, Q, K.Sig);
+        // ---- update (filters_smoothers.py:55-68)
+        PHr = mfma4(Pp, K.Hr, 0.0);
+        PHq = mfma4(K.Hr, Pp, 0.0);
+        S = mfma4(K.Hr, PHr, K.Xi);
+        innov = y - mfma4(K.Hr, f_r, 0.0);
+    }
     const double rS = rcp_nr1(S);                               // 2e-15 (one Newton step): two FMAs less on the chain
     x.P = fma(-(PHr * rS), PHq, Pp);                            // Pf = Pp - K (Pp H)^T
     const double g = rS * innov;
@@ -80,13 +103,14 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
 }
 
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
+template <bool E1 = false>
 CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
     softplus_pair_uniform(x.u2(), sp, dsp);
     // theta = dt 2 pi g(u2) fs as ONE multiply by the constant dt 2 pi fs (the reference rounds three times,
     // models.py:296-297: a relative 1e-16 on an angle of ~0.05 rad)
     fast_sincos_uniform(K.ang * sp, s1, c1);
-    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+    ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
 
 // The speculative step.  Softplus: t = exp(-u2), then theta = ang (u2 + t q(t)) with the lean degree-7 polynomials of
@@ -137,6 +161,7 @@ CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, doub
 //     values fall outside [1.5, 700) as unsigned offsets) and one |d| compare, each a v_cmp into a scalar register pair ORed
 //     into a 64-bit scalar accumulator -- three vector instructions instead of six, and the chunk's verdict is a scalar
 //     compare (no readfirstlane).
+template <bool E1>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                   double& innov, unsigned long long* uncommon) {
     const double u2 = x.u2();
@@ -152,7 +177,7 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
     const unsigned hx = (unsigned)__double2hiint(u2) - 0x3FF80000u;                  // 1.5 -> 0, 700 -> 0x008DDFFF
     *uncommon |= __builtin_amdgcn_ballot_w64(hx > 0x008DDFFFu) | __builtin_amdgcn_ballot_w64(!(fabs(d) <= 0x1p-7));
     a.th += d; a.c1 = c1; a.s1 = s1;
-    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+    ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
 
 // Tried with it and dropped (all measured on the bench configuration, same box, A/B): the step's measurement through LDS
@@ -165,11 +190,11 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
 constexpr int kEkf4Unroll = 4;
 
 #ifdef CGP_EKF4_KERNELS      // the kernels are instantiated by cgp_inst_ekf4.hip alone; other units take the step functions
-__global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
+template <bool E1>
+CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3;
     const int64_t trial = blockIdx.x;
-    if (trial >= io.B) return;
 
     HarmonicLCD<1> model;
     model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
@@ -184,6 +209,9 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
     K.Sig = 0.0;
     if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
     else if (r + q == 5) K.Sig = model.MS[1];
+    K.SigHr = (r == 1) ? model.q : 0.0;                                 // Sigma[r][1]: the chirp block of Sigma is q I
+    K.SigHq = (q == 1) ? model.q : 0.0;
+    K.c0 = model.q + K.Xi;
     // J = [c -s jv0 0; s c jv1 0; 0 0 M0 M1; 0 0 M2 M3], this lane holds J[q][r]
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
@@ -232,7 +260,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
             ekf4_anchor(K, x.u2(), anchor);
             auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec1(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1>(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_off, t * 128u);
@@ -249,7 +277,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
             if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step_checked(K, readlane_f64(ychunk, slot), x, S, innov);
+                ekf4_mfma_step_checked<E1>(K, readlane_f64(ychunk, slot), x, S, innov);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_off, t * 128u);
@@ -264,6 +292,17 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
         }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+
+__global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+    // the measurement vector of every chirp / La Scala builder is e_1 (models.py:118): the short-chain form of the update;
+    // any other H (the API takes one per trial) runs the general form -- a wave-uniform choice
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;
+    if (e1) ekf4_mfma_trial<true>(io, ma);
+    else ekf4_mfma_trial<false>(io, ma);
 }
 
 

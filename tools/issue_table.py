@@ -19,7 +19,7 @@ def main(dirs):
         units = bench['config']['batch_per_gpu'] * bench['config']['T']
         roles = {}
         for name, c in pmc.items():
-            role = 'smoother' if 'smooth' in name or 'eks' in name or 'sgps' in name.lower() else 'filter'
+            role = 'smoother' if 'smooth' in name or 'eks' in name or 'sgps' in name.lower() or 'split_kernel' in name else 'filter'
             g = lambda k: c.get(k, {}).get('mean', 0.0) / units
             roles[role] = {'kernel': name, 'valu': g('SQ_INSTS_VALU'), 'salu': g('SQ_INSTS_SALU'), 'lds': g('SQ_INSTS_LDS'),
                            'fma_f64': g('SQ_INSTS_VALU_FMA_F64'), 'mul_f64': g('SQ_INSTS_VALU_MUL_F64'), 'add_f64': g('SQ_INSTS_VALU_ADD_F64'),

@@ -12,16 +12,16 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
-python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.log"
+python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench.json" 2> "$OUT/bench.log"
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
              "GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $group -d "$OUT/pmc_$i" -o pmc --output-format csv -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$i.log" || echo "pmc pass $i ($group) FAILED"
+    rocprofv3 --pmc $group -d "$OUT/pmc_$i" -o pmc --output-format csv -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2> "$OUT/pmc_$i.log" || echo "pmc pass $i ($group) FAILED"
     echo "pmc pass $i done"
 done
 python tools/parse_pmc.py "$OUT" > "$OUT/pmc.json"
