@@ -187,6 +187,10 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
 // instructions but the old loop skeleton ran at 2.94 ms, as before: a step is the dependent chain softplus -> rotation ->
 // five matrix instructions -> 1 / S, and what matters is which instructions the scheduler can put into its bubbles.
 // Four steps per loop iteration let one step's trailing work (verdicts, stores, parking) overlap the next step's head.
+// Two chain-shortening variants measured SLOWER on top of the final kernel (2.57 ms): the rotation entries of the Jacobian as
+// a quartic in the angle increment with per-lane coefficients from the previous rotation pair (four dependent operations
+// fewer, nine instructions more: 2.77 ms), and the exponent argument -log2(e) u[2] formed beside the mean update instead of
+// behind its quad broadcast (two operations fewer, six instructions more: 2.73 ms).
 constexpr int kEkf4Unroll = 4;
 
 #ifdef CGP_EKF4_KERNELS      // the kernels are instantiated by cgp_inst_ekf4.hip alone; other units take the step functions
