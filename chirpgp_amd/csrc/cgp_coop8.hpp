@@ -31,6 +31,7 @@
 //     reciprocal of a pivot is 3 dependent instructions, a square root 7); a non-positive pivot poisons the step with
 //     NaN like the reference's Cholesky does.
 #pragma once
+#include <atomic>
 #include "cgp_coop4.hpp"
 
 namespace cgp {
@@ -727,8 +728,17 @@ inline hipError_t launch_coop8_smoother(const SmootherIO& io_in, const ModelArgs
     if (io_in.B <= 0 || io_in.T <= 0) return hipSuccess;
     if (io_in.T * Elem::D * Elem::D * 8 > kOobMaxBytes) return hipErrorInvalidValue;      // 2 GiB buffer windows (callers check coop8_smoother_ok)
     const size_t dyn = Elem::USES_SIGMA ? sigma_lds_bytes(ma, Elem::D) : 0;
+    // workgroups of the split kernel a CU holds (registers, LDS): asked once per kernel and dynamic-LDS size, then remembered
+    static std::atomic<long long> occ_cache{-1};                           // (dyn << 8) | per_cu
     int per_cu = 0;
-    if (io_in.segs != 1 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, coop8_split_kernel<Elem, kWalkApply>, 64, dyn) != hipSuccess) per_cu = 4;
+    if (io_in.segs != 1) {
+        const long long seen = occ_cache.load(std::memory_order_relaxed);
+        if (seen >= 0 && (size_t)(seen >> 8) == dyn) per_cu = (int)(seen & 0xFF);
+        else {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, coop8_split_kernel<Elem, kWalkApply>, 64, dyn) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+            occ_cache.store(((long long)dyn << 8) | (per_cu & 0xFF), std::memory_order_relaxed);
+        }
+    }
     const int segs = walk_segments(io_in, per_cu);
     if (segs <= 1) {
         hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
@@ -742,7 +752,11 @@ inline hipError_t launch_coop8_smoother(const SmootherIO& io_in, const ModelArgs
     io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
     void* ws = nullptr;
     hipError_t e = hipMallocAsync(&ws, sizeof(double) * kMap8Doubles * (size_t)io.B * io.segs, stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {               // no stream-ordered allocator here: the one-wave-per-trial form needs no scratch
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+        return hipGetLastError();
+    }
     io.ws = (double*)ws;
     const unsigned grid = (unsigned)(io.B * io.segs);
     hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
