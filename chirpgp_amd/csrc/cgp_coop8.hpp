@@ -430,8 +430,10 @@ inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t
 // two 8 x 8 x 8 products = four v_mfma_f64_4x4x4 (the G operands come from LDS already arranged per block, the carry is
 // re-arranged between blocks with bank-masked DPP moves).  Two record forms:
 //   * one wavefront per trial (coop8_smoother_kernel): records (G, Pp, mp); the walk does X = Ps' - Pp, W = X G^T,
-//     Ps = G W + Pf, ms = G (ms' - mp) + mf with (Pf, mf) of its step read a SECOND time from the input arrays, requested a
-//     batch of eight steps ahead (1.5 x the algorithmic traffic, but the kernel is bound by the lanes' vector work, not by HBM);
+//     Ps = G W + Pf, ms = G (ms' - mp) + mf.  Round 2 read (Pf, mf) of a step a SECOND time from the input arrays (1.5 x the
+//     algorithmic traffic); round 3: every lane parks its filtering row in LDS when it loads it for the gain (44 doubles a
+//     step, 23 KB a tile; the records go in quarters of 16 to make room) and the walk takes it from there -- every row is read
+//     from HBM ONCE;
 //   * the affine form (coop8_split_kernel): records (G, C, c) with the step's constants folded by the lanes that build the
 //     gains, so the walk reads nothing from HBM and has no subtraction on its chain -- every filtering row is read ONCE.  As
 //     the whole-record kernel it measured SLOWER (BASELINE C5's smoother 5.11 against 4.75 ms, EKS 3.9 against 3.5: the 860
@@ -463,14 +465,17 @@ inline int walk_segments(const SmootherIO& io, int blocks_per_cu) {
     return segs < 2 ? 1 : (int)segs;
 }
 
-// ---- one wavefront per trial: records (G, Pp, mp), the walk reads (Pf, mf) of its step from the input arrays
-struct Elem8WalkOperands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc; };
+// ---- one wavefront per trial: records (G, Pp, mp) in quarters of 16, the tile's filtering rows (Pf, mf) parked beside them
+constexpr int kRowDoubles = 45;                   // Pf (packed lower, 36) | mf (8) | one zero; odd: conflict-free lane stride
+constexpr int kRowmf = 36, kRowZero = 44;
+struct Elem8WalkOperands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc, Pfv, mfr; };
 
 template <class Elem>
 __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {      // one wavefront per trial, the whole record
     constexpr int D = Elem::D;
     static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
-    __shared__ double elems[32 * kElemDoubles];
+    __shared__ double elems[16 * kElemDoubles];      // (G, Pp, mp) of a quarter tile: 13.9 KB
+    __shared__ double rows[64 * kRowDoubles];        // (Pf, mf) of the whole tile: 23.0 KB -- together 36.9 KB: four workgroups a CU
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -480,7 +485,8 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
 
     Elem elem;
     elem.setup(ma, trial);
-    for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / Pp and the zero slot stay zero
+    for (int k = lane; k < 16 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / Pp / Pf and the zero slots stay zero
+    for (int k = lane; k < 64 * kRowDoubles; k += 64) rows[k] = 0.0;
     if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
@@ -490,21 +496,20 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     const bool entry = i < D && j < D;
     const bool mean_lane = (J == 0 && q == 0 && i < D);
 
-    // per-lane offsets (doubles) of the operands of one step inside its LDS record, and inside the input rows
+    // per-lane offsets (doubles) of the operands of one step inside its LDS record and inside its parked row
     const int oA = (4 * I + q) * 8 + r;              // G[4 I + q'][4 K + r'] at + 4 K
     const int oB = (4 * J + q) * 8 + r;              // G[4 J + q'][4 K + r'] at + 4 K
     const int oM = (4 * I + q) * 8 + 4 * J + r;      // G[4 I + q'][4 J + r']
     const int oP = entry ? kElemC + Sym<8>::idx(i, j) : kElemZero;
     const int om = (4 * J + r < D) ? kElemc + 4 * J + r : kElemZero;          // mp[4 J + r]
-    // The walk addresses the input and output rows through buffer windows with per-lane byte offsets: a lane that has
-    // nothing to read or write carries an out-of-range offset (reads 0 / is dropped), so no load or store sits behind an
-    // exec-mask branch and the compiler can count them: it waits for the prefetched loads only, not for the stores behind them.
-    const unsigned bP = entry ? 8u * (unsigned)((i >= j) ? i * D + j : j * D + i) : kOobOffset;      // lower triangle of Pf, like the other kernels
+    const int oPf = entry ? Sym<8>::idx(i, j) : kRowZero;                      // Pf[i][j] (from its lower triangle, like the other kernels)
+    const int omf = (i < D) ? kRowmf + i : kRowZero;                           // mf[4 I + r]
+    // The output rows leave through buffer windows with per-lane byte offsets: a lane that has nothing to write carries an
+    // out-of-range offset (dropped), so no store sits behind an exec-mask branch.
     const unsigned bS = entry ? 8u * (unsigned)(i * D + j) : kOobOffset;
-    const unsigned bmr = (i < D) ? 8u * (unsigned)i : kOobOffset;                                    // mf[4 I + r]
     const unsigned bms = mean_lane ? 8u * (unsigned)i : kOobOffset;
-    OobWindow wPf, wmf, wPs, wms;
-    wPf.init(Pfs, T * D * D * 8); wmf.init(mfs, T * D * 8); wPs.init(Pss, T * D * D * 8); wms.init(mss, T * D * 8);
+    OobWindow wPs, wms;
+    wPs.init(Pss, T * D * D * 8); wms.init(mss, T * D * 8);
 
     // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
     double Ps = entry ? Pfs[(T - 1) * D * D + ((i >= j) ? i * D + j : j * D + i)] : 0.0;
@@ -514,70 +519,63 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
 
     for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
         const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
-        // ---- every lane: prediction and gain of its own step
+        // ---- every lane: its filtering row -- parked in LDS for the walk, which round 2 had read a SECOND time from HBM
+        // (1.5 x the algorithmic traffic of BASELINE C5's smoother) -- then prediction and gain of its own step
         const int64_t mystep = base + lane;
         Mat<D> G; Vec<D> mp; Sym<D> Pp;
-        if (mystep >= 0) {
-            Vec<D> mf; Sym<D> Pf;
-            load_vec<D>(mfs + mystep * D, mf);
-            load_sym<D>(Pfs + mystep * D * D, Pf);
-            elem.gain(mf, Pf, G, mp, Pp);
-        } else {
-            CGP_UNROLL for (int a = 0; a < D; a++) { mp.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < D; c++) G.a[a][c] = 0.0; }
-            CGP_UNROLL for (int a = 0; a < Sym<D>::N; a++) Pp.a[a] = 0.0;
+        {
+            double* mine = rows + lane * kRowDoubles;
+            if (mystep >= 0) {
+                Vec<D> mf; Sym<D> Pf;
+                load_vec<D>(mfs + mystep * D, mf);
+                load_sym<D>(Pfs + mystep * D * D, Pf);
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[Sym<8>::idx(a, c)] = Pf(a, c);
+                CGP_UNROLL for (int a = 0; a < D; a++) mine[kRowmf + a] = mf.v[a];
+                elem.gain(mf, Pf, G, mp, Pp);
+            } else {                                                       // before the start of the record: a zero row and a zero record
+                CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[Sym<8>::idx(a, c)] = 0.0;
+                CGP_UNROLL for (int a = 0; a < D; a++) { mine[kRowmf + a] = 0.0; mp.v[a] = 0.0; CGP_UNROLL for (int c = 0; c < D; c++) G.a[a][c] = 0.0; }
+                CGP_UNROLL for (int a = 0; a < Sym<D>::N; a++) Pp.a[a] = 0.0;
+            }
         }
-        // The records go to LDS in two halves of 32 (27.9 KB: four workgroups -- one per SIMD -- fit a CU; all 64 at once would
-        // be 55.8 KB, two workgroups per CU, and a batch of 1000 trials would run in two rounds): lanes 32..63, the later
-        // steps, first; lanes 0..31 keep theirs in registers until the first half has been walked.
-        CGP_UNROLL for (int half = 1; half >= 0; half--) {
-            if ((lane >> 5) == half) {
-                double* mine = elems + (lane & 31) * kElemDoubles;
+        // The records go to LDS in four quarters of 16 (13.9 KB): lanes 48..63, the latest steps, first; the other lanes keep
+        // theirs in registers until their quarter has its turn.
+        CGP_UNROLL for (int quarter = 3; quarter >= 0; quarter--) {
+            if ((lane >> 4) == quarter) {
+                double* mine = elems + (lane & 15) * kElemDoubles;
                 CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c < D; c++) mine[a * 8 + c] = G.a[a][c];
                 CGP_UNROLL for (int a = 0; a < D; a++) CGP_UNROLL for (int c = 0; c <= a; c++) mine[kElemC + Sym<8>::idx(a, c)] = Pp(a, c);
                 CGP_UNROLL for (int a = 0; a < D; a++) mine[kElemc + a] = mp.v[a];
             }
             wave_lds_fence();
-            // ---- the wavefront walks the half from its last step to its first, in four batches of eight steps.  The
-            // filtering rows (Pf, mf) of a batch are requested one batch ahead -- by then the lines a lane read for its own
-            // gain have long left L2, and a miss costs three walk steps -- the LDS operands one step ahead.  Steps before the
-            // start of the record (last tile) are walked too: their loads return 0 and their stores are dropped.
+            // ---- the wavefront walks the quarter from its last step to its first, the LDS operands one step ahead.  Steps
+            // before the start of the record (last tile) are walked too: their records and rows are zero and their stores
+            // fall outside the windows (the step index wraps).
             auto fetch = [&](int s, Elem8WalkOperands& o) {
-                const double* p = elems + (s & 31) * kElemDoubles;
+                const double* p = elems + (s & 15) * kElemDoubles;
+                const double* w = rows + (s & 63) * kRowDoubles;
                 o.gA0 = p[oA]; o.gA1 = p[oA + 4]; o.gB0 = p[oB]; o.gB1 = p[oB + 4]; o.gM = p[oM]; o.Ppv = p[oP]; o.mpc = p[om];
+                o.Pfv = w[oPf]; o.mfr = w[omf];
             };
-            auto request = [&](int s_top, double (&pf)[8], double (&mf)[8]) {
-                CGP_UNROLL for (int u = 0; u < 8; u++) {
-                    const unsigned step = (unsigned)(base + (s_top - u));
-                    pf[u] = wPf.load(bP + step * (unsigned)(D * D * 8));
-                    mf[u] = wmf.load(bmr + step * (unsigned)(D * 8));
-                }
-            };
-            double pf_cur[8], mf_cur[8], pf_nxt[8], mf_nxt[8];
-            request(32 * half + 31, pf_cur, mf_cur);
             Elem8WalkOperands cur, nxt;
-            fetch(32 * half + 31, cur);
-#pragma unroll 1
-            for (int batch = 0; batch < 4; batch++) {
-                const int s_top = 32 * half + 31 - 8 * batch;
-                if (batch < 3) request(s_top - 8, pf_nxt, mf_nxt);
-                CGP_UNROLL for (int u = 0; u < 8; u++) {
-                    const int s = s_top - u;
-                    fetch((s - 1) & 31, nxt);                                  // (the record fetched after the half's last step is not used)
-                    // W = (Ps' - Pp) G^T
-                    const double X = Ps - cur.Ppv;
-                    const double W = mfma4x4(blk_rows_of_k1(X), cur.gB1, mfma4x4(blk_rows_of_k0(X), cur.gB0, 0.0));
-                    // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] (ms' - mp)[4 J + k] + mf
-                    double ym = mfma4x4(cur.gM, xc - cur.mpc, 0.0);
-                    ym = (ym + blk_xor1(ym)) + mf_cur[u];
-                    // Ps = G W + Pf
-                    Ps = mfma4x4(cur.gA1, blk_cols_of_k1(W), mfma4x4(cur.gA0, blk_cols_of_k0(W), pf_cur[u]));
-                    xc = blk_swap12(ym);
-                    const unsigned step = (unsigned)(base + s);
-                    wPs.store(Ps, bS + step * (unsigned)(D * D * 8));
-                    wms.store(ym, bms + step * (unsigned)(D * 8));
-                    cur = nxt;
-                }
-                CGP_UNROLL for (int u = 0; u < 8; u++) { pf_cur[u] = pf_nxt[u]; mf_cur[u] = mf_nxt[u]; }
+            fetch(16 * quarter + 15, cur);
+#pragma unroll 8
+            for (int u = 0; u < 16; u++) {
+                const int s = 16 * quarter + 15 - u;
+                fetch(16 * quarter + ((s - 1) & 15), nxt);                 // (the record fetched after the quarter's last step is not used)
+                // W = (Ps' - Pp) G^T
+                const double X = Ps - cur.Ppv;
+                const double W = mfma4x4(blk_rows_of_k1(X), cur.gB1, mfma4x4(blk_rows_of_k0(X), cur.gB0, 0.0));
+                // mean: ym[4 I + r] = sum_J sum_k G[4 I + r][4 J + k] (ms' - mp)[4 J + k] + mf
+                double ym = mfma4x4(cur.gM, xc - cur.mpc, 0.0);
+                ym = (ym + blk_xor1(ym)) + cur.mfr;
+                // Ps = G W + Pf
+                Ps = mfma4x4(cur.gA1, blk_cols_of_k1(W), mfma4x4(cur.gA0, blk_cols_of_k0(W), cur.Pfv));
+                xc = blk_swap12(ym);
+                const unsigned step = (unsigned)(base + s);
+                wPs.store(Ps, bS + step * (unsigned)(D * D * 8));
+                wms.store(ym, bms + step * (unsigned)(D * 8));
+                cur = nxt;
             }
             wave_lds_fence();
         }

@@ -21,11 +21,12 @@ int dispatch_filter_coop8_ekf(int n_harm, const FilterIO& io, const ModelArgs& m
     default: return CGP_E_UNSUPPORTED;
     }
 }
-// The cooperative smoother keeps 32 affine maps in 27.9 KB of static LDS; with the staged sigma-point set beside it a
-// workgroup must stay within 40 KB so that four of them (one per SIMD) share a CU's 160 KB (every cubature rule fits;
-// larger sets take the lane-scan kernel).
+// The cooperative smoother keeps 16 step records and the tile's 64 filtering rows in 36.9 KB of static LDS (the split kernel:
+// 32 records, 27.9 KB); with the staged sigma-point set beside it a workgroup must stay within 40 KB so that four of them
+// (one per SIMD) share a CU's 160 KB (every cubature rule fits; larger sets take the lane-scan kernel).
 bool coop8_smoother_ok(int d, int64_t T, const ModelArgs& ma) {
-    return d >= 5 && d <= 8 && T * d * d * 8 <= kOobMaxBytes && sigma_lds_bytes(ma, d) + sizeof(double) * 32 * kElemDoubles + 64 <= 40 * 1024;
+    return d >= 5 && d <= 8 && T * d * d * 8 <= kOobMaxBytes &&
+           sigma_lds_bytes(ma, d) + sizeof(double) * (16 * kElemDoubles + 64 * kRowDoubles) + 64 <= 40 * 1024;
 }
 int dispatch_smoother_coop8_linear(int method, int d, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
     if (method != CGP_S_EKS && method != CGP_S_SGP) return CGP_E_UNSUPPORTED;
