@@ -142,10 +142,6 @@ def dev(x, device=None):
 _const_cache = {}
 
 
-def torch_index(idx, like):
-    """NumPy integer index -> int64 tensor on `like`'s device."""
-    return _torch().as_tensor(np.asarray(idx, dtype=np.int64), device=like.device)
-
 # Optional timing hook used by bench.py: when set to a list, every kernel launch appends
 # (name, start_event, end_event), the events recorded on the launch stream immediately around the C-ABI call.
 kernel_events = None
@@ -178,6 +174,21 @@ def dev_const(x):
         if len(_const_cache) >= 512:
             _const_cache.clear()
         t = _const_cache[key] = dev(a)
+    return t
+
+
+def _index_const(a):
+    """Device copy of a small int32 index array, cached by value like dev_const (a lock-step line search passes the same
+    few index sets again and again; an uncached pageable upload would serialise the host behind the previous kernel)."""
+    torch = _torch()
+    if a.size > 65536:
+        return torch.from_numpy(a).cuda()
+    key = (torch.cuda.current_device(), 'i32', a.shape, a.tobytes())
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) >= 512:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.from_numpy(a).cuda()
     return t
 
 
@@ -315,7 +326,7 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         keep = [ys_d]
         idx_d = None
         if idx_h is not None:
-            idx_d = torch.from_numpy(idx_h.astype(np.int32)).to(ys_d.device)
+            idx_d = _index_const(idx_h.astype(np.int32))
             keep.append(idx_d)
         model = _model_struct(spec, gamma, B, keep)
         sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))

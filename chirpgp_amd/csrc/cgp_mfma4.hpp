@@ -117,7 +117,7 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // cgp_fastmath.hpp (ang rides in q's coefficients), valid for u2 >= 1.5.  Rotation: (cos, sin)(theta) is advanced
 // INCREMENTALLY from the previous step's,
 //     (cos, sin)(theta) = rotation of (cos, sin)(theta_prev) by d = theta - theta_prev,
-// with sin d, cos d to d^5 / d^6 (remainders < 4e-19 while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
+// with sin d, cos d to d^3 / d^4 (remainders < 2.4e-13 d while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
 // fresh sincos.  d is formed as ang q t + (ang u2 - theta_prev), whose second term does not wait for the polynomials; what
 // accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
 // of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| > 2^-7 (or NaN) sets
@@ -131,30 +131,8 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
     fast_sincos_uniform(a.th, a.s1, a.c1);
 }
 
-CGP_DEV void ekf4_mfma_step_spec(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
-                                 double& innov, unsigned* uncommon) {
-    const double u2 = x.u2();
-    const double t = exp_neg_lean(R, u2);
-    const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
-    double qa, dsp;
-    softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
-    const double d = fma(qa, t, lin);
-    const double d2 = d * d, d4 = d2 * d2;
-    const double sd = fma(d * d2, horner(R.s5, d2, R.s3), d);                        // d - d^3/6 + d^5/120
-    const double cd = fma(d4, horner(R.c6, d2, R.c4), fma(-0.5, d2, 1.0));           // 1 - d^2/2 + d^4/24 - d^6/720
-    const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
-    // verdicts without compares, scalar registers or branches: clamp the high words into their admissible ranges and
-    // OR the bits the clamp changed into a vector accumulator (non-zero = some step left the regime; NaN, inf and
-    // negative u2 fall outside the signed range [1.5, 700), NaN / inf angles above the magnitude bound)
-    const int hx = __double2hiint(u2);
-    const unsigned hd = (unsigned)__double2hiint(d) & 0x7fffffffu;
-    *uncommon |= (unsigned)(hx ^ max(0x3FF80000, min(hx, 0x4085DFFF))) | (hd ^ min(hd, 0x3F7FFFFFu));
-    a.th += d; a.c1 = c1; a.s1 = s1;
-    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
-}
-
-// The one-trial-per-wave kernel's form of the speculative step (round 3), five vector instructions shorter:
-//   * the increment's sine and cosine to d^3 / d^4 only: while |d| <= 2^-7 the dropped terms are below d^5 / 120 = 2.4e-13
+// Round 3 made the step five vector instructions shorter:
+//   * the increment's sine and cosine to d^3 / d^4 only (round 2: d^5 / d^6): while |d| <= 2^-7 the dropped terms are below d^5 / 120 = 2.4e-13
 //     relative and d^6 / 720 = 3e-16 (the bench records' largest increment, 2.7e-3, gives 1.2e-15), and the pair is re-anchored
 //     every 64 steps;
 //   * the regime verdicts as WAVE MASKS: one integer range compare of u2's high word (NaN, inf, negative and out-of-range
@@ -320,11 +298,12 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 // the anchor use the per-lane softplus / sincos, and the output windows span the wave's four consecutive trials.
 // One lane per trial needs T x 1.3 us whatever the batch (its step is a 500-instruction dependent chain); this
 // kernel needs T x 0.4 us per 4096 trials.
+template <bool E1 = false>
 CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
     softplus_pair_wide(x.u2(), sp, dsp);
     fast_sincos(K.ang * sp, s1, c1);
-    ekf4_mfma_finish(K, y, c1, s1, dsp, x, S, innov);
+    ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
 CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
     double sp, dsp;
@@ -336,12 +315,11 @@ CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) 
 // DENSE = false: constants pinned, 297 registers, one wave per SIMD (the dispatcher then has to spread the waves over all
 // SIMDs: best up to 4096 trials).  DENSE = true: constants left to the compiler, 234 registers, two waves per SIMD
 // (beyond 4096 trials, where waves have to share SIMDs anyway: 8 - 14 % faster there, 50 % slower below).
-template <bool DENSE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENSE ? 2 : 1))) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs ma) {
+template <bool DENSE, bool E1>
+CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3, b = (lane >> 2) & 3;
     const int64_t first = (int64_t)blockIdx.x * 4;
-    if (first >= io.B) return;
     const int ntr = (io.B - first < 4) ? (int)(io.B - first) : 4;          // trials of this wave
     const int64_t trial = first + (b < ntr ? b : ntr - 1);                 // blocks past the batch redo the last trial
 
@@ -357,6 +335,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     K.Sig = 0.0;
     if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
     else if (r + q == 5) K.Sig = model.MS[1];
+    K.SigHr = (r == 1) ? model.q : 0.0;
+    K.SigHq = (q == 1) ? model.q : 0.0;
+    K.c0 = model.q + K.Xi;
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
     K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
@@ -393,29 +374,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
         }
         wave_lds_fence();
         const Ekf4State x0 = x;
-        unsigned uncommon = 0;
+        unsigned long long uncommon = 0;                         // the verdicts of the four trials, pooled: a wave mask
         if (checked_left == 0) {
             Ekf4Anchor anchor;
             ekf4_anchor_lane(K, x.u2(), anchor);
-            for (int slot = 0; slot < nsteps; slot++) {
+            auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1>(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store(x.P, p_base + t * 128u);
-                mfs.store(x.uq, m_base + t * 32u);               // kOobOffset + t * 32 stays out of range (windows < 2 GiB)
+                Pfs.store_s(x.P, p_base, t * 128u);              // the step's row offset rides in the scalar offset
+                mfs.store_s(x.uq, m_base, t * 32u);
+            };
+            int slot = 0;
+            for (; slot + kEkf4Unroll <= nsteps; slot += kEkf4Unroll) {
+                CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
             }
+            for (; slot < nsteps; slot++) one(slot);
         }
-        const bool redo = __builtin_amdgcn_ballot_w64(uncommon != 0) != 0;
+        const bool redo = uncommon != 0;
         if (checked_left > 0 || redo) {
             if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step_checked_lane(K, ych[b][slot], x, S, innov);
+                ekf4_mfma_step_checked_lane<E1>(K, ych[b][slot], x, S, innov);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store(x.P, p_base + t * 128u);
-                mfs.store(x.uq, m_base + t * 32u);
+                Pfs.store_s(x.P, p_base, t * 128u);
+                mfs.store_s(x.uq, m_base, t * 32u);
             }
             checked_left--;
         }
@@ -431,6 +417,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
     if (lane == 0 && io.nll && nll_final) {
         CGP_UNROLL for (int bb = 0; bb < 4; bb++) if (bb < ntr) io.nll[first + bb] = cum[bb];
     }
+}
+
+template <bool DENSE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENSE ? 2 : 1))) ekf4_mfma_x4_kernel(FilterIO io, ModelArgs ma) {
+    const int64_t first = (int64_t)blockIdx.x * 4;
+    if (first >= io.B) return;
+    // the H = e_1 form of the update when all four trials of the wave have it (a wave-uniform choice)
+    const int bq = (threadIdx.x >> 2) & 3;
+    const int ntr0 = (io.B - first < 4) ? (int)(io.B - first) : 4;
+    const double* __restrict__ Hp = io.H + (first + (bq < ntr0 ? bq : ntr0 - 1)) * io.H_stride;
+    const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;
+    if (__builtin_amdgcn_ballot_w64(!e1) == 0) ekf4_mfma_x4_trials<DENSE, true>(io, ma);
+    else ekf4_mfma_x4_trials<DENSE, false>(io, ma);
 }
 
 // 4 T x 128 bytes of covariance rows must fit the 2 GiB window of a wave
