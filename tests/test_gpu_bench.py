@@ -72,3 +72,17 @@ def test_default_line_carries_the_other_baseline_configs():
         assert oc[tag]['filter_ms'] > 0 and oc[tag]['smoother_ms'] > 0
         if rf['frac'] is not None:
             assert rf['algorithmic_frac'] <= rf['frac'] * 1.05       # useful work cannot exceed what was executed
+
+
+def test_two_rank_rehearsal_of_the_default_line():
+    """The driver's N > 1 command in rehearsal (two ranks on the one GPU, gloo collectives): the default shapes, so the ranks go
+    through `other_configs` (C3 / C5 sharded 500 + 500, C4 and C1 per rank), the strong C2 figure, the final gathers, and rank 0
+    times the host CPU AFTER the process group is gone -- the control flow a multi-GPU node will run, which no other test reaches."""
+    r = _run('--gpus', '2', '--rehearse', '--steps', '2', '--warmup', '1', '--other-steps', '1')
+    assert r['n_gpus'] == 2 and r['ranks_seen'] == 2 and r['collectives'].startswith('gloo')
+    assert r['config']['batch_per_gpu'] == 1000 and r['config']['global_batch'] == 2000 and r['strong']['batch_per_gpu'] == 500
+    oc = r['other_configs']
+    assert oc['C3']['batch_per_gpu'] == 500 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 500
+    assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 1024 and oc['C1']['global_batch'] == 2
+    assert all(v['value'] > 0 and v['filter_ms'] > 0 for v in oc.values())
+    assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0
