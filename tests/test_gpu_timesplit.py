@@ -114,6 +114,44 @@ def test_d6_d8_smoothers_time_split(nh, method):
         cs.assert_close(g, o, 1e-10, f'd{2 * nh + 2} {method} split vs whole {n}')
 
 
+@pytest.mark.parametrize('d', [5, 7])
+def test_odd_dimensions_time_split(d):
+    """`rts` at d = 5 and 7: the tile layout's padded rows / columns of the composed maps (and of the workspace records) stay zero."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from oracle import port
+    T, B = 1300, 3
+    rng = np.random.default_rng(d)
+    F = np.eye(d) * 0.98 + 0.02 * rng.standard_normal((d, d))
+    Sigma = np.eye(d) * 0.02
+    H = rng.standard_normal(d)
+    lin = pm.linear_cond_m_cov(F, Sigma)
+    ys = rng.standard_normal((B, T))
+    f = port.filter(port.F_EKF, lin, None, H, 0.1, np.zeros(d), np.eye(d), 0., ys)
+    want = port.smoother(port.S_EKS, lin, None, 0., f[0], f[1])
+    got = fs.rts(F, Sigma, f[0], f[1], **SPLIT)
+    whole = fs.rts(F, Sigma, f[0], f[1], **WHOLE)
+    for g, w, o, n in zip(got, want, whole, ('mss', 'Pss')):
+        cs.assert_close(g, w, 1e-9, f'rts d={d} split {n}')
+        cs.assert_close(g, o, 1e-11, f'rts d={d} split vs whole {n}')
+
+
+@pytest.mark.parametrize('kind', ['sgp', 'harmonic'])
+def test_sigma_point_smoothers_at_the_eight_gpu_shard_size(kind):
+    """BASELINE C3 / C5 sharded over 8 GPUs: 125 trials x 10 000 steps.  The default launch (time-split) against the
+    one-wave-per-trial form of the same kernels on the engine's own filtering results."""
+    import torch
+    import bench
+    from chirpgp_amd import filters_smoothers as fs
+    wl = bench.make_workload(125, 10000, kind=kind)
+    ys = torch.from_numpy(wl['ys']).cuda()
+    f = fs.sgp_filter(wl['disc'], wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys)
+    auto = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'])
+    whole = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'], flags=NO_TIME_SPLIT)
+    for a, b in zip(auto, whole):
+        cs.assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-10, f'{kind} auto vs whole')
+    assert torch.isfinite(auto[0]).all()
+
+
 def test_small_batch_takes_the_time_split_form_by_default_and_is_faster():
     """B = 125, T = 10 000 (BASELINE C3's shard on one of 8 GPUs): the default call is the time-split form -- same results as the
     whole-record walk to rounding, and at least twice as fast (measured ~4x; the bound is loose on purpose)."""
