@@ -4,8 +4,9 @@ namespace cgp {
 template <int NH>
 static int kpt(bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     using DM = LinearDisc<NH + 2>;
-    return hip_rc(wave ? launch_filter<EkfPredict<DM, true>, KptUpdate<NH>>(io, ma, st)
-                       : launch_filter<EkfPredict<DM, false>, KptUpdate<NH>>(io, ma, st));
+    // one wavefront per trial: the measurement's softplus / sincos in their wave-uniform forms
+    return hip_rc(wave ? launch_filter<EkfPredict<DM, true>, KptUpdate<NH, true>>(io, ma, st)
+                       : launch_filter<EkfPredict<DM, false>, KptUpdate<NH, false>>(io, ma, st));
 }
 int dispatch_filter_kpt(int key, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     switch (key) {

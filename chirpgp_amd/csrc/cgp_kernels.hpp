@@ -71,12 +71,12 @@ template <int D> struct LinearMeasurement {
     }
 };
 // ekf_for_kpt (filters_smoothers.py:298-311): H = grad h(mp), pred = h(mp).
-template <int NH> struct KptUpdate {
+template <int NH, bool UNIFORM = false> struct KptUpdate {
     static constexpr int D = NH + 2;
     CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>&, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
                                double& S, double& innov) {
         Vec<D> H;
-        const double pred = KptMeasurement<NH>::eval(mp, H);
+        const double pred = KptMeasurement<NH, UNIFORM>::eval(mp, H);
         scalar_update<D>(mp, Pp, H, Xi, y, true, pred, mf, Pf, S, innov);
     }
 };

@@ -429,16 +429,22 @@ template <int NH> struct HarmonicSDE {
 
 // ------------------------------------------------------------------------------------------------ KPT measurement
 // h(x) = sum_k x[k] sin(k g(x[0] + x[d-1])) and its gradient (models.py:575-578).
-template <int NH> struct KptMeasurement {
+// UNIFORM: every lane of the wavefront evaluates the same argument (one wavefront per trial): the wave-uniform softplus and
+// sincos take their regime branches on scalars instead of diverging per lane.  The harmonics k = 2 .. NH come from the
+// fundamental's pair by the angle-addition recurrence (two dependent operations each) instead of NH range reductions.
+template <int NH, bool UNIFORM = false> struct KptMeasurement {
     static constexpr int D = NH + 2;
     CGP_DEV static double eval(const Vec<D>& x, Vec<D>& H) {
-        double gs, dgs;
-        softplus_pair(x.v[0] + x.v[D - 1], gs, dgs);
-        double h = 0.0, dsum = 0.0;
+        double gs, dgs, s1, c1;
+        if constexpr (UNIFORM) { softplus_pair_uniform(x.v[0] + x.v[D - 1], gs, dgs); fast_sincos_uniform(gs, s1, c1); }
+        else { softplus_pair(x.v[0] + x.v[D - 1], gs, dgs); fast_sincos(gs, s1, c1); }
+        double h = 0.0, dsum = 0.0, sn = s1, cs = c1;
         CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0;
         CGP_UNROLL for (int k = 1; k <= NH; k++) {
-            double sn, cs;
-            fast_sincos(gs * (double)k, sn, cs);
+            if (k > 1) {                                              // (sin, cos)(k g) from ((k - 1) g) and (g)
+                const double sk = fma(sn, c1, cs * s1), ck = fma(cs, c1, -(sn * s1));
+                sn = sk; cs = ck;
+            }
             h = fma(x.v[k], sn, h);
             H.v[k] = sn;
             dsum = fma(x.v[k] * cs, (double)k * dgs, dsum);
