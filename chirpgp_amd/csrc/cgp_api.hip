@@ -178,7 +178,11 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : (mfma_ekf ? Shape::MfmaEkfFilter : Shape::EkfFilter), sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
-    case CGP_M_LINEAR:       rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_LINEAR:
+        // kf at d = 4, one wavefront per trial: the matrix-core step of the EKF with the constant Jacobian F
+        if (method == CGP_F_EKF && model->d == 4 && wave && !(flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL)) && T * 128 <= 0x7FFFFF00LL) rc = dispatch_filter_kf4_mfma(io, ma, st);
+        else rc = dispatch_filter_disc_linear(method, model->d, wave, io, ma, st);
+        break;
     case CGP_M_HARMONIC_LCD:
     case CGP_M_LASCALA_LCD:
         // d = 4 EKF, one wavefront per trial: the lane-cooperative kernel (covariance spread over a 16-lane DPP row)

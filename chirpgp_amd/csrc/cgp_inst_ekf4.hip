@@ -6,4 +6,5 @@
 #include "cgp_mfma4.hpp"
 namespace cgp {
 int dispatch_filter_mfma4(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_ekf4_mfma(io, ma, st); }
+int dispatch_filter_kf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_kf4_mfma(io, ma, st); }
 }  // namespace cgp

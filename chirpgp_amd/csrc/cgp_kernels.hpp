@@ -462,6 +462,7 @@ inline hipError_t launch_smoother(const SmootherIO& io, const ModelArgs& ma, hip
 // `key` is d for the linear models and n_harm for the harmonic / KPT ones.  Return CGP_E_UNSUPPORTED if the
 // combination is not compiled in, CGP_E_HIP on a launch error.
 int dispatch_filter_disc_linear(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
+int dispatch_filter_kf4_mfma(const FilterIO&, const ModelArgs&, hipStream_t);      // kf at d = 4 on the matrix cores (cgp_mfma4.hpp)
 int dispatch_filter_disc_harm(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_sde_linear(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_sde_harm(int method, int key, bool wave, const FilterIO&, const ModelArgs&, hipStream_t);
