@@ -277,6 +277,106 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 
+// ---------------------------------------------------------------------------------------------- linear model, d = 4: kf
+// The same layout and update for a LINEAR cond_m_cov (kf, filters_smoothers.py:145-184; BASELINE config C1): the Jacobian is
+// the constant F -- no softplus, no rotation, nothing to speculate on -- so a step is the eight matrix instructions and the
+// rank-one update alone.  E1: the H = e_1 form of the update (see ekf4_mfma_finish_j).  What bounds such a step was measured
+// with tools/ubench/kf_chain.hip: the matrix pipe takes one v_mfma_f64_4x4x4 per 20 cycles from a wavefront, in order (eight
+// independent ones: 161 cycles), a dependent one 32; the step as the compiler orders it takes 216 cycles there, and an order
+// pinned by hand with scheduling barriers (the chain's instructions first, the others in their shadows) 252 -- slower.
+template <bool E1>
+CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, q = lane & 3;
+    const int64_t trial = blockIdx.x;
+    const double* __restrict__ prm = ma.params + trial * ma.param_stride;      // F (4 x 4, row-major) | Sigma (4 x 4)
+    const double JT = prm[q * 4 + r];                                            // F[q][r]: A operand "F", B operand "F^T"
+    const double Sig = prm[16 + r * 4 + q];
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const double Hr = Hp[r];
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    const double SigHr = prm[16 + r * 4 + 1], SigHq = prm[16 + 4 + q], c0 = prm[16 + 5] + Xi;
+
+    const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
+    double ur = m0p[r], uq = m0p[q];
+    double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
+
+    const int64_t T = io.T;
+    const double* __restrict__ ys = io.record(trial);
+    OobWindow mfs, Pfs;
+    mfs.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
+    Pfs.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
+    const bool want_nll = io.nll != nullptr;
+    const unsigned p_off = (((lane >> 2) & 3) == 0) ? 8u * (4 * r + q) : kOobOffset;
+    const unsigned m_off = (lane < 4) ? 8u * lane : kOobOffset;
+
+    __shared__ double2 park[64];
+    double cum = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        asm volatile("" : "+v"(ychunk));
+        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        wave_lds_fence();
+        auto one = [&](int slot) {
+            const double y = readlane_f64(ychunk, slot);
+            const double f_r = mfma4(JT, ur, 0.0), f_q = mfma4(ur, JT, 0.0);   // F u by row and by column
+            const double Q = mfma4(P, JT, 0.0);                                  // P F^T
+            double Pp, PHr, PHq, S, innov;
+            if constexpr (E1) {
+                const double a = dpp_f64<kQuadBcast1>(JT);                       // row 1 of F
+                const double Pa = mfma4(P, a, 0.0);
+                S = mfma4(a, Pa, c0);
+                PHr = mfma4(JT, Pa, SigHr);
+                PHq = mfma4(Pa, JT, SigHq);
+                Pp = mfma4(JT, Q, Sig);
+                innov = y - dpp_f64<kQuadBcast1>(f_q);
+            } else {
+                Pp = mfma4(JT, Q, Sig);                                          // F P F^T + Sigma
+                PHr = mfma4(Pp, Hr, 0.0);
+                PHq = mfma4(Hr, Pp, 0.0);
+                S = mfma4(Hr, PHr, Xi);
+                innov = y - mfma4(Hr, f_r, 0.0);
+            }
+            const double rS = rcp_nr1(S);
+            P = fma(-(PHr * rS), PHq, Pp);                                       // Pf = Pp - K K^T S (filters_smoothers.py:66)
+            const double g = rS * innov;
+            ur = fma(PHr, g, f_r);
+            uq = fma(PHq, g, f_q);
+            park[slot] = make_double2(S, innov);
+            const unsigned t = (unsigned)(t0 + slot);
+            Pfs.store_s(P, p_off, t * 128u);
+            mfs.store_s(uq, m_off, t * 32u);
+        };
+        int slot = 0;
+        for (; slot + kEkf4Unroll <= nsteps; slot += kEkf4Unroll) {
+            CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
+        }
+        for (; slot < nsteps; slot++) one(slot);
+        if (want_nll) {
+            wave_lds_fence();
+            const double2 si = park[lane < nsteps ? lane : 0];
+            cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
+        }
+    }
+    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+__global__ void __launch_bounds__(64) kf4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;
+    if (e1) kf4_mfma_trial<true>(io, ma);
+    else kf4_mfma_trial<false>(io, ma);
+}
+inline int launch_kf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return CGP_OK;
+    if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(kf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+
 __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
     const int64_t trial = blockIdx.x;
     if (trial >= io.B) return;
