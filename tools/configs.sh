@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/configs.jsonl
 : > $OUT
-run() { echo "# $*" >> $OUT; python bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" >> $OUT 2>/dev/null || echo '{"error": true}' >> $OUT; }
+run() { echo "# $*" >> $OUT; python bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 "$@" >> $OUT 2>/dev/null || echo '{"error": true}' >> $OUT; }
 run --workload ekf
 run --workload sgp
 run --workload cd_sgp --batch 512 --T 50000

@@ -11,13 +11,13 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
-python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.log"
+python bench.py --steps 10 --warmup 2 --no-other-configs > "$OUT/bench.json" 2> "$OUT/bench.log"
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $group -d "$OUT/pmc_$i" -o pmc --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$i.log"
+    rocprofv3 --pmc $group -d "$OUT/pmc_$i" -o pmc --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2> "$OUT/pmc_$i.log"
     echo "pmc pass $i ($group) done"
 done
 python tools/parse_pmc.py "$OUT" > "$OUT/pmc.json"
