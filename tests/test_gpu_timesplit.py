@@ -114,6 +114,29 @@ def test_d6_d8_smoothers_time_split(nh, method):
         cs.assert_close(g, o, 1e-10, f'd{2 * nh + 2} {method} split vs whole {n}')
 
 
+def test_time_split_with_one_parameter_vector_per_trial():
+    """A parameter sweep through the smoothers: every trial its own model (param_stride != 0), d = 4 and d = 8."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    rng = np.random.default_rng(12)
+    B, T = 6, 1100
+    prm = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * np.exp(0.2 * rng.standard_normal((B, 6)))
+    for nh in (1, 3):
+        if nh == 1:
+            _, _, disc, m0, P0, H = pm.build_chirp_model(prm)
+            ys = np.stack([cs.chirp_measurements(T, 70 + b)[2] for b in range(B)])
+        else:
+            _, _, disc, m0, P0, H = pm.build_harmonic_chirp_model(prm, nh)
+            ys = np.stack([cs.chirp_measurements(T, 70 + b, num_harmonics=nh)[2] for b in range(B)])
+        f = fs.ekf(disc, H, 0.1, m0, P0, 1e-3, ys)
+        for a, b_ in zip(fs.eks(disc, f[0], f[1], 1e-3, **SPLIT), fs.eks(disc, f[0], f[1], 1e-3, **WHOLE)):
+            cs.assert_close(a, b_, 1e-11 if nh == 1 else 1e-10, f'per-trial params eks nh={nh}')   # (d = 8: the two record forms round differently)
+        sg = SigmaPoints.gauss_hermite(4, 3) if nh == 1 else SigmaPoints.cubature(8)
+        g = fs.sgp_filter(disc, sg, H, 0.1, m0, P0, 1e-3, ys)
+        for a, b_ in zip(fs.sgp_smoother(disc, sg, g[0], g[1], 1e-3, **SPLIT), fs.sgp_smoother(disc, sg, g[0], g[1], 1e-3, **WHOLE)):
+            cs.assert_close(a, b_, 1e-10, f'per-trial params sgp_smoother nh={nh}')
+
+
 @pytest.mark.parametrize('d', [5, 7])
 def test_odd_dimensions_time_split(d):
     """`rts` at d = 5 and 7: the tile layout's padded rows / columns of the composed maps (and of the workspace records) stay zero."""
