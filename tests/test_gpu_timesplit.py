@@ -114,6 +114,34 @@ def test_d6_d8_smoothers_time_split(nh, method):
         cs.assert_close(g, o, 1e-10, f'd{2 * nh + 2} {method} split vs whole {n}')
 
 
+def test_random_record_lengths_split_equals_whole():
+    """Forty random (T, B) pairs, T from 2 to 700 -- below one tile, on tile and quad boundaries, one step past them: the
+    forced time-split launch (which falls back to one wave per trial when a record has too few tiles) against the whole-record
+    walk, for `eks` (d = 4) and `rts` (d = 6)."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from oracle import port
+    rng = np.random.default_rng(2024)
+    c = cs.chirp_case(T=700, seed=51)
+    d6 = 6
+    F6 = np.eye(d6) * 0.97 + 0.02 * rng.standard_normal((d6, d6)); S6 = np.eye(d6) * 0.05
+    lin6 = pm.linear_cond_m_cov(F6, S6)
+    Ts = [2, 3, 4, 5, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193, 257, 321, 449, 450, 451] + list(rng.integers(6, 700, size=20))
+    for T in Ts:
+        T = int(T)
+        B = int(rng.integers(1, 5))
+        ys = c.ys[None, :T] + 0.05 * rng.standard_normal((B, T))
+        f = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        for a, b_ in zip(fs.eks(c.disc, f[0], f[1], c.dt, **SPLIT), fs.eks(c.disc, f[0], f[1], c.dt, **WHOLE)):
+            cs.assert_close(a, b_, 1e-11, f'eks T={T} B={B}')
+        f6 = port.filter(port.F_EKF, lin6, None, np.ones(d6), 0.1, np.zeros(d6), np.eye(d6), 0., rng.standard_normal((B, T)))
+        want = port.smoother(port.S_EKS, lin6, None, 0., f6[0], f6[1])
+        got = fs.rts(F6, S6, f6[0], f6[1], **SPLIT)
+        whole = fs.rts(F6, S6, f6[0], f6[1], **WHOLE)
+        for a, b_, o in zip(got, want, whole):       # (a random F: the affine records' C = Pf - G Pp G^T cancels to ~1e-11 of the scale)
+            cs.assert_close(a, b_, 1e-7, f'rts d=6 T={T} B={B}')
+            cs.assert_close(a, o, 1e-7, f'rts d=6 T={T} B={B} vs whole')
+
+
 def test_time_split_with_one_parameter_vector_per_trial():
     """A parameter sweep through the smoothers: every trial its own model (param_stride != 0), d = 4 and d = 8."""
     from chirpgp_amd import filters_smoothers as fs, models as pm
