@@ -3,7 +3,7 @@
 namespace cgp {
 template <int NH>
 static int kpt(bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
-    using DM = LinearDisc<NH + 2>;
+    using DM = KptLinear<NH + 2>;           // F = I + e_{d-1} e_0^T as d + 1 additions; any other F densely
     // one wavefront per trial: the measurement's softplus / sincos in their wave-uniform forms
     return hip_rc(wave ? launch_filter<EkfPredict<DM, true>, KptUpdate<NH, true>>(io, ma, st)
                        : launch_filter<EkfPredict<DM, false>, KptUpdate<NH, false>>(io, ma, st));

@@ -123,6 +123,36 @@ template <int D_> struct LinearDisc {
     }
 };
 
+// The linear dynamics of the KPT model (models.py:561-570): F = I + e_{d-1} e_0^T -- the phase accumulates the frequency --
+// passed like any linear model as dense (F, Sigma).  When F has exactly that form (every build_kpt_chirp_model result) the
+// prediction is d + 1 additions instead of two dense d x d x d products (250 multiply-adds at d = 5, most of a step of
+// ekf_for_kpt); any other F takes LinearDisc's dense path.  The choice is uniform over the wavefront / per lane's trial.
+template <int D_> struct KptLinear : LinearDisc<D_> {
+    static constexpr int D = D_;
+    using Base = LinearDisc<D_>;
+    bool shift = false;
+    CGP_DEV void setup(const double* __restrict__ p, double dt, int model_id) {
+        Base::setup(p, dt, model_id);
+        bool ok = true;
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j < D; j++) ok = ok && (this->F.a[i][j] == ((i == j || (i == D - 1 && j == 0)) ? 1.0 : 0.0));
+        shift = ok;
+    }
+    CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
+        if (!shift) { Base::propagate(u, P, f, T, Pp); return; }
+        f = u;
+        f.v[D - 1] = u.v[D - 1] + u.v[0];
+        // T = F P: row d - 1 += row 0;  Pp = T F^T + Sigma: column d - 1 += column 0
+        CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) T.a[i][j] = P(i, j) + ((i == D - 1) ? P(0, j) : 0.0);
+        CGP_UNROLL for (int i = 0; i < D; i++)
+            CGP_UNROLL for (int j = 0; j <= i; j++) {
+                double v = T.a[i][j];
+                if (i == D - 1 && j == D - 1) v += T.a[D - 1][0];
+                Pp(i, j) = v + this->Sigma(i, j);
+            }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ harmonic chirp, LCD
 // disc_harmonic_chirp_lcd (models.py:332-386); NH = 1, freq_scale = 1 is disc_chirp_lcd (models.py:264-311);
 // model_id CGP_M_LASCALA_LCD (params = ell, sigma) is disc_model_lascala_lcd (models.py:419-434): rho = 1, q = 0.
