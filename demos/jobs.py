@@ -45,13 +45,14 @@ JOBS = {
 }
 
 
-def run_job(job, num_mcs=100, T=3141, results='./results', maxiter=200, seed=0, mags=None, quiet=False):
-    """-> [(mc, mag, rmse, nll at the start, nll at the optimum), ...]"""
+def run_job(job, num_mcs=100, T=3141, results=None, maxiter=200, seed=0, mags=None, quiet=False):
+    """The job's Monte-Carlo loop; result files go to `results` (None: not saved).
+    -> [(mc, mag, rmse, nll at the start, nll at the optimum), ...]"""
     method, family, model_h, signal_h, sg = JOBS[job]
     rows = []
     for mc in range(num_mcs):
         out = demo(method, sgps=sg() if sg else None, num_harmonics=model_h, signal_harmonics=signal_h, family=family, T=T,
-                   seed=seed + mc, maxiter=maxiter, save_dir=None, mags=mags, quiet=quiet)
+                   seed=seed + mc, maxiter=maxiter, save_dir=results, result_name=job, mc=mc, mags=mags, quiet=quiet)
         for name, err, nll0, nll1 in out:
             rows.append((mc, name, err, nll0, nll1))
     return rows
@@ -66,10 +67,7 @@ def main(argv=None):
     ap.add_argument('--maxiter', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
     a = ap.parse_args(argv)
-    method, family, model_h, signal_h, sg = JOBS[a.job]
-    for mc in range(a.num_mcs):
-        demo(method, sgps=sg() if sg else None, num_harmonics=model_h, signal_harmonics=signal_h, family=family, T=a.T,
-             seed=a.seed + mc, maxiter=a.maxiter, save_dir=a.results, result_name=a.job, mc=mc)
+    return run_job(a.job, num_mcs=a.num_mcs, T=a.T, results=a.results, maxiter=a.maxiter, seed=a.seed)
 
 
 if __name__ == '__main__':

@@ -238,11 +238,8 @@ def test_job_counterparts_run_end_to_end(job, tmp_path):
     the NLL, the RMSE is finite and the result file has the reference's layout and name."""
     import jobs
     from chirpgp_amd import results
-    method, family, model_h, signal_h, sg = jobs.JOBS[job]
-    import _pipeline
-    rows = _pipeline.demo(method, sgps=sg() if sg else None, num_harmonics=model_h, signal_harmonics=signal_h, family=family, T=1000,
-                          seed=5, maxiter=40, save_dir=str(tmp_path), result_name=job, mc=0, mags=('const',), quiet=True)
-    (name, err, nll0, nll1), = rows
+    rows = jobs.run_job(job, num_mcs=1, T=1000, results=str(tmp_path), maxiter=40, seed=5, mags=('const',), quiet=True)
+    (mc, name, err, nll0, nll1), = rows
     assert np.isfinite(err) and nll1 < nll0
     z = np.load(results.result_path(str(tmp_path), job, 'const', 0))
     d = {'kpt_mle': 3, 'harmonic_kpt_mle': 5, 'harmonic_ekfs_mle': 8}.get(job, 4)
