@@ -59,3 +59,28 @@ def test_crlb_ghf_job(tmp_path):
     # the EKF job on the same draws gives errors of the same size (the two filters agree closely on this mildly nonlinear model)
     ekf = crlb_ekf.main(['--filter', 'ekf', '--num-mcs', '4000', '--T', '100', '--chunk', '2000'])
     assert np.allclose(mean_c, ekf[0].cpu().numpy(), rtol=0.2)
+
+
+def test_mc_mle_sharded_over_two_ranks_equals_one_process(tmp_path):
+    """demos/mc_mle.py under torchrun (two ranks rehearsed on the one GPU, gloo): records sharded in contiguous blocks, no
+    exchange during the run, one all_gather of the per-record RMSEs -- and the same numbers as the one-process run, because a
+    record's noise depends on its global number only (counter-based generator) and its MLE only on the record."""
+    import subprocess
+    script = os.path.join(ROOT, 'demos', 'mc_mle.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    common = ['--num-mcs', '7', '--T', '800', '--compare', '0']
+    one = subprocess.run([sys.executable, script, *common], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), script, *common, '--rehearse'], env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line1 = [l for l in one.stdout.splitlines() if 'RMSE of the frequency estimate' in l][0]
+    line2 = [l for l in two.stdout.splitlines() if 'over all shards' in l][0]
+    import re
+    m1 = re.search(r'estimate: ([0-9.]+) \+- ([0-9.]+)', line1)
+    m2 = re.search(r'RMSE ([0-9.]+) \+- ([0-9.]+)', line2)
+    assert m1 and m2, (line1, line2)
+    assert m1.group(1) == m2.group(1) and m1.group(2) == m2.group(2), (line1, line2)
