@@ -10,28 +10,28 @@ namespace cgp {
 
 // Launch-shape choice.  One wavefront per trial is the latency-optimal shape while the batch is about the number of
 // SIMDs (1024): a step then costs its dependent-instruction chain once.  One lane per trial costs more per step but
-// carries 64 trials per wave, so it wins as soon as several wavefronts would have to share a SIMD.  Measured crossovers
-// on MI355X (tools/sweep_b.sh, EKF + EKS, d = 4, T = 2000):
-//     EKF-type filters            wave 1.87 ms vs lane 2.52 ms at B = 2048;  3.55 vs 2.53 at B = 4096   -> 2.5 waves / SIMD
-//     d = 4 chirp EKF (MFMA)      four trials per wave above B = 1024: 0.95 ms vs lane 2.64 ms at B = 4096, 1.89 vs 2.67
-//                                 at 8192, 3.53 vs 2.75 at 16384                                         -> 10 trials / SIMD
-//     sigma-point filters         the fan is spread over the lanes of the wave, which one lane per trial cannot do -> 8 / SIMD
-//     time-parallel smoothers     throughput-bound at ~2.9 TB/s for every B; the step-by-step lane-per-trial scan is
-//                                 latency-bound (T x 1.9 us) until B ~ 16K                              -> 16 / SIMD
-enum class Shape { EkfFilter, MfmaEkfFilter, SigmaFilter, AffineSmoother, SerialSmoother };
-static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, Shape shape, const cgp_sigma* sg = nullptr) {
+// carries 64 trials per wave, so it wins as soon as enough wavefronts would have to share a SIMD -- how many depends on how
+// much faster the lane-cooperative (matrix-core) kernel's step is than the one-lane step.  Crossovers measured on MI355X in
+// round 3 (bench.py --batch B --flags 2 | 4; wave-per-trial time grows linearly with B beyond 1024, the lane-per-trial time is
+// flat until B ~ 64 K), in trials per SIMD:
+//     EKF, chirp / La Scala d = 4 (MFMA, four trials per wave above 1024)   1.25 ms vs 2.58 at 8 K, 2.29 vs 2.65 at 16 K, 3.33 vs 2.89 at 24 K   -> 20
+//     EKF, 2 / 3 harmonics d = 6 / 8 (tile layout)                          0.93 vs 1.81 at 4 K, 1.73 vs 1.82 at 8 K, 3.29 vs 1.88 at 16 K        -> 8
+//     sigma-point filter, d = 4 (MFMA sums)                                 1.38 vs 8.17 at 4 K, 5.12 vs 8.18 at 16 K, 6.2 vs 5.1 at 32 K         -> 24
+//     sigma-point filter, d = 6 / 8 (tile layout)                           2.52 vs 6.95 at 4 K, 9.58 vs 6.99 at 16 K                             -> 11
+//     cd_ekf / cd_eks, d = 4 (MFMA)                                         1.41 vs 1.38 / 1.38 vs 1.90 at 4 K, 4.95 vs 1.40 / 4.89 vs 2.07 at 16 K -> 4 / 5
+//     cd_sgp filter / smoother, d = 4 (MFMA)                                2.3 vs 28.6 at 4 K, 9.2 vs 28.7 at 16 K                               -> 48
+//     discrete smoothers on the cooperative walks (d = 4 .. 8)              never slower than one lane per trial: 0.36 vs 9.98 ms (sigma-point d = 4,
+//                                                                           4 K), 2.77 vs 18.4 (EKS d = 8, 16 K), 9.4 vs 10.6 (EKS d = 4, 256 K)   -> always
+//     everything on the generic kernels                                     as measured in round 1: 2.5 (EKF-type), 8 (sigma-point), 16 (affine scan)
+struct ShapeLimit { int num, den; };                      // one wavefront per trial while B * den < num * SIMDs; num < 0: always
+static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, ShapeLimit limit, const cgp_sigma* sg = nullptr) {
     // the wave-per-trial shapes stage the sigma-point set in LDS; a set that does not fit runs one lane per trial
     if (sg && SigmaSet::stage_bytes(sg->s, sg->d, sg->n_groups, sg->group_start != nullptr) > (size_t)kSigLdsMaxBytes) return false;
     if (flags & CGP_WAVE_PER_TRIAL) return true;
     if (flags & CGP_THREAD_PER_TRIAL) return false;
+    if (limit.num < 0) return true;
     const int64_t simds = (int64_t)(ctx ? ctx->num_cus : 256) * 4;
-    switch (shape) {
-    case Shape::EkfFilter:      return 2 * B < 5 * simds;
-    case Shape::MfmaEkfFilter:  return B < 10 * simds;
-    case Shape::SigmaFilter:    return B < 8 * simds;
-    case Shape::AffineSmoother: return B < 16 * simds;
-    default:                    return 2 * B < 5 * simds;
-    }
+    return B * limit.den < (int64_t)limit.num * simds;
 }
 
 static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sigma, const cgp_sigma* sg) {
@@ -173,9 +173,20 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     const ModelArgs ma = model_args(model, sigma, dt, flags);
-    const bool mfma_ekf = method == CGP_F_EKF && model->n_harm == 1 && !(flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_ONE_TRIAL_PER_WAVE)) &&
-                          (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
-    const bool wave = choose_wave(ctx, B, flags, sig ? Shape::SigmaFilter : (mfma_ekf ? Shape::MfmaEkfFilter : Shape::EkfFilter), sig ? sigma : nullptr);
+    // which lane-cooperative kernel (if any) a wave-per-trial launch of this call would take decides the crossover
+    const bool spec = !(flags & CGP_GENERIC_KERNEL);
+    const bool chirp4 = spec && model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
+    const bool harm8 = spec && model->model_id == CGP_M_HARMONIC_LCD && (model->n_harm == 2 || model->n_harm == 3);
+    const bool sde4 = spec && model->model_id == CGP_M_HARMONIC_SDE && model->n_harm == 1;
+    const bool mfma = !(flags & CGP_DPP_KERNEL);
+    ShapeLimit limit = sig ? ShapeLimit{8, 1} : ShapeLimit{5, 2};
+    if (method == CGP_F_EKF && chirp4 && mfma && !(flags & CGP_ONE_TRIAL_PER_WAVE)) limit = {20, 1};
+    else if (method == CGP_F_EKF && harm8) limit = {8, 1};
+    else if (method == CGP_F_SGP && chirp4 && mfma) limit = {24, 1};
+    else if (method == CGP_F_SGP && harm8) limit = {11, 1};
+    else if (method == CGP_F_CD_EKF && sde4 && mfma) limit = {4, 1};
+    else if (method == CGP_F_CD_SGP && sde4 && mfma) limit = {48, 1};
+    const bool wave = choose_wave(ctx, B, flags, limit, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:
@@ -239,7 +250,20 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     }
     const ModelArgs ma = model_args(model, sigma, dt, flags);
     const bool affine = (method == CGP_S_EKS || method == CGP_S_SGP) && !(flags & CGP_SEQUENTIAL_SCAN);
-    const bool wave = choose_wave(ctx, B, flags, affine ? Shape::AffineSmoother : (sig ? Shape::SigmaFilter : Shape::SerialSmoother), sig ? sigma : nullptr);
+    // launch shape (see choose_wave): the cooperative walks of the discrete smoothers are never slower than one lane per trial
+    const bool spec = !(flags & CGP_GENERIC_KERNEL);
+    const bool sde4 = spec && model->model_id == CGP_M_HARMONIC_SDE && model->n_harm == 1 && !(flags & CGP_DPP_KERNEL);
+    bool coop_walk = false;
+    if (affine && spec) {
+        if (model->model_id == CGP_M_LINEAR) coop_walk = coop8_smoother_ok(model->d, T, ma) || (model->d == 4 && walk4_smoother_fits(T, ma));
+        else if (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD)
+            coop_walk = (model->n_harm >= 2 && coop8_smoother_ok(model->d, T, ma) && coop8_smoother_harm_ok(method, ma)) || (model->n_harm == 1 && walk4_smoother_fits(T, ma));
+    }
+    ShapeLimit limit = affine ? ShapeLimit{16, 1} : (sig ? ShapeLimit{8, 1} : ShapeLimit{5, 2});
+    if (coop_walk) limit = {-1, 1};
+    else if (method == CGP_S_CD_EKS && sde4) limit = {5, 1};
+    else if (method == CGP_S_CD_SGP && sde4) limit = {48, 1};
+    const bool wave = choose_wave(ctx, B, flags, limit, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:
