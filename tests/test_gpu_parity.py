@@ -806,3 +806,35 @@ def test_second_device_while_first_is_current():
     from oracle import port
     want = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys)
     cs.assert_close(f[0][2].cpu().numpy(), want[0], RTOL, 'cuda:1 mfs')
+
+
+@pytest.mark.parametrize('kind', ['sgp', 'harmonic_ekf', 'cd_sgp'])
+def test_default_launch_shape_at_a_mid_size_batch(kind):
+    """B = 5000: beyond one wavefront per SIMD but below the round-3 crossovers (cgp_api.hip:choose_wave), so the DEFAULT launch
+    takes the lane-cooperative kernels with several wavefronts per SIMD -- every 250th trial against the port."""
+    import bench
+    from oracle import port
+    import copy
+    fs = _fs()
+    B, T = 5000, 96
+    wl = bench.make_workload(B, T, kind=kind)
+    sel = np.arange(0, B, 250)
+    a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'])
+    if kind == 'sgp':
+        f = fs.sgp_filter(wl['disc'], wl['sgps'], *a, wl['ys'])
+        s = fs.sgp_smoother(wl['disc'], wl['sgps'], f[0], f[1], wl['dt'])
+        wf = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a, wl['ys'][sel])
+        ws = port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], wf[0], wf[1])
+    elif kind == 'harmonic_ekf':
+        f = fs.ekf(wl['disc'], *a, wl['ys'])
+        s = fs.eks(wl['disc'], f[0], f[1], wl['dt'])
+        wf = port.filter(port.F_EKF, wl['disc'], None, *a, wl['ys'][sel])
+        ws = port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], wf[0], wf[1])
+    else:
+        dg = copy.copy(wl['drift']); dg.gamma = wl['disp'].outer()
+        f = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], *a, wl['ys'])
+        s = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], f[0], f[1], wl['dt'])
+        wf = port.filter(port.F_CD_SGP, dg, wl['sgps'], *a, wl['ys'][sel])
+        ws = port.smoother(port.S_CD_SGP, dg, wl['sgps'], wl['dt'], wf[0], wf[1])
+    for g, w, n in zip(tuple(x[sel] for x in f) + tuple(x[sel] for x in s), wf + ws, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
+        cs.assert_close(g, w, 1e-7, f'{kind} B=5000 {n}')
