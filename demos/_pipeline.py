@@ -37,46 +37,87 @@ def magnitudes(rng):
     return (('const', constant_mag(1.)), ('damped', damped_exp_mag(0.3)), ('ou', random_ou_mag(1., 1., rng)))
 
 
-def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
-    """MLE -> filter -> smoother -> E[g(V)] on one measurement record.
-    method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs' | 'kpt';  family: 'chirp' | 'harmonic' | 'lascala' | 'kpt'
-    (default: 'kpt' for method 'kpt', else 'harmonic' when num_harmonics > 0, else 'chirp').
-    Returns a dict with opt_params, the scipy result, nll0 (objective at the start), the smoothing results and est_freq."""
+def _family_setup(method, family, num_harmonics, dt, init):
     if family is None:
         family = 'kpt' if method == 'kpt' else ('harmonic' if num_harmonics else 'chirp')
     build, init_default = FAMILIES[family]
-    init = init_default if init is None else init
     build_kw = {}
     if family == 'harmonic':
         build_kw = dict(num_harmonics=num_harmonics)
     elif family == 'kpt':
         build_kw = dict(fs=1. / dt, num_harmonics=max(num_harmonics, 1))
-    filt = FILTER_OF[method]
-    nll0 = float(mle.batched_nll(filt, build, np.log(np.expm1(np.asarray(init, dtype=np.float64))), ys, Xi, dt, sgps, **build_kw)[0])
-    opt_params, res = mle.fit(filt, build, init, ys, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
+    return build, (init_default if init is None else init), build_kw
+
+
+def _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, ys):
+    """Filter + smoother + E[g(V)] at given model parameters; `params` and `ys` may both carry a leading record axis."""
     if method == 'kpt':      # tetralith/jobs/kpt_mle.py:54-76: ekf_for_kpt, then the LINEAR smoother; frequency = g(x_0) fs / 2 pi
-        F, Sigma, m0, P0, h = build(opt_params, **build_kw)
+        F, Sigma, m0, P0, h = build(params, **build_kw)
         mfs, Pfs, _ = fs.ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys)
         mss, Pss = fs.rts(F, Sigma, mfs, Pfs)
         scale = 1. / dt / 2 / math.pi
-        est = gaussian_expectation(ms=mss[:, 0] * scale, chol_Ps=np.sqrt(Pss[:, 0, 0]) * scale, func=g, force_shape=True)[:, 0]
-        return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
-    drift, dispersion, m_and_cov, m0, P0, H = build(opt_params, **build_kw)
-    if method == 'ekfs':
-        mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
-        mss, Pss = fs.eks(m_and_cov, mfs, Pfs, dt)
-    elif method == 'ghfs':
-        mfs, Pfs, _ = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
-        mss, Pss = fs.sgp_smoother(m_and_cov, sgps, mfs, Pfs, dt)
-    elif method == 'cd_ekfs':
-        mfs, Pfs, _ = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
-        mss, Pss = fs.cd_eks(drift, dispersion, mfs, Pfs, dt)
-    else:   # the reference passes the dispersion MATRIX: dispersion(jnp.eye(4)) (demos/cd_ghfs_mle.py:48)
-        mfs, Pfs, _ = fs.cd_sgp_filter(drift, dispersion(None), sgps, H, Xi, m0, P0, dt, ys)
-        mss, Pss = fs.cd_sgp_smoother(drift, dispersion(None), sgps, mfs, Pfs, dt)
-    # the frequency state is the last-but-one component (index 2 of the chirp model, -2 of the harmonic one)
-    est = gaussian_expectation(ms=mss[:, -2], chol_Ps=np.sqrt(Pss[:, -2, -2]), func=g, force_shape=True)[:, 0]
+        ms, sd = mss[..., 0] * scale, np.sqrt(Pss[..., 0, 0]) * scale
+    else:
+        drift, dispersion, m_and_cov, m0, P0, H = build(params, **build_kw)
+        if method == 'ekfs':
+            mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
+            mss, Pss = fs.eks(m_and_cov, mfs, Pfs, dt)
+        elif method == 'ghfs':
+            mfs, Pfs, _ = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
+            mss, Pss = fs.sgp_smoother(m_and_cov, sgps, mfs, Pfs, dt)
+        elif method == 'cd_ekfs':
+            mfs, Pfs, _ = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
+            mss, Pss = fs.cd_eks(drift, dispersion, mfs, Pfs, dt)
+        else:   # the reference passes the dispersion MATRIX: dispersion(jnp.eye(4)) (demos/cd_ghfs_mle.py:48)
+            mfs, Pfs, _ = fs.cd_sgp_filter(drift, dispersion(None), sgps, H, Xi, m0, P0, dt, ys)
+            mss, Pss = fs.cd_sgp_smoother(drift, dispersion(None), sgps, mfs, Pfs, dt)
+        # the frequency state is the last-but-one component (index 2 of the chirp model, -2 of the harmonic one)
+        ms, sd = mss[..., -2], np.sqrt(Pss[..., -2, -2])
+    est = gaussian_expectation(ms=ms.reshape(-1), chol_Ps=sd.reshape(-1), func=g, force_shape=True)[:, 0].reshape(ms.shape)
+    return mss, Pss, est
+
+
+def run_records(method, yss, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
+    """The pipeline for R records in LOCK STEP: one maximum-likelihood fit for all of them (chirpgp_amd.mle.fit_many: every
+    line-search probe of every record in one kernel launch), then ONE batched filter and ONE batched smoother launch with a
+    parameter vector per record -- R records for about the wall time of one (the reference's jobs loop over them,
+    tetralith/jobs/ekfs_mle.py:26-81).  yss (R, T) -> dict(opt_params (R, P), fun (R,), nll0 (R,), mss, Pss, est_freq (R, T))."""
+    build, init, build_kw = _family_setup(method, family, num_harmonics, dt, init)
+    filt = FILTER_OF[method]
+    yss = np.asarray(yss, dtype=np.float64)
+    R = yss.shape[0]
+    theta0 = np.tile(np.log(np.expm1(np.asarray(init, dtype=np.float64))), (R, 1))
+    nll0 = mle.batched_nll(filt, build, theta0, yss, Xi, dt, sgps, **build_kw)
+    params, info = mle.fit_many(filt, build, init, yss, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
+    mss, Pss, est = _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, yss)
+    return dict(opt_params=params, fun=info['fun'], nll0=nll0, mss=mss, Pss=Pss, est_freq=est, nit=info['nit'], launches=info['launches'])
+
+
+def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
+    """MLE -> filter -> smoother -> E[g(V)] on one measurement record.
+    method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs' | 'kpt';  family: 'chirp' | 'harmonic' | 'lascala' | 'kpt'
+    (default: 'kpt' for method 'kpt', else 'harmonic' when num_harmonics > 0, else 'chirp').
+    Returns a dict with opt_params, the scipy result, nll0 (objective at the start), the smoothing results and est_freq."""
+    build, init, build_kw = _family_setup(method, family, num_harmonics, dt, init)
+    filt = FILTER_OF[method]
+    nll0 = float(mle.batched_nll(filt, build, np.log(np.expm1(np.asarray(init, dtype=np.float64))), ys, Xi, dt, sgps, **build_kw)[0])
+    opt_params, res = mle.fit(filt, build, init, ys, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
+    mss, Pss, est = _filter_and_smooth(method, build, build_kw, opt_params, sgps, Xi, dt, ys)
     return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
+
+
+def records_of_run(seed, T, dt, Xi, signal_harmonics, mags=None):
+    """The measurement records of ONE Monte-Carlo run, one per magnitude law: (position, name, ys) in the order the random
+    stream of numpy.random.default_rng(seed) produces them (the Ornstein-Uhlenbeck magnitude draws from the same stream)."""
+    ts = np.linspace(dt, dt * T, T)
+    rng = np.random.default_rng(seed)
+    _, true_phase_func = meow_freq(offset=8.)
+    for k, (name, mag) in enumerate(magnitudes(rng)):
+        if mags is not None and name not in mags:
+            continue
+        clean = (gen_chirp(ts, mag, true_phase_func) if signal_harmonics == 0
+                 else gen_harmonic_chirp(ts, [mag] * signal_harmonics, true_phase_func))
+        yield k, name, clean + math.sqrt(Xi) * rng.standard_normal(T)
 
 
 def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001, maxiter=200, save_dir=None, mags=None, quiet=False,
@@ -87,14 +128,9 @@ def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001,
     position of the magnitude law, as the demos have a single run)."""
     sig_h = num_harmonics if signal_harmonics is None else signal_harmonics
     ts = np.linspace(dt, dt * T, T)
-    rng = np.random.default_rng(seed)
-    true_freq_func, true_phase_func = meow_freq(offset=8.)
+    true_freq_func, _ = meow_freq(offset=8.)
     out = []
-    for k, (name, mag) in enumerate(magnitudes(rng)):
-        if mags is not None and name not in mags:
-            continue
-        clean = gen_chirp(ts, mag, true_phase_func) if sig_h == 0 else gen_harmonic_chirp(ts, [mag] * sig_h, true_phase_func)
-        ys = clean + math.sqrt(Xi) * rng.standard_normal(T)
+    for k, name, ys in records_of_run(seed, T, dt, Xi, sig_h, mags):
         t0 = time.time()
         r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter, family=family)
         err = float(rmse(true_freq_func(ts), r['est_freq'])) if r['res'].success or np.isfinite(r['res'].fun) else float('nan')

@@ -244,3 +244,36 @@ def test_job_counterparts_run_end_to_end(job, tmp_path):
     z = np.load(results.result_path(str(tmp_path), job, 'const', 0))
     d = {'kpt_mle': 3, 'harmonic_kpt_mle': 5, 'harmonic_ekfs_mle': 8}.get(job, 4)
     assert set(z.files) == {'smoothing_mean', 'smoothing_cov', 'rmse'} and z['smoothing_mean'].shape == (1000, d)
+
+
+@pytest.mark.parametrize('job', ['ekfs_mle', 'ghfs_mle', 'kpt_mle', 'harmonic_ekfs_mle', 'cd_ekfs_mle'])
+def test_lockstep_job_matches_the_record_by_record_loop(job, tmp_path):
+    """demos/jobs.py --lockstep: the Monte-Carlo runs of a magnitude law in ONE lock-step fit + one batched filter / smoother
+    launch.  Same records as the record-by-record loop (same random stream); every run lowers its NLL; the optimum found is
+    no worse than the loop's (scipy's L-BFGS-B) beyond a small slack; and the smoothing results saved ARE the batched
+    smoother's at the lock-step parameters (checked against a single-record call at those parameters)."""
+    import jobs
+    import _pipeline
+    from chirpgp_amd import results
+    n, T = 3, 800
+    kw = dict(num_mcs=n, T=T, maxiter=40, seed=11, mags=('const', 'damped'), quiet=True)
+    rows_l = jobs.run_job(job, results=str(tmp_path / 'lock'), lockstep=True, **kw)
+    rows_s = sorted(jobs.run_job(job, results=str(tmp_path / 'loop'), **kw))
+    assert [(r[0], r[1]) for r in rows_l] == [(r[0], r[1]) for r in rows_s] and len(rows_l) == 2 * n
+    for (mc, name, err_l, nll0_l, nll1_l), (_, _, err_s, nll0_s, nll1_s) in zip(rows_l, rows_s):
+        npt.assert_allclose(nll0_l, nll0_s, rtol=1e-12)            # same record, same start point
+        assert np.isfinite(err_l) and nll1_l < nll0_l
+        assert nll1_l <= nll1_s + 0.02 * abs(nll0_s - nll1_s), (job, mc, name, nll1_l, nll1_s)
+        z = np.load(results.result_path(str(tmp_path / 'lock'), job, name, mc))
+        assert np.isfinite(z['smoothing_mean']).all() and z['smoothing_mean'].shape[0] == T
+    # the batched launch with per-record parameters == the single-record launches at the same parameters
+    method, family, model_h, signal_h, sg = jobs.JOBS[job]
+    yss = np.stack([next(ys for _, nm, ys in _pipeline.records_of_run(11 + mc, T, 1e-3, 0.1, signal_h) if nm == 'damped') for mc in range(n)])
+    sgps = sg() if sg else None
+    r = _pipeline.run_records(method, yss, 0.1, 1e-3, sgps=sgps, num_harmonics=model_h, maxiter=5, family=family)
+    build, _, bkw = _pipeline._family_setup(method, family, model_h, 1e-3, None)
+    for i in range(n):
+        mss, Pss, est = _pipeline._filter_and_smooth(method, build, bkw, r['opt_params'][i], sgps, 0.1, 1e-3, yss[i])
+        npt.assert_allclose(r['mss'][i], mss, rtol=1e-10, atol=1e-12)
+        npt.assert_allclose(r['Pss'][i], Pss, rtol=1e-10, atol=1e-12)
+        npt.assert_allclose(r['est_freq'][i], est, rtol=1e-10, atol=1e-12)
