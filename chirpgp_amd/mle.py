@@ -34,11 +34,13 @@ def batched_nll(method, build, thetas, ys, Xi, dt, sgps=None, record_index=None,
     if n_rec < 1 or G % n_rec:
         raise ValueError(f'{G} parameter vectors cannot be shared out evenly over {n_rec} records')
     kw = dict(nll_final_only=True, want=(False, False, True), trials_per_record=G // n_rec, record_index=record_index)
+    with np.errstate(all='ignore'):        # a probe whose parameters under- or overflow yields a NaN objective, which the line search rejects
+        built = build(M.g(thetas), **build_kw)
     if method == 'ekf_for_kpt':
-        F, Sigma, m0, P0, h = build(M.g(thetas), **build_kw)
+        F, Sigma, m0, P0, h = built
         out = fs.ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw)
     else:
-        drift, disp, disc, m0, P0, H = build(M.g(thetas), **build_kw)
+        drift, disp, disc, m0, P0, H = built
         if method == 'ekf':
             out = fs.ekf(disc, H, Xi, m0, P0, dt, ys, **kw)
         elif method == 'sgp_filter':
