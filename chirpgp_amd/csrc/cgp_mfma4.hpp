@@ -42,8 +42,8 @@ struct Ekf4MfmaConst {
     double M0, M1, M2, M3, rho, ang;           // M32 block, exp(-lam dt), dt 2 pi fs
     double Hr, Xi, Sig;
     double kc, ks, kj, kk;                     // J[q][r] = kc c + ks s + kk + kj dth f[q ^ 1]  (kj = -1 at (0, 2), +1 at (1, 2))
+    double SigHq, c0;                          // H = e_1 form of the update: Sigma[1][q], Sigma[1][1] + Xi
     double kcr, ksr, kja;                      // kc rho, ks rho, kj ang: the damping and the angle scale ride in the per-lane coefficients
-    double SigHr, SigHq, c0;                   // H = e_1 form of the update: Sigma[r][1], Sigma[1][q], Sigma[1][1] + Xi
     CGP_DEV void fold() { kcr = kc * rho; ksr = ks * rho; kja = kj * ang; }
 };
 // The mean is distributed like the covariance: ur = u[r] (row layout) and uq = u[q] (column layout) at lane (r, q); the
@@ -61,29 +61,45 @@ struct Ekf4State {
 // so the per-lane scalar copies of u0..u3 and f0..f3, the quad broadcasts of PH and the FMA chains for f and H . f are
 // gone; the Jacobian column d f / d u2 = dth (-f1, f0) is a quad swap of f by column times a per-lane sign.
 //
-// E1 = true (round 3): the measurement vector is the unit vector e_1 -- every chirp / La Scala model of the reference has
-// H = [0, 1, 0, 0] (models.py:118) -- and the update leaves the dependent chain two matrix instructions earlier.  With
-// a = J^T H = row 1 of J (one quad broadcast of RJT):
-//     P a                       mfma(A = P,   B = a by row)                      in parallel with Q = P J^T
-//     S  = a . (P a) + c0       mfma(A = a,   B = P a, C = Sigma_11 + Xi)         in parallel with Pp = J Q + Sigma
-//     Pp H = J (P a) + Sigma H  mfma(A = RJT, B = P a, C = Sigma[r][1]) by row,  mfma(A = P a, B = RJT, C = Sigma[1][q]) by column
-// -- the same eight matrix instructions (H . f is a quad broadcast of f by column), but S waits for TWO of them behind the
-// Jacobian instead of four (Q, Pp, Pp H, S); Pp itself is only needed by the covariance update at the end of the step.
-template <bool E1 = false>
+// E1 != 0 (round 3): the measurement vector is the unit vector e_1 -- every chirp / La Scala model of the reference has
+// H = [0, 1, 0, 0] (models.py:118).  Then H picks entries of Q = P J^T and Pp = J Q + Sigma instead of contracting with them:
+//     P a = P J^T e_1 = column 1 of Q                  one quad broadcast of Q            (a = J^T H = row 1 of J)
+//     (Pp H)[r] = Pp[r][1]  by row                      one quad broadcast of Pp
+//     (H Pp)[q] = Pp[1][q]  by column                   mfma(A = P a, B = RJT, C = Sigma[1][q]) = (J P a)[q] + Sigma[1][q]: a lane
+//                                                        cannot fetch another ROW cheaply; issued beside Pp, not behind it
+//     S = Pp[1][1] + Xi                                 E1 == 2 (one trial per wavefront): a v_readlane pair of lane (1, 1);
+//                                                        E1 == 1 (one trial per MFMA block, the x4 kernel): mfma(A = a, B = P a, C = Sigma_11 + Xi)
+//     H f = f[1]                                        one quad broadcast of f by column
+// -- FIVE matrix instructions a step (f by row, f by column, Q, Pp, H Pp) where the general form has eight.  What this kernel
+// is bound by was measured in round 3's last microbenchmarks: INSTRUCTION ISSUE first, its dependent chain second.  A wavefront
+// that has its SIMD to itself issues nothing in the shadow of its own v_mfma_f64_4x4x4 (tools/ubench/mfma_valu_overlap.hip:
+// M matrix + N vector instructions take 20 M + 5 N cycles, not the maximum of the two); a v_fma_f64 / v_mul_f64 / v_add_f64
+// occupies it for 5 cycles, a v_mov_dpp 4, a v_readlane 12, v_rcp_f64 16 (tools/ubench/issue_costs.hip); the step's
+// operations as straight-line code take about the sum of these costs in any reasonable order (tools/ubench/ekf4_parts.hip:
+// 477 cycles in source order, 508 in a latency-driven list schedule; the dependent chain alone is ~ 310).  So a quad
+// broadcast (two v_mov_dpp, 8 cycles) beats the matrix instruction (20) that would put the same numbers into the same
+// lanes.  The chain still counts in the step's tail: H Pp as mfma(A = H, B = Pp) + S as its quad broadcast (no P a, no
+// v_readlane) is three instructions shorter but one matrix instruction deeper, and measured 2.64 against 2.60 ms -- the
+// linear filter, whose step is the tail alone, takes that form and gains 4 % (kf4_mfma_trial).
+template <int E1 = 0>
 CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
     const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
     const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
     const double kjd = K.kja * dsp;
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
     double Pp, PHr, PHq;
-    if constexpr (E1) {
-        const double a = dpp_f64<kQuadBcast1>(RJT);                    // a[r] = J[1][r], the same in the four lanes of a quad
-        const double Pa = mfma4(x.P, a, 0.0);                          // (P a)[r]
+    if constexpr (E1 != 0) {
         const double Q = mfma4(x.P, RJT, 0.0);
-        S = mfma4(a, Pa, K.c0);                                        // a . (P a) + Sigma_11 + Xi = H Pp H^T + Xi
-        PHr = mfma4(RJT, Pa, K.SigHr);                                 // (J P a)[r] + Sigma[r][1]
-        PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q]
+        const double Pa = dpp_f64<kQuadBcast1>(Q);                     // (P a)[r] = Q[r][1], a = J^T H = row 1 of J
         Pp = mfma4(RJT, Q, K.Sig);
+        PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q], beside Pp
+        PHr = dpp_f64<kQuadBcast1>(Pp);                                // Pp[r][1]
+        if constexpr (E1 == 1) {
+            const double a = dpp_f64<kQuadBcast1>(RJT);                // a[r] = J[1][r]
+            S = mfma4(a, Pa, K.c0);                                    // a . (P a) + Sigma_11 + Xi, per MFMA block
+        } else {
+            S = readlane_f64(Pp, 17) + K.Xi;                           // lane (r, b, q) = (1, 0, 1)
+        }
         innov = y - dpp_f64<kQuadBcast1>(f_q);                         // H . f = f[1]
     } else {
         // ---- predict: Pp = J P J^T + Sigma
@@ -103,7 +119,7 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
 }
 
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
-template <bool E1 = false>
+template <int E1 = 0>
 CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
     softplus_pair_uniform(x.u2(), sp, dsp);
@@ -139,7 +155,7 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 //     values fall outside [1.5, 700) as unsigned offsets) and one |d| compare, each a v_cmp into a scalar register pair ORed
 //     into a 64-bit scalar accumulator -- three vector instructions instead of six, and the chunk's verdict is a scalar
 //     compare (no readfirstlane).
-template <bool E1>
+template <int E1>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                   double& innov, unsigned long long* uncommon) {
     const double u2 = x.u2();
@@ -192,10 +208,9 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     K.Sig = 0.0;
     if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
     else if (r + q == 5) K.Sig = model.MS[1];
-    K.SigHr = (r == 1) ? model.q : 0.0;                                 // Sigma[r][1]: the chirp block of Sigma is q I
-    K.SigHq = (q == 1) ? model.q : 0.0;
-    K.c0 = model.q + K.Xi;
     // J = [c -s jv0 0; s c jv1 0; 0 0 M0 M1; 0 0 M2 M3], this lane holds J[q][r]
+    K.SigHq = (q == 1) ? model.q : 0.0;                                 // Sigma[1][q]: the chirp block of Sigma is q I
+    K.c0 = model.q + K.Xi;
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
     K.kj = (r == 2 && q == 0) ? -1.0 : ((r == 2 && q == 1) ? 1.0 : 0.0);
@@ -229,12 +244,17 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double2 park[64 * kParkStride];
     double cum = 0.0;
     int checked_left = 0;
+    // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
+    // start exposes the whole memory latency (and, vmcnt counting in order, the drain of every store still in flight) once per
+    // 64 steps -- 2.7 us of a 16 us chunk
+    double ynext = (lane < T) ? ys[lane] : 0.0;
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
         wave_lds_fence();                                                   // the previous chunk's NLL flush has read its slots
-        // 64 measurements with one coalesced 512-B load.  The empty asm consumes the loaded register here, so the compiler's
-        // s_waitcnt vmcnt(0) for it sits in this outer loop and not in front of every step's v_readlane
-        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        // The empty asm consumes the loaded register here, so the compiler's s_waitcnt for it sits in this outer loop and
+        // not in front of every step's v_readlane
+        double ychunk = ynext;
         asm volatile("" : "+v"(ychunk));
+        ynext = (t0 + 64 + lane < T) ? ys[t0 + 64 + lane] : 0.0;
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         const Ekf4State x0 = x;
         unsigned long long uncommon = 0;
@@ -243,7 +263,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             ekf4_anchor(K, x.u2(), anchor);
             auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1>(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_off, t * 128u);
@@ -260,7 +280,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step_checked<E1>(K, readlane_f64(ychunk, slot), x, S, innov);
+                ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_off, t * 128u);
@@ -280,7 +300,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
 // ---------------------------------------------------------------------------------------------- linear model, d = 4: kf
 // The same layout and update for a LINEAR cond_m_cov (kf, filters_smoothers.py:145-184; BASELINE config C1): the Jacobian is
 // the constant F -- no softplus, no rotation, nothing to speculate on -- so a step is the eight matrix instructions and the
-// rank-one update alone.  E1: the H = e_1 form of the update (see ekf4_mfma_finish_j).  What bounds such a step was measured
+// rank-one update alone.  E1: the H = e_1 form of the update (see ekf4_mfma_finish).  What bounds such a step was measured
 // with tools/ubench/kf_chain.hip: the matrix pipe takes one v_mfma_f64_4x4x4 per 20 cycles from a wavefront, in order (eight
 // independent ones: 161 cycles), a dependent one 32; the step as the compiler orders it takes 216 cycles there, and an order
 // pinned by hand with scheduling barriers (the chain's instructions first, the others in their shadows) 252 -- slower.
@@ -295,7 +315,6 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
     const double Hr = Hp[r];
     const double Xi = io.Xi[trial * io.Xi_stride];
-    const double SigHr = prm[16 + r * 4 + 1], SigHq = prm[16 + 4 + q], c0 = prm[16 + 5] + Xi;
 
     const double* __restrict__ m0p = io.m0 + trial * io.m0_stride;
     double ur = m0p[r], uq = m0p[q];
@@ -314,9 +333,11 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
 
     __shared__ double2 park[64];
     double cum = 0.0;
+    double ynext = (lane < T) ? ys[lane] : 0.0;                                  // one chunk ahead (see ekf4_mfma_trial)
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
-        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+        double ychunk = ynext;
         asm volatile("" : "+v"(ychunk));
+        ynext = (t0 + 64 + lane < T) ? ys[t0 + 64 + lane] : 0.0;
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         wave_lds_fence();
         auto one = [&](int slot) {
@@ -324,13 +345,11 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             const double f_r = mfma4(JT, ur, 0.0), f_q = mfma4(ur, JT, 0.0);   // F u by row and by column
             const double Q = mfma4(P, JT, 0.0);                                  // P F^T
             double Pp, PHr, PHq, S, innov;
-            if constexpr (E1) {
-                const double a = dpp_f64<kQuadBcast1>(JT);                       // row 1 of F
-                const double Pa = mfma4(P, a, 0.0);
-                S = mfma4(a, Pa, c0);
-                PHr = mfma4(JT, Pa, SigHr);
-                PHq = mfma4(Pa, JT, SigHq);
+            if constexpr (E1) {                                                  // see ekf4_mfma_finish: five matrix instructions
                 Pp = mfma4(JT, Q, Sig);
+                PHq = mfma4(Hr, Pp, 0.0);
+                PHr = dpp_f64<kQuadBcast1>(Pp);
+                S = dpp_f64<kQuadBcast1>(PHq) + Xi;
                 innov = y - dpp_f64<kQuadBcast1>(f_q);
             } else {
                 Pp = mfma4(JT, Q, Sig);                                          // F P F^T + Sigma
@@ -398,7 +417,7 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 // the anchor use the per-lane softplus / sincos, and the output windows span the wave's four consecutive trials.
 // One lane per trial needs T x 1.3 us whatever the batch (its step is a 500-instruction dependent chain); this
 // kernel needs T x 0.4 us per 4096 trials.
-template <bool E1 = false>
+template <int E1 = 0>
 CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
     softplus_pair_wide(x.u2(), sp, dsp);
@@ -435,8 +454,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
     K.Sig = 0.0;
     if (r == q) K.Sig = (r < 2) ? model.q : (r == 2 ? model.MS[0] : model.MS[2]);
     else if (r + q == 5) K.Sig = model.MS[1];
-    K.SigHr = (r == 1) ? model.q : 0.0;
-    K.SigHq = (q == 1) ? model.q : 0.0;
+    K.SigHq = (q == 1) ? model.q : 0.0;                                 // Sigma[1][q]: the chirp block of Sigma is q I
     K.c0 = model.q + K.Xi;
     K.kc = ((q == 0 && r == 0) || (q == 1 && r == 1)) ? 1.0 : 0.0;
     K.ks = (q == 0 && r == 1) ? -1.0 : ((q == 1 && r == 0) ? 1.0 : 0.0);
@@ -480,7 +498,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
             ekf4_anchor_lane(K, x.u2(), anchor);
             auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1>(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1 ? 1 : 0>(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_base, t * 128u);              // the step's row offset rides in the scalar offset
@@ -497,7 +515,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
             if (redo) { x = x0; checked_left = kCheckedChunks; }
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step_checked_lane<E1>(K, ych[b][slot], x, S, innov);
+                ekf4_mfma_step_checked_lane<E1 ? 1 : 0>(K, ych[b][slot], x, S, innov);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_base, t * 128u);
