@@ -242,6 +242,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
     __shared__ double2 park[64 * kParkStride];
+    __shared__ double ybuf[64 + 8];                                         // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
     int checked_left = 0;
     // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
@@ -261,19 +262,27 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         if (checked_left == 0) {
             Ekf4Anchor anchor;
             ekf4_anchor(K, x.u2(), anchor);
-            auto one = [&](int slot) {
+            auto one = [&](int slot, double y) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, readlane_f64(ychunk, slot), x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, y, x, anchor, S, innov, &uncommon);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_off, t * 128u);
                 mfs.store_s(x.uq, m_off, t * 32u);
             };
+            // The step's measurement: the chunk's 64 values go to LDS once, and every group of four steps reads its four with
+            // two broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
+            // (tools/ubench/issue_costs.hip)
+            ybuf[lane] = ychunk;
+            wave_lds_fence();
             int slot = 0;
-            for (; slot + kEkf4Unroll <= nsteps; slot += kEkf4Unroll) {
-                CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
+            double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
+            for (; slot + 4 <= nsteps; slot += 4) {
+                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
+                one(slot, ya.x); one(slot + 1, ya.y); one(slot + 2, yb.x); one(slot + 3, yb.y);
+                ya = na; yb = nb;
             }
-            for (; slot < nsteps; slot++) one(slot);
+            for (; slot < nsteps; slot++) one(slot, readlane_f64(ychunk, slot));
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
