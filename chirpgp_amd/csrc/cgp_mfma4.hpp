@@ -136,8 +136,8 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // with sin d, cos d to d^3 / d^4 (remainders < 2.4e-13 d while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
 // fresh sincos.  d is formed as ang q t + (ang u2 - theta_prev), whose second term does not wait for the polynomials; what
 // accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
-// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| > 2^-7 (or NaN) sets
-// *uncommon and the whole chunk is repeated with the checked step.
+// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-7 (or NaN) marks
+// the chunk's verdict (Ekf4Verdict) and the whole chunk is repeated with the checked step.
 struct Ekf4Anchor { double th, c1, s1; };
 
 CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
@@ -151,13 +151,20 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 //   * the increment's sine and cosine to d^3 / d^4 only (round 2: d^5 / d^6): while |d| <= 2^-7 the dropped terms are below d^5 / 120 = 2.4e-13
 //     relative and d^6 / 720 = 3e-16 (the bench records' largest increment, 2.7e-3, gives 1.2e-15), and the pair is re-anchored
 //     every 64 steps;
-//   * the regime verdicts as WAVE MASKS: one integer range compare of u2's high word (NaN, inf, negative and out-of-range
-//     values fall outside [1.5, 700) as unsigned offsets) and one |d| compare, each a v_cmp into a scalar register pair ORed
-//     into a 64-bit scalar accumulator -- three vector instructions instead of six, and the chunk's verdict is a scalar
-//     compare (no readfirstlane).
+//   * the regime verdicts from the high words of u2 and d alone (integer range checks; the chunk's verdict is one ballot pair).
+// The regime verdicts of a chunk as two running maxima in vector registers (one integer add / and + one v_max_u32 each, which the
+// compiler pairs into v_max3_u32 across steps; round 3 first had them as v_cmp + s_or_b64 pairs: five instructions a step):
+// u = the largest offset of u2's high word from that of 1.5 (NaN, inf, negative and out-of-range values land above the
+// offset of 700 as unsigned numbers), d = the largest high word of |d| (NaN above everything).
+struct Ekf4Verdict {
+    unsigned u = 0u, d = 0u;
+    CGP_DEV unsigned long long uncommon() const {          // wave mask of the lanes that left the speculative regime
+        return __builtin_amdgcn_ballot_w64(u > 0x008DDFFFu) | __builtin_amdgcn_ballot_w64(d >= 0x3F800000u);      // u2 outside [1.5, 700), |d| >= 2^-7
+    }
+};
 template <int E1>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
-                                  double& innov, unsigned long long* uncommon) {
+                                  double& innov, Ekf4Verdict& verdict) {
     const double u2 = x.u2();
     const double t = exp_neg_lean(R, u2);
     const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
@@ -169,7 +176,9 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
     const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
     const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
     const unsigned hx = (unsigned)__double2hiint(u2) - 0x3FF80000u;                  // 1.5 -> 0, 700 -> 0x008DDFFF
-    *uncommon |= __builtin_amdgcn_ballot_w64(hx > 0x008DDFFFu) | __builtin_amdgcn_ballot_w64(!(fabs(d) <= 0x1p-7));
+    const unsigned hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
+    verdict.u = verdict.u > hx ? verdict.u : hx;
+    verdict.d = verdict.d > hd ? verdict.d : hd;
     a.th += d; a.c1 = c1; a.s1 = s1;
     ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
@@ -262,13 +271,16 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         if (checked_left == 0) {
             Ekf4Anchor anchor;
             ekf4_anchor(K, x.u2(), anchor);
-            auto one = [&](int slot, double y) {
+            Ekf4Verdict verdict;
+            // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in the
+            // instruction's immediate offset (the compiler folds the constant added to the vector offset) -- no scalar add per step
+            auto one = [&](int slot, unsigned k, double y) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, y, x, anchor, S, innov, &uncommon);
-                park[slot * kParkStride] = make_double2(S, innov);
+                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, y, x, anchor, S, innov, verdict);
+                park[(slot + k) * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store_s(x.P, p_off, t * 128u);
-                mfs.store_s(x.uq, m_off, t * 32u);
+                Pfs.store_s(x.P, p_off + k * 128u, t * 128u);
+                mfs.store_s(x.uq, m_off + k * 32u, t * 32u);
             };
             // The step's measurement: the chunk's 64 values go to LDS once, and every group of four steps reads its four with
             // two broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
@@ -279,10 +291,11 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
             for (; slot + 4 <= nsteps; slot += 4) {
                 const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
-                one(slot, ya.x); one(slot + 1, ya.y); one(slot + 2, yb.x); one(slot + 3, yb.y);
+                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
                 ya = na; yb = nb;
             }
-            for (; slot < nsteps; slot++) one(slot, readlane_f64(ychunk, slot));
+            for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
+            uncommon = verdict.uncommon();
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
@@ -505,9 +518,10 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
         if (checked_left == 0) {
             Ekf4Anchor anchor;
             ekf4_anchor_lane(K, x.u2(), anchor);
+            Ekf4Verdict verdict;
             auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 1 : 0>(K, R, ych[b][slot], x, anchor, S, innov, &uncommon);
+                ekf4_mfma_step_spec1<E1 ? 1 : 0>(K, R, ych[b][slot], x, anchor, S, innov, verdict);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_base, t * 128u);              // the step's row offset rides in the scalar offset
@@ -518,6 +532,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
                 CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
             }
             for (; slot < nsteps; slot++) one(slot);
+            uncommon = verdict.uncommon();
         }
         const bool redo = uncommon != 0;
         if (checked_left > 0 || redo) {
