@@ -355,7 +355,7 @@ constexpr double kLog1pOverTLean[8] = {0.999999999990116, -0.49999999432118947, 
 // step wants the rotation angle scale * softplus, so the scale rides in the coefficients: one multiply less on the chain).
 struct SpecRegs {
     double ex[8], lq[8];
-    double log2e, ln2hi, ln2lo;
+    double log2e, ln2hi, ln2lo, ln2;
     double s3, s5, c4, c6;       // -1/6, 1/120, 1/24, -1/720
     // PIN = false leaves the values as ordinary constants the compiler may rematerialise: fewer live registers, a few
     // more moves -- the trade for a kernel that wants two waves per SIMD rather than the shortest chain
@@ -363,7 +363,7 @@ struct SpecRegs {
         auto keep = [](double v) { return PIN ? FastMathRegs::pin(v) : v; };
         CGP_UNROLL for (int i = 0; i < 8; i++) ex[i] = keep(kExpLean[i]);
         CGP_UNROLL for (int i = 0; i < 8; i++) lq[i] = keep(kLog1pOverTLean[i] * scale);
-        log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo);
+        log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo); ln2 = keep(kLn2Hi + kLn2Lo);
         s3 = keep(-1.0 / 6.0); s5 = keep(1.0 / 120.0);
         c4 = keep(1.0 / 24.0); c6 = keep(-1.0 / 720.0);
     }
@@ -375,6 +375,21 @@ CGP_DEV double exp_neg_lean(const Regs& R, double x) {
     const double k = __builtin_rint(nx * R.log2e);
     double r = fma(-k, R.ln2hi, nx);
     r = fma(-k, R.ln2lo, r);
+    const double r2 = r * r;
+    const double a0 = horner(R.ex[1], r, R.ex[0]), a1 = horner(R.ex[3], r, R.ex[2]);
+    const double a2 = horner(R.ex[5], r, R.ex[4]), a3 = horner(R.ex[7], r, R.ex[6]);
+    const double r4 = r2 * r2;
+    const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2);
+    return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
+}
+// The same with a ONE-constant range reduction, r = -x - k ln2 with ln2 rounded to double: the reduction's error is
+// k ulp(ln2) / 2 <= 6e-14 absolute for x < 700 (k <= 1010), 2e-15 for the x < 20 of a chirp's frequency state -- far inside
+// the lean polynomial's own 1e-10.  One vector instruction less on a step that is bound by instruction issue.
+template <class Regs>
+CGP_DEV double exp_neg_lean1(const Regs& R, double x) {
+    const double nx = -x;
+    const double k = __builtin_rint(nx * R.log2e);
+    const double r = fma(-k, R.ln2, nx);
     const double r2 = r * r;
     const double a0 = horner(R.ex[1], r, R.ex[0]), a1 = horner(R.ex[3], r, R.ex[2]);
     const double a2 = horner(R.ex[5], r, R.ex[4]), a3 = horner(R.ex[7], r, R.ex[6]);

@@ -82,8 +82,7 @@ struct Ekf4State {
 // v_readlane) is three instructions shorter but one matrix instruction deeper, and measured 2.64 against 2.60 ms -- the
 // linear filter, whose step is the tail alone, takes that form and gains 4 % (kf4_mfma_trial).
 template <int E1 = 0>
-CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
-    const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
+CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, double dsp, Ekf4State& x, double& S, double& innov) {
     const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
     const double kjd = K.kja * dsp;
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
@@ -117,6 +116,11 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
     x.ur = fma(PHr, g, f_r);                                    // mf = mp + K innov, in both layouts
     x.uq = fma(PHq, g, f_q);
 }
+template <int E1 = 0>
+CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
+    const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
+    ekf4_mfma_finish_j<E1>(K, y, J0T, dsp, x, S, innov);
+}
 
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
 template <int E1 = 0>
@@ -138,13 +142,26 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
 // of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-7 (or NaN) marks
 // the chunk's verdict (Ekf4Verdict) and the whole chunk is repeated with the checked step.
-struct Ekf4Anchor { double th, c1, s1; };
+//
+// What is rotated is not (cos, sin) but the rotating part of this lane's entry of J0 and its quarter-turn partner,
+//     A = rho (kc cos + ks sin) = J0[q][r] - kk,     B = rho (ks cos - kc sin):     A' = cd A + sd B,   B' = cd B - sd A
+// (both zero outside the rotation block): five operations give the next J0 entry A' + kk, where rotating (cos, sin) and then
+// forming the entry took six.
+struct Ekf4Anchor {
+    double th, A, B;
+    CGP_DEV void set(const Ekf4MfmaConst& K, double th_, double c1, double s1) {
+        th = th_;
+        A = fma(K.kcr, c1, K.ksr * s1);
+        B = fma(K.ksr, c1, -(K.kcr * s1));
+    }
+};
 
 CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
-    double sp, dsp;
+    double sp, dsp, s1, c1;
     softplus_pair_uniform(u2, sp, dsp);
-    a.th = K.ang * sp;
-    fast_sincos_uniform(a.th, a.s1, a.c1);
+    const double th = K.ang * sp;
+    fast_sincos_uniform(th, s1, c1);
+    a.set(K, th, c1, s1);
 }
 
 // Round 3 made the step five vector instructions shorter:
@@ -166,7 +183,7 @@ template <int E1>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                   double& innov, Ekf4Verdict& verdict) {
     const double u2 = x.u2();
-    const double t = exp_neg_lean(R, u2);
+    const double t = exp_neg_lean1(R, u2);
     const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
     double qa, dsp;
     softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
@@ -174,13 +191,13 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
     const double d2 = d * d, d4 = d2 * d2;
     const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
     const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
-    const double c1 = fma(a.c1, cd, -a.s1 * sd), s1 = fma(a.s1, cd, a.c1 * sd);
+    const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
     const unsigned hx = (unsigned)__double2hiint(u2) - 0x3FF80000u;                  // 1.5 -> 0, 700 -> 0x008DDFFF
     const unsigned hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
-    a.th += d; a.c1 = c1; a.s1 = s1;
-    ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
+    a.th += d; a.A = A; a.B = B;
+    ekf4_mfma_finish_j<E1>(K, y, A + K.kk, dsp, x, S, innov);
 }
 
 // Tried with it and dropped (all measured on the bench configuration, same box, A/B): the step's measurement through LDS
@@ -447,10 +464,11 @@ CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4S
     ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
 CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
-    double sp, dsp;
+    double sp, dsp, s1, c1;
     softplus_pair_wide(u2, sp, dsp);
-    a.th = K.ang * sp;
-    fast_sincos(a.th, a.s1, a.c1);
+    const double th = K.ang * sp;
+    fast_sincos(th, s1, c1);
+    a.set(K, th, c1, s1);
 }
 
 // DENSE = false: constants pinned, 297 registers, one wave per SIMD (the dispatcher then has to spread the waves over all
