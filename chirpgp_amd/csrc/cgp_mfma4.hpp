@@ -44,7 +44,8 @@ struct Ekf4MfmaConst {
     double kc, ks, kj, kk;                     // J[q][r] = kc c + ks s + kk + kj dth f[q ^ 1]  (kj = -1 at (0, 2), +1 at (1, 2))
     double SigHq, c0;                          // H = e_1 form of the update: Sigma[1][q], Sigma[1][1] + Xi
     double kcr, ksr, kja;                      // kc rho, ks rho, kj ang: the damping and the angle scale ride in the per-lane coefficients
-    CGP_DEV void fold() { kcr = kc * rho; ksr = ks * rho; kja = kj * ang; }
+    double angm;                               // ang in the lanes of the rotation block, 0 elsewhere (see Ekf4Anchor)
+    CGP_DEV void fold() { kcr = kc * rho; ksr = ks * rho; kja = kj * ang; angm = (kc != 0.0 || ks != 0.0) ? ang : 0.0; }
 };
 // The mean is distributed like the covariance: ur = u[r] (row layout) and uq = u[q] (column layout) at lane (r, q); the
 // frequency state u[2] every lane needs is one quad broadcast of uq.
@@ -143,15 +144,17 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-7 (or NaN) marks
 // the chunk's verdict (Ekf4Verdict) and the whole chunk is repeated with the checked step.
 //
-// What is rotated is not (cos, sin) but the rotating part of this lane's entry of J0 and its quarter-turn partner,
-//     A = rho (kc cos + ks sin) = J0[q][r] - kk,     B = rho (ks cos - kc sin):     A' = cd A + sd B,   B' = cd B - sd A
-// (both zero outside the rotation block): five operations give the next J0 entry A' + kk, where rotating (cos, sin) and then
-// forming the entry took six.
+// What is rotated is not (cos, sin) but this lane's entry of J0 itself and its quarter-turn partner,
+//     A = rho (kc cos + ks sin) + kk = J0[q][r],     B = rho (ks cos - kc sin):     A' = cd A + sd B,   B' = cd B - sd A:
+// four operations give the next J0 entry directly, where rotating (cos, sin) and then forming the entry took six.  In the
+// lanes outside the rotation block (A = kk or 0, B = 0) the increment d is ZERO, hence sd = 0, cd = 1 and A' = A: the angle
+// scale rides in per-lane coefficients (K.angm and the polynomial of SpecRegs::init(K.angm)) that vanish there, at no cost.
+// (The verdict on |d| is taken over the wavefront, so the lanes of the rotation block speak for it.)
 struct Ekf4Anchor {
     double th, A, B;
-    CGP_DEV void set(const Ekf4MfmaConst& K, double th_, double c1, double s1) {
-        th = th_;
-        A = fma(K.kcr, c1, K.ksr * s1);
+    CGP_DEV void set(const Ekf4MfmaConst& K, double sp, double c1, double s1) {      // sp = softplus(u2): theta = ang sp
+        th = K.angm * sp;
+        A = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));
         B = fma(K.ksr, c1, -(K.kcr * s1));
     }
 };
@@ -159,9 +162,8 @@ struct Ekf4Anchor {
 CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
     double sp, dsp, s1, c1;
     softplus_pair_uniform(u2, sp, dsp);
-    const double th = K.ang * sp;
-    fast_sincos_uniform(th, s1, c1);
-    a.set(K, th, c1, s1);
+    fast_sincos_uniform(K.ang * sp, s1, c1);
+    a.set(K, sp, c1, s1);
 }
 
 // Round 3 made the step five vector instructions shorter:
@@ -184,7 +186,7 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
                                   double& innov, Ekf4Verdict& verdict) {
     const double u2 = x.u2();
     const double t = exp_neg_lean1(R, u2);
-    const double lin = fma(K.ang, u2, -a.th);                                        // off the chain: needs u2 only
+    const double lin = fma(K.angm, u2, -a.th);                                       // off the chain: needs u2 only
     double qa, dsp;
     softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
     const double d = fma(qa, t, lin);
@@ -197,7 +199,7 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
     a.th += d; a.A = A; a.B = B;
-    ekf4_mfma_finish_j<E1>(K, y, A + K.kk, dsp, x, S, innov);
+    ekf4_mfma_finish_j<E1>(K, y, A, dsp, x, S, innov);
 }
 
 // Tried with it and dropped (all measured on the bench configuration, same box, A/B): the step's measurement through LDS
@@ -263,7 +265,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const unsigned m_off = (lane < 4) ? 8u * lane : kOobOffset;
 
     SpecRegs R;
-    R.init(K.ang);
+    R.init(K.angm);
     // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
@@ -466,9 +468,8 @@ CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4S
 CGP_DEV void ekf4_anchor_lane(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
     double sp, dsp, s1, c1;
     softplus_pair_wide(u2, sp, dsp);
-    const double th = K.ang * sp;
-    fast_sincos(th, s1, c1);
-    a.set(K, th, c1, s1);
+    fast_sincos(K.ang * sp, s1, c1);
+    a.set(K, sp, c1, s1);
 }
 
 // DENSE = false: constants pinned, 297 registers, one wave per SIMD (the dispatcher then has to spread the waves over all
@@ -518,7 +519,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
     const bool want_nll = io.nll != nullptr;
 
     SpecRegs R;
-    R.init<!DENSE>(K.ang);
+    R.init<!DENSE>(K.angm);
     __shared__ double ych[4][64];
     __shared__ double2 park[4][64];
     double cum[4] = {0.0, 0.0, 0.0, 0.0};
