@@ -373,6 +373,7 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const unsigned m_off = (lane < 4) ? 8u * lane : kOobOffset;
 
     __shared__ double2 park[64];
+    __shared__ double ybuf[64 + 8];
     double cum = 0.0;
     double ynext = (lane < T) ? ys[lane] : 0.0;                                  // one chunk ahead (see ekf4_mfma_trial)
     for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -381,8 +382,7 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         ynext = (t0 + 64 + lane < T) ? ys[t0 + 64 + lane] : 0.0;
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         wave_lds_fence();
-        auto one = [&](int slot) {
-            const double y = readlane_f64(ychunk, slot);
+        auto one = [&](int slot, double y) {
             const double f_r = mfma4(JT, ur, 0.0), f_q = mfma4(ur, JT, 0.0);   // F u by row and by column
             const double Q = mfma4(P, JT, 0.0);                                  // P F^T
             double Pp, PHr, PHq, S, innov;
@@ -409,11 +409,16 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             Pfs.store_s(P, p_off, t * 128u);
             mfs.store_s(uq, m_off, t * 32u);
         };
+        ybuf[lane] = ychunk;                                                     // measurements through LDS, as in ekf4_mfma_trial
+        wave_lds_fence();
         int slot = 0;
-        for (; slot + kEkf4Unroll <= nsteps; slot += kEkf4Unroll) {
-            CGP_UNROLL for (int k = 0; k < kEkf4Unroll; k++) one(slot + k);
+        double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
+        for (; slot + 4 <= nsteps; slot += 4) {
+            const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
+            one(slot, ya.x); one(slot + 1, ya.y); one(slot + 2, yb.x); one(slot + 3, yb.y);
+            ya = na; yb = nb;
         }
-        for (; slot < nsteps; slot++) one(slot);
+        for (; slot < nsteps; slot++) one(slot, readlane_f64(ychunk, slot));
         if (want_nll) {
             wave_lds_fence();
             const double2 si = park[lane < nsteps ? lane : 0];
