@@ -202,18 +202,17 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, dou
     ekf4_mfma_finish_j<E1>(K, y, A, dsp, x, S, innov);
 }
 
-// Tried with it and dropped (all measured on the bench configuration, same box, A/B): the step's measurement through LDS
-// (one broadcast ds_read a step ahead instead of two v_readlane: 2.69 against 2.65 ms), the max-ILP scheduling strategy for
-// this kernel once it is unrolled (2.72 against 2.65 ms; the other matrix-core kernels keep it), unrolling by 2 / 3 / 8 / 16
-// (2.70 / 2.70 / 2.65 / 2.68 ms).  What the instruction count alone buys is small -- the same step with 19 fewer vector
-// instructions but the old loop skeleton ran at 2.94 ms, as before: a step is the dependent chain softplus -> rotation ->
-// five matrix instructions -> 1 / S, and what matters is which instructions the scheduler can put into its bubbles.
-// Four steps per loop iteration let one step's trailing work (verdicts, stores, parking) overlap the next step's head.
-// Two chain-shortening variants measured SLOWER on top of the final kernel (2.57 ms): the rotation entries of the Jacobian as
-// a quartic in the angle increment with per-lane coefficients from the previous rotation pair (four dependent operations
-// fewer, nine instructions more: 2.77 ms), and the exponent argument -log2(e) u[2] formed beside the mean update instead of
-// behind its quad broadcast (two operations fewer, six instructions more: 2.73 ms).  A timing-only build without anything off
-// the chain (stores, parking, verdicts) runs at 2.37 ms: the dependent chain is 92 % of the step as it stands.
+// Tried with it and dropped (all measured on the bench configuration, same box, A/B): the max-ILP scheduling strategy for this
+// kernel once it is unrolled (2.72 against 2.65 ms; the other matrix-core kernels keep it; iterative-ilp / -minreg / -maxocc and
+// no post-RA scheduler: 2.64 - 2.73 against 2.59), unrolling by 2 / 3 / 8 / 16 (2.70 / 2.70 / 2.65 / 2.68 ms), the four steps as
+// one block in the order of a latency-driven list scheduler, pinned with scheduling barriers (tools/sched/ekf4_sched.py: 2.69
+// against 2.60), both lean polynomials in Horner form (four operations fewer, eight levels deeper: no change), the measurement
+// as ONE broadcast ds_read per step issued a step ahead (2.69 against 2.65; two ds_read_b128 per FOUR steps, a group ahead, are
+// what the kernel uses now: 2.58 -> 2.50).  Two chain-shortening variants that ADD instructions measured slower (2.57 ms then):
+// the rotation entries of the Jacobian as a quartic in the angle increment with per-lane coefficients from the previous
+// rotation pair (four dependent operations fewer, nine instructions more: 2.77 ms), and the exponent argument -log2(e) u[2]
+// formed beside the mean update instead of behind its quad broadcast (two fewer, six more: 2.73 ms).  All of it fits one
+// picture: the step costs about the sum of its instructions' issue costs, and the order hardly matters.
 constexpr int kEkf4Unroll = 4;
 
 #ifdef CGP_EKF4_KERNELS      // the kernels are instantiated by cgp_inst_ekf4.hip alone; other units take the step functions
