@@ -838,3 +838,38 @@ def test_default_launch_shape_at_a_mid_size_batch(kind):
         ws = port.smoother(port.S_CD_SGP, dg, wl['sgps'], wl['dt'], wf[0], wf[1])
     for g, w, n in zip(tuple(x[sel] for x in f) + tuple(x[sel] for x in s), wf + ws, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
         cs.assert_close(g, w, 1e-7, f'{kind} B=5000 {n}')
+
+
+@pytest.mark.parametrize('kw', [pytest.param(WAVE, id='one_trial_per_wave'), pytest.param(WAVE_X4, id='four_trials_per_wave'),
+                                pytest.param(THREAD, id='lane_per_trial')])
+def test_measurement_vectors_other_than_the_chirp_builders(kw):
+    """The matrix-core EKF / KF kernels take a short form of the update when H = [0, 1, 0, 0] (every chirp builder's H: H
+    picks entries of Pp, cgp_mfma4.hpp) and the general form otherwise, chosen per wavefront.  A batch with a measurement
+    vector PER TRIAL -- e_1 in some, dense in others, so that the four-trials-per-wave kernel sees mixed wavefronts -- on the
+    chirp model (ekf + eks) and on a linear d = 4 model (kf + rts), against the C port."""
+    from oracle import port, np_filters as nf
+    fs = _fs()
+    B, T = 9, 300
+    c = _batch_case(cs.chirp_case, B, T=T)
+    rng = np.random.default_rng(77)
+    H = np.tile(np.array([0., 1., 0., 0.]), (B, 1))
+    H[[1, 2, 6]] = np.array([0.3, 1., -0.2, 0.1]) + 0.05 * rng.standard_normal((3, 4))
+    H[8] = np.array([0., 1., 0., 1e-3])                          # nearly e_1: must take the general form too
+    want = port.filter(port.F_EKF, c.disc, None, H, c.Xi, c.m0, c.P0, c.dt, c.ys)
+    got = fs.ekf(c.disc, H, c.Xi, c.m0, c.P0, c.dt, c.ys, **kw)
+    for g, w, nm in zip(got, want, ('mfs', 'Pfs', 'nll')):
+        cs.assert_close(g, w, RTOL, f'ekf, per-trial H: {nm}')
+    ws = port.smoother(port.S_EKS, c.disc, None, c.dt, want[0], want[1])
+    gs = fs.eks(c.disc, want[0], want[1], c.dt, **kw)
+    for g, w, nm in zip(gs, ws, ('mss', 'Pss')):
+        cs.assert_close(g, w, RTOL, f'eks: {nm}')
+    # linear model, d = 4: one H for the batch (kf takes a single model), e_1 and dense in turn
+    F = 0.9 * np.eye(4) + 0.04 * rng.standard_normal((4, 4))
+    Sigma = 0.1 * np.eye(4) + 0.01 * np.ones((4, 4))
+    ys = rng.standard_normal((5, T))
+    for Hl in (np.array([0., 1., 0., 0.]), np.array([0.4, -1., 0.2, 0.7])):
+        gf = fs.kf(F, Sigma, Hl, 0.3, np.zeros(4), np.eye(4), ys, **kw)
+        for b in range(ys.shape[0]):
+            wf = nf.kf(F, Sigma, Hl, 0.3, np.zeros(4), np.eye(4), ys[b])
+            for g, w in zip(gf, wf):
+                npt.assert_allclose(g[b], w, rtol=1e-9, atol=1e-12)
