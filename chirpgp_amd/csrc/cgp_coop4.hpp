@@ -31,6 +31,15 @@ template <int CTRL> CGP_DEV double dpp_f64(double x) {
     const int hi = dpp_i32<CTRL>(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
+// Lane N of every 16-lane row to all lanes of the row, as ONE 64-bit move (v_mov_b64_dpp row_newbcast:N; the double-precision
+// DPP of gfx90a+ takes no other control): 5 issue cycles where a quad_perm broadcast of a double is two v_mov_b32_dpp (8).
+// In the matrix-core layout lane = 16 r + 4 b + q of a kernel whose four MFMA blocks b are replicas, row_bcast_f64<q0> IS the
+// quad broadcast of lane q0 (it takes block 0's copy).
+template <int N> CGP_DEV double row_bcast_f64(double x) {
+    long long v = __builtin_bit_cast(long long, x);
+    long long r = __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xF, 0xF, false);     // (update_dpp would tie the result to a copy of its `old` operand)
+    return __builtin_bit_cast(double, r);
+}
 constexpr int kQuadBcast0 = 0x00, kQuadBcast1 = 0x55, kQuadBcast2 = 0xAA, kQuadBcast3 = 0xFF;
 constexpr int kQuadSwap1 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int kQuadSwap2 = 0x4E;   // quad_perm:[2,3,0,1]

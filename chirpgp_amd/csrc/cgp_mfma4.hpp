@@ -52,6 +52,7 @@ struct Ekf4MfmaConst {
 struct Ekf4State {
     double P, ur, uq;
     CGP_DEV double u2() const { return dpp_f64<kQuadBcast2>(uq); }
+    CGP_DEV double u2_replicated() const { return row_bcast_f64<2>(uq); }      // one trial per wavefront: the four blocks are replicas
 };
 
 // Everything of a step after the rotation (c1, s1) = (cos, sin)(theta) and the softplus derivative dsp are known -- the
@@ -89,18 +90,21 @@ CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, do
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
     double Pp, PHr, PHq;
     if constexpr (E1 != 0) {
+        // E1 == 2: one trial per wavefront, the four blocks are replicas -- a 64-bit row broadcast (one instruction) does
+        // what the quad broadcast (two) does when every block carries its own trial
+        auto bcast1 = [](double v) { if constexpr (E1 == 2) return row_bcast_f64<1>(v); else return dpp_f64<kQuadBcast1>(v); };
         const double Q = mfma4(x.P, RJT, 0.0);
-        const double Pa = dpp_f64<kQuadBcast1>(Q);                     // (P a)[r] = Q[r][1], a = J^T H = row 1 of J
+        const double Pa = bcast1(Q);                                   // (P a)[r] = Q[r][1], a = J^T H = row 1 of J
         Pp = mfma4(RJT, Q, K.Sig);
         PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q], beside Pp
-        PHr = dpp_f64<kQuadBcast1>(Pp);                                // Pp[r][1]
+        PHr = bcast1(Pp);                                              // Pp[r][1]
         if constexpr (E1 == 1) {
             const double a = dpp_f64<kQuadBcast1>(RJT);                // a[r] = J[1][r]
             S = mfma4(a, Pa, K.c0);                                    // a . (P a) + Sigma_11 + Xi, per MFMA block
         } else {
             S = readlane_f64(Pp, 17) + K.Xi;                           // lane (r, b, q) = (1, 0, 1)
         }
-        innov = y - dpp_f64<kQuadBcast1>(f_q);                         // H . f = f[1]
+        innov = y - bcast1(f_q);                                       // H . f = f[1]
     } else {
         // ---- predict: Pp = J P J^T + Sigma
         const double Q = mfma4(x.P, RJT, 0.0);
@@ -184,7 +188,7 @@ struct Ekf4Verdict {
 template <int E1>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
                                   double& innov, Ekf4Verdict& verdict) {
-    const double u2 = x.u2();
+    const double u2 = (E1 == 2) ? x.u2_replicated() : x.u2();
     const double t = exp_neg_lean1(R, u2);
     const double lin = fma(K.angm, u2, -a.th);                                       // off the chain: needs u2 only
     double qa, dsp;
@@ -388,7 +392,7 @@ CGP_DEV void kf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             if constexpr (E1) {                                                  // see ekf4_mfma_finish: five matrix instructions
                 Pp = mfma4(JT, Q, Sig);
                 PHq = mfma4(Hr, Pp, 0.0);
-                PHr = dpp_f64<kQuadBcast1>(Pp);
+                PHr = dpp_f64<kQuadBcast1>(Pp);                                  // (64-bit row broadcasts, which serve the EKF: 1.26 against 1.23 ms here)
                 S = dpp_f64<kQuadBcast1>(PHq) + Xi;
                 innov = y - dpp_f64<kQuadBcast1>(f_q);
             } else {

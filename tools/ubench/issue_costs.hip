@@ -24,6 +24,8 @@ template <int KIND, int N> __global__ void k(double* out, long long* cyc, int n)
             if (KIND == 9) xi[j] = __builtin_amdgcn_mov_dpp(xi[j], 0x55, 0xf, 0xf, false);
             if (KIND == 10) xi[j] = xi[j] + i;
             if (KIND == 11) x[j] = fma(x[j], -0.5, 1.0);
+            if (KIND == 12) { long long v = __builtin_bit_cast(long long, x[j]); v = __builtin_amdgcn_update_dpp(v, v, 0x151, 0xf, 0xf, false); x[j] = __builtin_bit_cast(double, v); }
+            if (KIND == 13) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(x[j]) : "v"(a), "v"(c));
         }
 #pragma unroll
         for (int j = 0; j < N; j++) { asm volatile("" : "+v"(x[j])); asm volatile("" : "+v"(xi[j])); }
@@ -42,9 +44,9 @@ template <int KIND, int N> double run(double* out, long long* cyc) {
 int main() {
     double* out; long long* cyc;
     (void)hipMalloc(&out, 64 * sizeof(double)); (void)hipMalloc(&cyc, 8);
-    const char* names[12] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64 + v_add_u32", "v_readlane_b32 + v_add_u32",
-                             "v_max_f64", "v_mov_b32 dpp", "v_add_u32 (SGPR operand)", "v_fma_f64 inline constants"};
+    const char* names[14] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64 + v_add_u32", "v_readlane_b32 + v_add_u32",
+                             "v_max_f64", "v_mov_b32 dpp", "v_add_u32 (SGPR operand)", "v_fma_f64 inline constants", "v_mov_b64 dpp row_newbcast", "v_fmac_f64 dpp row_newbcast"};
 #define ROW(K) printf("%-28s %6.2f ticks per instruction (N = 8: %6.1f, N = 24: %6.1f)\n", names[K], (run<K, 24>(out, cyc) - run<K, 8>(out, cyc)) / 16.0, run<K, 8>(out, cyc), run<K, 24>(out, cyc));
-    ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
+    ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13)
     return 0;
 }
