@@ -84,7 +84,7 @@ CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneC
     Sym<4> l; double sd[3], dv[4];
     mfma4_factor(P, l, sd, dv);
     sd[2] += (dv[3] > 0.0) ? 0.0 : __builtin_nan("");
-    const double m0 = dpp_f64<kQuadBcast0>(mcol), m1 = dpp_f64<kQuadBcast1>(mcol), m2 = dpp_f64<kQuadBcast2>(mcol), m3 = dpp_f64<kQuadBcast3>(mcol);
+    const double m0 = row_bcast_f64<0>(mcol), m1 = row_bcast_f64<1>(mcol), m2 = row_bcast_f64<2>(mcol), m3 = row_bcast_f64<3>(mcol);
     double a[2], wd[2]; bool ok;
     cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) cd4_mfma_fan<false, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
@@ -97,7 +97,7 @@ CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneC
     C = blk_allreduce(C);                                                // sum_p W d_r a_q   (columns 0, 1; zero elsewhere)
     F = blk_allreduce(F);                                                // sum_p W a_q, in every row (zero for q >= 2)
     kmcol = fma(K.cc2, m2, fma(K.cc3, m3, F));                           // E[a_2] = m_3, E[a_3] = -g^2 m_2 - 2 g m_3: the closed-form columns' coefficients
-    const double P2 = dpp_f64<kQuadBcast2>(P), P3 = dpp_f64<kQuadBcast3>(P);      // P[r][2], P[r][3]
+    const double P2 = row_bcast_f64<2>(P), P3 = row_bcast_f64<3>(P);      // P[r][2], P[r][3]
     const double Cf = C + fma(K.cc2, P2, K.cc3 * P3);
     kP = mfma4x4(Cf, K.ident, Cf + K.gam);                               // C^T + (C + gamma)
 }
@@ -288,7 +288,7 @@ struct Cd4JacCoef {
 };
 // a(m) in column form and the lane's entry of J^T at the mean (column form in, quad broadcasts).
 CGP_DEV void cd4_ekf_eval(const SoftplusRegs& R, const Cd4LaneCoef& K, const Cd4JacCoef& Jc, double fs, double mcol, double& acol, double& JT) {
-    const double m0 = dpp_f64<kQuadBcast0>(mcol), m1 = dpp_f64<kQuadBcast1>(mcol), m2 = dpp_f64<kQuadBcast2>(mcol), m3 = dpp_f64<kQuadBcast3>(mcol);
+    const double m0 = row_bcast_f64<0>(mcol), m1 = row_bcast_f64<1>(mcol), m2 = row_bcast_f64<2>(mcol), m3 = row_bcast_f64<3>(mcol);
     double sp, dsp;
     softplus_pair_uniform(R, m2, sp, dsp);
     const double w = (kTwoPi * sp) * fs, dw = (kTwoPi * dsp) * fs;

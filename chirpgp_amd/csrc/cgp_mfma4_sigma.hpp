@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             }
             Y = blk_allreduce(Y);                                        // sum_p W z_r z_q
             F = blk_allreduce(F);                                        // sum_p W z_q, in every row r
-            const double f0 = dpp_f64<kQuadBcast0>(F), f1 = dpp_f64<kQuadBcast1>(F);
+            const double f0 = row_bcast_f64<0>(F), f1 = row_bcast_f64<1>(F);
             const double f2 = fma(M0, u2, M1 * u3), f3 = fma(M2, u2, M3 * u3);
             const double Fr = fma(cr0, f0, cr1 * f1);
             const double Pp = fma(-Fr, mq * F, Y) + fma(l33sq, K1, Sig);
@@ -196,10 +196,10 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             const double rS = rcp_nr1(S);
             P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
             const double g = rS * innov;
-            u0 = fma(dpp_f64<kQuadBcast0>(PHc), g, f0);                  // mf = mp + K innov
-            u1 = fma(dpp_f64<kQuadBcast1>(PHc), g, f1);
-            u2 = fma(dpp_f64<kQuadBcast2>(PHc), g, f2);
-            u3 = fma(dpp_f64<kQuadBcast3>(PHc), g, f3);
+            u0 = fma(row_bcast_f64<0>(PHc), g, f0);                  // mf = mp + K innov
+            u1 = fma(row_bcast_f64<1>(PHc), g, f1);
+            u2 = fma(row_bcast_f64<2>(PHc), g, f2);
+            u3 = fma(row_bcast_f64<3>(PHc), g, f3);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
             wP.store(P, t * 128u + offP);
             wm.store2(u0, u1, t * 32u + offm);
