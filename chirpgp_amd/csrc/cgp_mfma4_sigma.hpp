@@ -100,6 +100,7 @@ template <class DM, bool TWO>
 __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
     static_assert(DM::D == 4, "d = 4 kernel");
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
+    __shared__ double ybuf[64 + 2];                                      // the chunk's measurements (+ the read-ahead past the last)
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int64_t trial = blockIdx.x;
@@ -159,9 +160,15 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        // the chunk's measurements go through LDS: one broadcast ds_read_b64 per step, issued a step ahead, where a v_readlane
+        // pair costs 24 issue cycles (tools/ubench/issue_costs.hip)
+        ybuf[lane] = ychunk;
+        wave_lds_fence();
+        double ynext = ybuf[0];
         for (int slot = 0; slot < nsteps; slot++) {
             const unsigned t = (unsigned)(t0 + slot);
-            const double y = readlane_f64(ychunk, slot);
+            const double y = ynext;
+            ynext = ybuf[slot + 1];
             // ---- sigma-point prediction (filters_smoothers.py:88-121)
             // A pivot <= 0 or NaN turns its square root -- for the last one, which only enters squared, the pivot itself --
             // into NaN, and with it every output of this and all later steps, as the reference's NaN factor does
