@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
     __shared__ __attribute__((aligned(16))) double pbuf[64 + 8 + 64];  // the covariance row-major (pitch 8), the mean, a dump for the lanes without a mean entry
     __shared__ double2 park[64];
+    __shared__ double ybuf[64 + 2];                                      // the chunk's measurements (+ the read-ahead past the last)
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -189,9 +190,13 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
         double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        ybuf[lane] = ychunk;
+        wave_lds_fence();
+        double ynext = ybuf[0];
         for (int slot = 0; slot < nsteps; slot++) {
             const unsigned t = (unsigned)(t0 + slot);
-            const double y = readlane_f64(ychunk, slot);
+            const double y = ynext;                                      // through LDS, a step ahead (a v_readlane pair costs 24 issue cycles)
+            ynext = ybuf[slot + 1];
             // ---- distributed (Pf, mf) -> every lane: through LDS, read back as broadcasts
             pbuf[i * 8 + j] = P;
             pbuf[mslot] = mrow;                                          // the lanes without a mean entry write to their dump slot: no branch
@@ -344,7 +349,7 @@ __global__ void __launch_bounds__(64) ekf8_coop_kernel(FilterIO io, ModelArgs ma
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         for (int slot = 0; slot < nsteps; slot++) {
             const unsigned t = (unsigned)(t0 + slot);
-            const double y = readlane_f64(ychunk, slot);
+            const double y = readlane_f64(ychunk, slot);                 // (through LDS as in sgp8_coop_kernel: 5.26 against 5.00 ms here)
             // ---- wave-uniform scalar chain: rotations at the frequency g(u_v) (models.py:370-376)
             const double uv = readlane_f64(mrow, kVLane);
             // evaluated without regime branches (lean softplus on [1.5, 700), sin / cos on the reduced range |x| <= pi/4 in
