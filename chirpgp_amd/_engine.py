@@ -20,7 +20,15 @@ NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNE
 LITERAL_SIGMA_SUM, DPP_KERNEL, FOUR_TRIALS_PER_WAVE, ONE_TRIAL_PER_WAVE = 0x40, 0x80, 0x200, 0x400
 TIME_SPLIT, NO_TIME_SPLIT = 0x800, 0x1000
 SIGMA_STANDARD = 0x1
-MAX_D = 8
+MAX_D = 12            # include/chirpgp_hip.h: CGP_MAX_D (9 .. 12: the harmonic LCD model with 4 or 5 harmonics)
+
+
+def _check_dimension(spec):
+    d = int(spec.d)
+    limit = MAX_D if int(spec.model_id) == M_HARMONIC_LCD else 8
+    if d > limit:
+        raise NotImplementedError(f'state dimension {d} > {limit} is not compiled into libchirpgp_hip.so for this model')
+    return d
 
 _vp = C.c_void_p
 
@@ -317,9 +325,7 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         if idx_h.size and (idx_h.min() < 0 or idx_h.max() >= R):
             raise ValueError(f'record_index outside 0..{R - 1}')
     B = (R if idx_h is None else int(idx_h.size)) * rep
-    d = int(spec.d)
-    if d > MAX_D:
-        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    d = _check_dimension(spec)
     # constants, stream, outputs and the launch all belong to the device the data lives on, whatever the current one is
     with torch.cuda.device(ys_d.device):
         ctx = context(ys_d.device.index)
@@ -357,8 +363,7 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
     B, T, d = (int(s) for s in m.shape)
     if d != int(spec.d):
         raise ValueError(f'model dimension {spec.d} != data dimension {d}')
-    if d > MAX_D:
-        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    _check_dimension(spec)
     with torch.cuda.device(m.device):
         ctx = context(m.device.index)
         keep = [m, P]
@@ -433,9 +438,7 @@ def _init_struct(H, Xi, m0, P0, d, B, keep):
 def run_simulate(spec, H, Xi, m0, P0, dt, T, seed, B, trial0=0, want=(True, True), flags=0, device=None):
     """cgp_simulate: B trajectories xs (B, T, d) and measurements ys (B, T) as CUDA tensors (None where not wanted)."""
     torch = _torch()
-    d = int(spec.d)
-    if d > MAX_D:
-        raise NotImplementedError(f'state dimension {d} > {MAX_D} is not compiled into libchirpgp_hip.so')
+    d = _check_dimension(spec)
     B, T = int(B), int(T)
     with torch.cuda.device(torch.cuda.current_device() if device is None else device):
         ctx = context(device)

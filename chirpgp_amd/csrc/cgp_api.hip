@@ -36,7 +36,9 @@ static bool choose_wave(const cgp_ctx* ctx, int64_t B, uint32_t flags, ShapeLimi
 
 static int check_model(cgp_ctx* ctx, const cgp_model* m, bool sde, bool need_sigma, const cgp_sigma* sg) {
     if (!m || !m->params) return fail(ctx, CGP_E_ARG, "model or model.params is NULL");
-    if (m->d < 1 || m->d > CGP_MAX_D) return fail(ctx, CGP_E_UNSUPPORTED, "state dimension outside 1.." + std::to_string(CGP_MAX_D));
+    // dimensions above 8 are compiled in for the harmonic LCD model alone (4 and 5 harmonics: d = 10, 12)
+    const int max_d = (m->model_id == CGP_M_HARMONIC_LCD) ? CGP_MAX_D : 8;
+    if (m->d < 1 || m->d > max_d) return fail(ctx, CGP_E_UNSUPPORTED, "state dimension outside 1.." + std::to_string(max_d) + " for this model");
     int want_params = -1, want_d = m->d;
     switch (m->model_id) {
     case CGP_M_LINEAR: case CGP_M_KPT: want_params = 2 * m->d * m->d; if (m->model_id == CGP_M_KPT) want_d = m->n_harm + 2; break;

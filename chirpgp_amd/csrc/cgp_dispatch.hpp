@@ -7,7 +7,7 @@ namespace cgp {
 // Largest state dimension for which the time-parallel smoother (30 / 108 doubles of affine map per lane at d = 4 / 8)
 // is instantiated.
 #ifndef CGP_TP_MAX_D
-#define CGP_TP_MAX_D 8
+#define CGP_TP_MAX_D 12
 #endif
 
 // d >= 6 harmonic models, one lane per fan: the collapsed quadrature is a compile-time property of the kernel (cgp_steps.hpp).

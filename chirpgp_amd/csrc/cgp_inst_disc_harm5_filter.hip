@@ -1,0 +1,8 @@
+// Harmonic chirp LCD model with 5 harmonics (d = 12: the reference's bat-call analyses, real_applications/bats/), filters on the
+// generic kernels -- a translation unit of its own to keep the build parallel.
+#include "cgp_dispatch.hpp"
+namespace cgp {
+int dispatch_filter_disc_harm5(int method, bool wave, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    return filter_disc<HarmonicLCD<5>>(method, wave, io, ma, st);
+}
+}  // namespace cgp

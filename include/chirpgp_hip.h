@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define CGP_VERSION 110          /* 0.1.1: measurement records may be shared between trials (cgp_filter) */
-#define CGP_MAX_D   8            /* largest state dimension compiled in */
+#define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
 

@@ -84,3 +84,14 @@ def test_mc_mle_sharded_over_two_ranks_equals_one_process(tmp_path):
     m2 = re.search(r'RMSE ([0-9.]+) \+- ([0-9.]+)', line2)
     assert m1 and m2, (line1, line2)
     assert m1.group(1) == m2.group(1) and m1.group(2) == m2.group(2), (line1, line2)
+
+
+def test_print_time_and_bats_shape_scripts():
+    """Counterparts of paper_plots_tables/print_time.py and of the bat-call analyses' timed section
+    (real_applications/bats/myotis_myotis_analysis.py:76-85), shortened: they run, time a pass and, for the bat shape,
+    follow the sweep."""
+    import print_time
+    import bats_shape
+    assert 0.0 < print_time.main(['--T', '1200', '--maxiter', '30']) < 5.0
+    elapsed, err = bats_shape.main(['--T', '3000'])
+    assert 0.0 < elapsed < 5.0 and err < 1500.0

@@ -873,3 +873,51 @@ def test_measurement_vectors_other_than_the_chirp_builders(kw):
             wf = nf.kf(F, Sigma, Hl, 0.3, np.zeros(4), np.eye(4), ys[b])
             for g, w in zip(gf, wf):
                 npt.assert_allclose(g[b], w, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('nh', [4, 5])
+def test_four_and_five_harmonics_the_bat_call_models(nh):
+    """The reference's real applications run the harmonic chirp model with 4 and 5 harmonics (d = 10, 12) through the
+    cubature filter and smoother (real_applications/bats/myotis_myotis_analysis.py:50-74, eptesicus_nilssonii_analysis.py:49-73;
+    frequency state scaled by 1e4, Xi = 1e-4).  Those dimensions run on the generic kernels: parity with the C port for
+    ekf / eks / sgp_filter / sgp_smoother, one wavefront and one lane per trial, a batch of three records."""
+    c = _batch_case(cs.harmonic_case, 3, T=180, nh=nh)
+    only = ('ekf', 'eks', 'sgp_filter', 'sgp_smoother')
+    want = bk.run_pairs('port', c, only=only)
+    for kw in (WAVE, THREAD):
+        got = bk.run_pairs('hip', c, hip_kw=kw, only=only)
+        bk.compare(got, want, RTOL, f'nh={nh}')
+
+
+def _bat_like_record(T, nh, seed, fs=250000.):
+    """A downward sweep 31 -> 22 kHz with nh harmonics sampled at 250 kHz, normalised like the reference's recordings
+    (real_applications/bats/myotis_myotis_analysis.py:44-46); the recordings themselves are not part of the reference."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(1, T + 1) / fs
+    f = 2.2e4 * (1 + 0.4 * np.exp(-3 * t / t[-1]))
+    phase = 2 * np.pi * np.cumsum(f) / fs
+    ys = sum(0.5 ** k * np.sin((k + 1) * phase) for k in range(nh))
+    return ys / np.max(np.abs(ys)) + 1e-2 * rng.standard_normal(T), f
+
+
+def test_bat_call_parameters_track_the_sweep():
+    """The bat-call application's own set-up -- 4 harmonics, frequency state scaled by 1e4, Xi = 1e-4, sigma = 10, ell = 0.2,
+    dt = 1 / 250 kHz, cubature filter + smoother (myotis_myotis_analysis.py:50-74) -- on a synthetic sweep: the smoothed
+    frequency follows the truth, and the engine agrees with the C port.  The recursion is badly conditioned while it locks on
+    (P0 and sigma are large): the two CPU oracles differ by 6e-6 from each other there, hence the loose gate."""
+    from chirpgp_amd import filters_smoothers as fs
+    from chirpgp_amd.models import g
+    from chirpgp_amd.quadratures import gaussian_expectation
+    nh, T = 4, 600
+    c = cs.harmonic_case(T=T, seed=35, nh=nh, params=(0.1, 1., 1., 0.2, 10., 2.), freq_scale=1e4, Xi=1e-4, dt=1. / 250000)
+    c.ys, truth = _bat_like_record(T, nh, 5)
+    want = bk.run_pairs('port', c, only=('sgp_filter', 'sgp_smoother'))
+    for kw in (WAVE, THREAD):
+        got = bk.run_pairs('hip', c, hip_kw=kw, only=('sgp_filter', 'sgp_smoother'))
+        for k in ('sgp_filter', 'sgp_smoother'):
+            for gv, wv in zip(got[k][:2], want[k][:2]):
+                assert np.isfinite(gv).all()
+                assert np.max(np.abs(gv - wv)) <= 1e-2 * np.max(np.abs(wv))
+        mss, Pss = got['sgp_smoother']
+        est = gaussian_expectation(ms=mss[:, -2], chol_Ps=np.sqrt(Pss[:, -2, -2]), func=g, force_shape=True)[:, 0] * 1e4
+        assert np.max(np.abs(est[T // 3:] / truth[T // 3:] - 1.0)) < 0.05, 'smoothed frequency off the sweep'
