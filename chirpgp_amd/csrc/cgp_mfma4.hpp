@@ -275,7 +275,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
     __shared__ double2 park[64 * kParkStride];
-    __shared__ double ybuf[64 + 8];                                         // the chunk's measurements (+ the read-ahead of the last group)
+    __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
     int checked_left = 0;
     // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
@@ -312,7 +312,18 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             ybuf[lane] = ychunk;
             wave_lds_fence();
             int slot = 0;
+            // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms; the
+            // same loop written generically over the group size -- arrays of read-ahead registers, one lambda for both group
+            // sizes -- compiled to a schedule that gained nothing, with 8 or with 16 steps)
             double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
+            double2 yc = *reinterpret_cast<const double2*>(ybuf + 4), yd = *reinterpret_cast<const double2*>(ybuf + 6);
+            for (; slot + 8 <= nsteps; slot += 8) {
+                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 8), nb = *reinterpret_cast<const double2*>(ybuf + slot + 10);
+                const double2 nc = *reinterpret_cast<const double2*>(ybuf + slot + 12), nd = *reinterpret_cast<const double2*>(ybuf + slot + 14);
+                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
+                one(slot, 4u, yc.x); one(slot, 5u, yc.y); one(slot, 6u, yd.x); one(slot, 7u, yd.y);
+                ya = na; yb = nb; yc = nc; yd = nd;
+            }
             for (; slot + 4 <= nsteps; slot += 4) {
                 const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
                 one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
