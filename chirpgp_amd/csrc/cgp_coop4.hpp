@@ -136,10 +136,7 @@ constexpr int64_t kOobMaxBytes = 0x7FFFFF00;
 // coalesced store; returns the new running total (wave-uniform).
 CGP_DEV double nll_flush_wave(double S_l, double innov_l, int lane, int nsteps, double cum, double* __restrict__ nll_chunk) {
     double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
-    CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
-        const double up = __shfl_up(v, delta, 64);
-        if (lane >= delta) v += up;
-    }
+    v = wave_inclusive_scan(v);
     v += cum;
     if (nll_chunk && lane < nsteps) nll_chunk[lane] = v;
     return readlane_f64(v, nsteps - 1);

@@ -241,11 +241,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
             }
             if (want_nll) {
                 double v = (lane < nsteps) ? nll_increment(S_l, innov_l) : 0.0;
-                CGP_UNROLL for (int delta = 1; delta < 64; delta *= 2) {
-                    const double up = __shfl_up(v, delta, 64);
-                    if (lane >= delta) v += up;
-                }
-                v += cum;
+                v = wave_inclusive_scan(v) + cum;
                 if (nll && lane < nsteps) nll[t0 + lane] = v;
                 cum = readlane_f64(v, nsteps - 1);
             }

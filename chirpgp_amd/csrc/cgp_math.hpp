@@ -204,6 +204,25 @@ template <int D> CGP_DEV void store_sym_full(double* __restrict__ p, const Sym<D
     }
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP moves (zeros shifted in): within the rows of 16 by row_shr 1 / 2 / 3 of the
+// input, then 4 and 8 of the partial sums on the lanes that have such a neighbour (bank masks), then the row totals forwarded
+// with row_bcast 15 / 31 (row masks) -- seven move-pair + add steps of ~ 13 cycles, where six __shfl_up rounds (two
+// ds_bpermute_b32 and an LDS round trip each) cost some 700 cycles per flush: ~ 10 cycles of every step of a 64-step chunk.
+template <int CTRL, int ROW_MASK, int BANK_MASK> CGP_DEV double dpp_zero_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+CGP_DEV double wave_inclusive_scan(double v) {
+    double s = v + dpp_zero_f64<0x111, 0xF, 0xF>(v);            // row_shr:1
+    s += dpp_zero_f64<0x112, 0xF, 0xF>(v);                      // row_shr:2
+    s += dpp_zero_f64<0x113, 0xF, 0xF>(v);                      // row_shr:3
+    s += dpp_zero_f64<0x114, 0xF, 0xE>(s);                      // row_shr:4 on lanes 4..15 of a row
+    s += dpp_zero_f64<0x118, 0xF, 0xC>(s);                      // row_shr:8 on lanes 8..15
+    s += dpp_zero_f64<0x142, 0xA, 0xF>(s);                      // row_bcast:15: lane 15 of rows 0, 2 into rows 1, 3
+    s += dpp_zero_f64<0x143, 0xC, 0xF>(s);                      // row_bcast:31: lane 31 into rows 2, 3
+    return s;
+}
 // Wave-uniform broadcast of a double held in lane `src` (src may be a runtime, wave-uniform value).
 CGP_DEV double readlane_f64(double x, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
