@@ -409,6 +409,30 @@ CGP_DEV void softplus_tail_lean(const Regs& R, double t, double& q_scaled, doubl
     dsp = rcp_nr1(1.0 + t);
 }
 
+// ---- the same step in its HIGH regime: frequency state x >= 5 (t = exp(-x) <= 6.74e-3; 23 Hz and up at the demos' scaling) ----
+// What the step needs of the softplus there takes far shorter polynomials than on t <= 0.223 (tools/gen_math_constants.py,
+// Chebyshev-node fits):
+//     log1p(t) / t on [0, e^-5], degree 3:  relative error 3.2e-12  (x t x the angle scale: 1.3e-16 rad of rotation angle)
+//     1 / (1 + t)  on [0, e^-5], degree 4:  relative error 2.7e-14  (no reciprocal, no Newton step)
+// -- 5 vector operations and a v_rcp_f64 less than the lean forms above, on a step that is bound by instruction issue.  The
+// degrees are set by the filter's sensitivity, not by the functions' own scale: 1 / (1 + t) to degree 3 (1.6e-11, a constant
+// bias of the Jacobian's softplus derivative) showed as 7e-10 in the weakly observed frequency-rate state -- too close to the
+// 1e-9 gate of the full-size tests -- so it takes degree 4, and exp keeps its lean degree-7 polynomial.
+constexpr double kLog1pOverTHigh[4] = {0.9999999999968153, -0.4999999848726392, 0.3333220972028625, -0.24732548838557097};
+constexpr double kSigmoidHigh[5] = {0.9999999999999734, -0.9999999998020426, 0.999999764797864, -0.9999021072027222, 0.9833379103966127};
+struct SpecRegsHigh {
+    double lq[4], sg[5];
+    CGP_DEV void init(double scale) {
+        CGP_UNROLL for (int i = 0; i < 4; i++) lq[i] = FastMathRegs::pin(kLog1pOverTHigh[i] * scale);
+        CGP_UNROLL for (int i = 0; i < 5; i++) sg[i] = FastMathRegs::pin(kSigmoidHigh[i]);
+    }
+};
+// scale * log1p(t) / t and 1 / (1 + t) for t <= exp(-5)
+CGP_DEV void softplus_tail_high(const SpecRegsHigh& H, double t, double& q_scaled, double& dsp) {
+    q_scaled = horner(horner(horner(H.lq[3], t, H.lq[2]), t, H.lq[1]), t, H.lq[0]);
+    dsp = horner(horner(horner(horner(H.sg[4], t, H.sg[3]), t, H.sg[2]), t, H.sg[1]), t, H.sg[0]);
+}
+
 // Pinned coefficients for a per-lane sigma-point fan that is evaluated without regime branches (cgp_mfma4_sigma.hpp,
 // cgp_mfma4_cd.hpp): the lean softplus above (SoftplusRegs) and, for the discrete model's rotation, sin / cos on the
 // reduced range |r| <= pi/4 (Taylor to r^17 / r^16) in Estrin form -- four dependent levels instead of the eight of

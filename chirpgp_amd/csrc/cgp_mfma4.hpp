@@ -183,24 +183,27 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 // offset of 700 as unsigned numbers), d = the largest high word of |d| (NaN above everything).
 struct Ekf4Verdict {
     unsigned u = 0u, d = 0u;
-    CGP_DEV unsigned long long uncommon() const {          // wave mask of the lanes that left the speculative regime
-        return __builtin_amdgcn_ballot_w64(u > 0x008DDFFFu) | __builtin_amdgcn_ballot_w64(d >= 0x3F800000u);      // u2 outside [1.5, 700), |d| >= 2^-7
+    // HIGH: the chunk ran on the short polynomials of the regime u2 >= 5 (cgp_fastmath.hpp: SpecRegsHigh)
+    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {          // wave mask of the lanes that left the speculative regime
+        constexpr unsigned span = HIGH ? 0x4085DFFFu - 0x40140000u : 0x4085DFFFu - 0x3FF80000u;      // u2 in [5, 700) / [1.5, 700)
+        return __builtin_amdgcn_ballot_w64(u > span) | __builtin_amdgcn_ballot_w64(d >= 0x3F800000u);      // ... or |d| >= 2^-7
     }
 };
-template <int E1>
-CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, double y, Ekf4State& x, Ekf4Anchor& a, double& S,
-                                  double& innov, Ekf4Verdict& verdict) {
+template <int E1, bool HIGH = false>
+CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
+                                  double& S, double& innov, Ekf4Verdict& verdict) {
     const double u2 = (E1 == 2) ? x.u2_replicated() : x.u2();
     const double t = exp_neg_lean1(R, u2);
     const double lin = fma(K.angm, u2, -a.th);                                       // off the chain: needs u2 only
     double qa, dsp;
-    softplus_tail_lean(R, t, qa, dsp);                                               // qa = ang log1p(t) / t
+    if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);
+    else softplus_tail_lean(R, t, qa, dsp);                                          // qa = ang log1p(t) / t
     const double d = fma(qa, t, lin);
     const double d2 = d * d, d4 = d2 * d2;
     const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
     const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
     const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
-    const unsigned hx = (unsigned)__double2hiint(u2) - 0x3FF80000u;                  // 1.5 -> 0, 700 -> 0x008DDFFF
+    const unsigned hx = (unsigned)__double2hiint(u2) - (HIGH ? 0x40140000u : 0x3FF80000u);  // 5 (1.5) -> 0, 700 -> the span above
     const unsigned hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
@@ -271,6 +274,8 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
 
     SpecRegs R;
     R.init(K.angm);
+    SpecRegsHigh RH;
+    RH.init(K.angm);
     // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
@@ -293,44 +298,59 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         const Ekf4State x0 = x;
         unsigned long long uncommon = 0;
         if (checked_left == 0) {
-            Ekf4Anchor anchor;
-            ekf4_anchor(K, x.u2(), anchor);
-            Ekf4Verdict verdict;
-            // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in the
-            // instruction's immediate offset (the compiler folds the constant added to the vector offset) -- no scalar add per step
-            auto one = [&](int slot, unsigned k, double y) {
-                double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 2 : 0>(K, R, y, x, anchor, S, innov, verdict);
-                park[(slot + k) * kParkStride] = make_double2(S, innov);
-                const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store_s(x.P, p_off + k * 128u, t * 128u);
-                mfs.store_s(x.uq, m_off + k * 32u, t * 32u);
-            };
-            // The step's measurement: the chunk's 64 values go to LDS once, and every group of four steps reads its four with
-            // two broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
+            Ekf4Anchor anchor0;
+            ekf4_anchor(K, x.u2(), anchor0);
+            // The step's measurement: the chunk's 64 values go to LDS once, and every group of steps reads its own with
+            // broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
             // (tools/ubench/issue_costs.hip)
             ybuf[lane] = ychunk;
             wave_lds_fence();
-            int slot = 0;
-            // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms; the
-            // same loop written generically over the group size -- arrays of read-ahead registers, one lambda for both group
-            // sizes -- compiled to a schedule that gained nothing, with 8 or with 16 steps)
-            double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
-            double2 yc = *reinterpret_cast<const double2*>(ybuf + 4), yd = *reinterpret_cast<const double2*>(ybuf + 6);
-            for (; slot + 8 <= nsteps; slot += 8) {
-                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 8), nb = *reinterpret_cast<const double2*>(ybuf + slot + 10);
-                const double2 nc = *reinterpret_cast<const double2*>(ybuf + slot + 12), nd = *reinterpret_cast<const double2*>(ybuf + slot + 14);
-                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
-                one(slot, 4u, yc.x); one(slot, 5u, yc.y); one(slot, 6u, yd.x); one(slot, 7u, yd.y);
-                ya = na; yb = nb; yc = nc; yd = nd;
+            // One speculative pass over the chunk; HIGH: on the short polynomials of the regime u2 >= 5 (SpecRegsHigh).
+            auto chunk = [&](auto high_c) {
+                constexpr bool HIGH = decltype(high_c)::value;
+                Ekf4Anchor anchor = anchor0;
+                Ekf4Verdict verdict;
+                // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in
+                // a vector offset of its own (hoisted out of the loop) -- no scalar add per step
+                auto one = [&](int slot, unsigned k, double y) {
+                    double S, innov;
+                    ekf4_mfma_step_spec1<E1 ? 2 : 0, HIGH>(K, R, RH, y, x, anchor, S, innov, verdict);
+                    park[(slot + k) * kParkStride] = make_double2(S, innov);
+                    const unsigned t = (unsigned)(t0 + slot);
+                    Pfs.store_s(x.P, p_off + k * 128u, t * 128u);
+                    mfs.store_s(x.uq, m_off + k * 32u, t * 32u);
+                };
+                int slot = 0;
+                // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms;
+                // the same loop written generically over the group size -- arrays of read-ahead registers, one lambda for both
+                // group sizes -- compiled to a schedule that gained nothing, with 8 or with 16 steps)
+                double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
+                double2 yc = *reinterpret_cast<const double2*>(ybuf + 4), yd = *reinterpret_cast<const double2*>(ybuf + 6);
+                for (; slot + 8 <= nsteps; slot += 8) {
+                    const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 8), nb = *reinterpret_cast<const double2*>(ybuf + slot + 10);
+                    const double2 nc = *reinterpret_cast<const double2*>(ybuf + slot + 12), nd = *reinterpret_cast<const double2*>(ybuf + slot + 14);
+                    one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
+                    one(slot, 4u, yc.x); one(slot, 5u, yc.y); one(slot, 6u, yd.x); one(slot, 7u, yd.y);
+                    ya = na; yb = nb; yc = nc; yd = nd;
+                }
+                for (; slot + 4 <= nsteps; slot += 4) {
+                    const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
+                    one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
+                    ya = na; yb = nb;
+                }
+                for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
+                return verdict.template uncommon<HIGH>();
+            };
+            // A chunk that starts at u2 >= 5.5 is tried in the HIGH regime first (the bench records: 80 % of the chunks, 0.2 % of
+            // them fall out of it); one that leaves it is repeated from its saved state in the common regime.
+            bool high = false;
+            if constexpr (E1) high = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x40160000u < 0x4085DFFFu - 0x40160000u;
+            uncommon = 1;
+            if (high) {
+                uncommon = chunk(std::true_type{});
+                if (uncommon != 0) x = x0;
             }
-            for (; slot + 4 <= nsteps; slot += 4) {
-                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
-                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
-                ya = na; yb = nb;
-            }
-            for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
-            uncommon = verdict.uncommon();
+            if (uncommon != 0) uncommon = chunk(std::false_type{});
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
@@ -541,6 +561,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
 
     SpecRegs R;
     R.init<!DENSE>(K.angm);
+    const SpecRegsHigh RH{};                                               // (the HIGH regime is tried by the one-trial-per-wavefront kernel only)
     __shared__ double ych[4][64];
     __shared__ double2 park[4][64];
     double cum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -561,7 +582,7 @@ CGP_DEV void ekf4_mfma_x4_trials(const FilterIO& io, const ModelArgs& ma) {
             Ekf4Verdict verdict;
             auto one = [&](int slot) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 1 : 0>(K, R, ych[b][slot], x, anchor, S, innov, verdict);
+                ekf4_mfma_step_spec1<E1 ? 1 : 0>(K, R, RH, ych[b][slot], x, anchor, S, innov, verdict);
                 park[b][slot] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pfs.store_s(x.P, p_base, t * 128u);              // the step's row offset rides in the scalar offset

@@ -921,3 +921,27 @@ def test_bat_call_parameters_track_the_sweep():
         mss, Pss = got['sgp_smoother']
         est = gaussian_expectation(ms=mss[:, -2], chol_Ps=np.sqrt(Pss[:, -2, -2]), func=g, force_shape=True)[:, 0] * 1e4
         assert np.max(np.abs(est[T // 3:] / truth[T // 3:] - 1.0)) < 0.05, 'smoothed frequency off the sweep'
+
+
+def test_high_frequency_regime_of_the_matrix_core_ekf():
+    """Chunks that start with the frequency state at 5.5 or above run on the short polynomials of the regime u2 >= 5
+    (exp to degree 6, log1p(t) / t to degree 2, 1 / (1 + t) to degree 3 without a reciprocal: cgp_fastmath.hpp, SpecRegsHigh)
+    and are repeated in the common regime when a step dips below 5.  Records that live inside that regime, one that hovers
+    around its two thresholds, one that sweeps through it: within 1e-9 of the C port (the polynomials are good for 1e-13 rad
+    of rotation angle), i.e. well inside what the common-regime kernel delivers."""
+    import math
+    from oracle import np_models as om_
+    T, dt, Xi = 1800, 1e-3, 0.05
+    ts = dt * np.arange(1, T + 1)
+    recs = []
+    for f_lo, f_hi, seed in [(8.5, 12.0, 1), (30.0, 60.0, 2), (4.9, 5.8, 3), (3.0, 9.0, 4)]:
+        freq = f_lo + (f_hi - f_lo) * 0.5 * (1 - np.cos(2 * math.pi * ts / ts[-1] * 2.5))
+        phase = np.cumsum(freq) * dt
+        recs.append(np.sin(2 * math.pi * phase) + math.sqrt(Xi) * np.random.default_rng(seed).standard_normal(T))
+    c = cs.chirp_case(T=8, params=(0.1, 0.5, 0.1, 0.3, 3., float(om_.g_inv(8.0))), Xi=Xi, dt=dt)
+    c.ys = np.stack(recs)
+    want = bk.run_pairs('port', c, only=('ekf',))
+    got = bk.run_pairs('hip', c, hip_kw=WAVE, only=('ekf',))
+    u2 = want['ekf'][0][:, :, 2]
+    assert (u2[0, 300:] > 5.5).all() and (u2[1, 300:] > 20).all() and (u2[2] < 5.0).any() and (u2[2] > 5.5).any() and (u2[3] < 4.0).any()
+    bk.compare(got, want, 1e-9, 'high-frequency regime')

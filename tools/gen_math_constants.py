@@ -51,3 +51,15 @@ q = lambda t: mp.log1p(t) / t if t != 0 else mp.mpf(1)
 lq = cheb_fit(q, mp.mpf(0), mp.exp(mp.mpf('-1.5')), 7)
 print('kExpLean[8] = {' + ', '.join(repr(v) for v in ex) + '};   // max rel err', mp.nstr(max_rel_err(mp.exp, ex, -ln2h, ln2h), 3))
 print('kLog1pOverTLean[8] = {' + ', '.join(repr(v) for v in lq) + '};   // max rel err', mp.nstr(max_rel_err(q, lq, mp.mpf(0), mp.exp(mp.mpf('-1.5'))), 3))
+
+
+# ---- the HIGH-regime polynomials of the d = 4 EKF step (cgp_fastmath.hpp: kLog1pOverTHigh, kSigmoidHigh) -------------------
+# Frequency state u2 >= 5 (23 Hz and up at the demos' scaling): t = exp(-u2) <= 6.74e-3, and what the step needs of it is
+# dt 2 pi fs (u2 + log1p(t)) to ~ 1e-15 rad (a systematic angle error is integrated by the oscillator states over the filter's
+# memory: 1e-13 rad showed as 7e-10 in the filtering means) and 1 / (1 + t) to ~ 1e-13 (the weakly observed frequency-rate state amplifies a bias of the
+# Jacobian's softplus derivative ~ 40 x: 1.6e-11 there showed as 7e-10) -- far shorter polynomials than on t <= 0.223.  exp keeps its lean degree-7 form (degree 6, 2.5e-9, is what put 1e-13 rad on the angle).
+tmax = mp.exp(mp.mpf(-5))
+lqh = cheb_fit(q, mp.mpf(0), tmax, 3)
+sgh = cheb_fit(lambda t: 1 / (1 + t), mp.mpf(0), tmax, 4)
+print('kLog1pOverTHigh[4] = {' + ', '.join(repr(v) for v in lqh) + '};   // max rel err', mp.nstr(max_rel_err(q, lqh, mp.mpf(0), tmax), 3))
+print('kSigmoidHigh[5] = {' + ', '.join(repr(v) for v in sgh) + '};   // max rel err', mp.nstr(max_rel_err(lambda t: 1 / (1 + t), sgh, mp.mpf(0), tmax), 3))
