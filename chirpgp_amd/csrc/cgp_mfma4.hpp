@@ -343,8 +343,10 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             };
             // A chunk that starts at u2 >= 5.5 is tried in the HIGH regime first (the bench records: 80 % of the chunks, 0.2 % of
             // them fall out of it); one that leaves it is repeated from its saved state in the common regime.
+            // (Not for an NLL-only launch: that is the objective of a maximum-likelihood fit, differentiated by finite differences --
+            // a chunk that changes regime between two probes would put a 1e-13 step into it, and the optimiser's path with it.)
             bool high = false;
-            if constexpr (E1) high = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x40160000u < 0x4085DFFFu - 0x40160000u;
+            if constexpr (E1) high = !nll_final && (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x40160000u < 0x4085DFFFu - 0x40160000u;
             uncommon = 1;
             if (high) {
                 uncommon = chunk(std::true_type{});

@@ -247,7 +247,9 @@ def test_per_trial_parameters_and_nll_only():
             cs.assert_close(g, w, RTOL, f'sweep.{n}')
         last = fs.ekf(disc, H, 0.1, m0, P0, 1e-3, ys, nll_final_only=True, want=(False, False, True), **kw)
         assert last[0] is None and last[1] is None
-        npt.assert_array_equal(last[2], got[2][:, -1])
+        # the same recursion, except that the matrix-core EKF keeps an NLL-only launch on its common-regime polynomials (the
+        # objective of a finite-difference gradient must not change regime between probes): roundings apart
+        npt.assert_allclose(last[2], got[2][:, -1], rtol=1e-12)
 
 
 def test_nan_semantics():
