@@ -412,24 +412,41 @@ CGP_DEV void softplus_tail_lean(const Regs& R, double t, double& q_scaled, doubl
 // ---- the same step in its HIGH regime: frequency state x >= 5 (t = exp(-x) <= 6.74e-3; 23 Hz and up at the demos' scaling) ----
 // What the step needs of the softplus there takes far shorter polynomials than on t <= 0.223 (tools/gen_math_constants.py,
 // Chebyshev-node fits):
-//     log1p(t) / t on [0, e^-5], degree 3:  relative error 3.2e-12  (x t x the angle scale: 1.3e-16 rad of rotation angle)
+//     exp(r), |r| <= ln 2 / 2, degree 6:    relative error 2.5e-9   (x t x the angle scale: 1.1e-13 rad of rotation angle)
+//     log1p(t) / t on [0, e^-5], degree 2:  relative error 2.4e-9   (1.0e-13 rad)
 //     1 / (1 + t)  on [0, e^-5], degree 4:  relative error 2.7e-14  (no reciprocal, no Newton step)
-// -- 5 vector operations and a v_rcp_f64 less than the lean forms above, on a step that is bound by instruction issue.  The
-// degrees are set by the filter's sensitivity, not by the functions' own scale: 1 / (1 + t) to degree 3 (1.6e-11, a constant
-// bias of the Jacobian's softplus derivative) showed as 7e-10 in the weakly observed frequency-rate state -- too close to the
-// 1e-9 gate of the full-size tests -- so it takes degree 4, and exp keeps its lean degree-7 polynomial.
-constexpr double kLog1pOverTHigh[4] = {0.9999999999968153, -0.4999999848726392, 0.3333220972028625, -0.24732548838557097};
+// -- 7 vector operations and a v_rcp_f64 less than the lean forms above, on a step that is bound by instruction issue.  The
+// degrees are set by the filter's sensitivity, measured against the C port on records that live at the regime's lower edge:
+// 1 / (1 + t) to degree 3 (1.6e-11, a constant bias of the Jacobian's softplus derivative) showed as 7e-10 in the weakly
+// observed frequency-rate state -- too close to the 1e-9 gate of the full-size tests -- hence degree 4; the two angle
+// polynomials cost 2.6e-11 at worst where the common regime's own lean polynomials cost 1.4e-10 (degree 7 / 3 instead: 1.2e-12).
+constexpr double kExpHigh[7] = {1.0, 1.0000000377388714, 0.5000000047146057, 0.16666415414041177, 0.04166635277111221,
+                                0.008375134774624326, 0.0013941118895837};
+constexpr double kLog1pOverTHigh[3] = {0.9999999976293401, -0.4999936650358292, 0.33082183854737557};
 constexpr double kSigmoidHigh[5] = {0.9999999999999734, -0.9999999998020426, 0.999999764797864, -0.9999021072027222, 0.9833379103966127};
 struct SpecRegsHigh {
-    double lq[4], sg[5];
+    double ex[7], lq[3], sg[5];
     CGP_DEV void init(double scale) {
-        CGP_UNROLL for (int i = 0; i < 4; i++) lq[i] = FastMathRegs::pin(kLog1pOverTHigh[i] * scale);
+        CGP_UNROLL for (int i = 0; i < 7; i++) ex[i] = FastMathRegs::pin(kExpHigh[i]);
+        CGP_UNROLL for (int i = 0; i < 3; i++) lq[i] = FastMathRegs::pin(kLog1pOverTHigh[i] * scale);
         CGP_UNROLL for (int i = 0; i < 5; i++) sg[i] = FastMathRegs::pin(kSigmoidHigh[i]);
     }
 };
+// exp(-x) with the degree-6 polynomial (log2e and ln2 from the lean set R)
+template <class Regs>
+CGP_DEV double exp_neg_high(const Regs& R, const SpecRegsHigh& H, double x) {
+    const double nx = -x;
+    const double k = __builtin_rint(nx * R.log2e);
+    const double r = fma(-k, R.ln2, nx);
+    const double r2 = r * r;
+    const double a0 = horner(H.ex[1], r, H.ex[0]), a1 = horner(H.ex[3], r, H.ex[2]), a2 = horner(H.ex[5], r, H.ex[4]);
+    const double r4 = r2 * r2;
+    const double b0 = horner(a1, r2, a0), b1 = horner(H.ex[6], r2, a2);
+    return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
+}
 // scale * log1p(t) / t and 1 / (1 + t) for t <= exp(-5)
 CGP_DEV void softplus_tail_high(const SpecRegsHigh& H, double t, double& q_scaled, double& dsp) {
-    q_scaled = horner(horner(horner(H.lq[3], t, H.lq[2]), t, H.lq[1]), t, H.lq[0]);
+    q_scaled = horner(horner(H.lq[2], t, H.lq[1]), t, H.lq[0]);
     dsp = horner(horner(horner(horner(H.sg[4], t, H.sg[3]), t, H.sg[2]), t, H.sg[1]), t, H.sg[0]);
 }
 

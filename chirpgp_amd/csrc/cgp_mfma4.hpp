@@ -193,7 +193,7 @@ template <int E1, bool HIGH = false>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
                                   double& S, double& innov, Ekf4Verdict& verdict) {
     const double u2 = (E1 == 2) ? x.u2_replicated() : x.u2();
-    const double t = exp_neg_lean1(R, u2);
+    const double t = HIGH ? exp_neg_high(R, RH, u2) : exp_neg_lean1(R, u2);
     const double lin = fma(K.angm, u2, -a.th);                                       // off the chain: needs u2 only
     double qa, dsp;
     if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);

@@ -53,13 +53,15 @@ print('kExpLean[8] = {' + ', '.join(repr(v) for v in ex) + '};   // max rel err'
 print('kLog1pOverTLean[8] = {' + ', '.join(repr(v) for v in lq) + '};   // max rel err', mp.nstr(max_rel_err(q, lq, mp.mpf(0), mp.exp(mp.mpf('-1.5'))), 3))
 
 
-# ---- the HIGH-regime polynomials of the d = 4 EKF step (cgp_fastmath.hpp: kLog1pOverTHigh, kSigmoidHigh) -------------------
-# Frequency state u2 >= 5 (23 Hz and up at the demos' scaling): t = exp(-u2) <= 6.74e-3, and what the step needs of it is
-# dt 2 pi fs (u2 + log1p(t)) to ~ 1e-15 rad (a systematic angle error is integrated by the oscillator states over the filter's
-# memory: 1e-13 rad showed as 7e-10 in the filtering means) and 1 / (1 + t) to ~ 1e-13 (the weakly observed frequency-rate state amplifies a bias of the
-# Jacobian's softplus derivative ~ 40 x: 1.6e-11 there showed as 7e-10) -- far shorter polynomials than on t <= 0.223.  exp keeps its lean degree-7 form (degree 6, 2.5e-9, is what put 1e-13 rad on the angle).
+# ---- the HIGH-regime polynomials of the d = 4 EKF step (cgp_fastmath.hpp: kExpHigh, kLog1pOverTHigh, kSigmoidHigh) ---------
+# Frequency state u2 >= 5 (23 Hz and up at the demos' scaling): t = exp(-u2) <= 6.74e-3.  The degrees were settled against the
+# C port on records at the regime's lower edge (tests/test_gpu_parity.py: test_high_frequency_regime_of_the_matrix_core_ekf):
+# the angle dt 2 pi fs (u2 + log1p(t)) to ~ 1e-13 rad costs 2.6e-11 in the filtering means at worst; 1 / (1 + t) needs ~ 1e-13
+# (the weakly observed frequency-rate state amplifies a bias of the Jacobian's softplus derivative: 1.6e-11 showed as 7e-10).
 tmax = mp.exp(mp.mpf(-5))
-lqh = cheb_fit(q, mp.mpf(0), tmax, 3)
+exh = cheb_fit(mp.exp, -ln2h * mp.mpf('1.0001'), ln2h * mp.mpf('1.0001'), 6)
+lqh = cheb_fit(q, mp.mpf(0), tmax, 2)
 sgh = cheb_fit(lambda t: 1 / (1 + t), mp.mpf(0), tmax, 4)
-print('kLog1pOverTHigh[4] = {' + ', '.join(repr(v) for v in lqh) + '};   // max rel err', mp.nstr(max_rel_err(q, lqh, mp.mpf(0), tmax), 3))
+print('kExpHigh[7] = {' + ', '.join(repr(v) for v in exh) + '};   // max rel err', mp.nstr(max_rel_err(mp.exp, exh, -ln2h, ln2h), 3))
+print('kLog1pOverTHigh[3] = {' + ', '.join(repr(v) for v in lqh) + '};   // max rel err', mp.nstr(max_rel_err(q, lqh, mp.mpf(0), tmax), 3))
 print('kSigmoidHigh[5] = {' + ', '.join(repr(v) for v in sgh) + '};   // max rel err', mp.nstr(max_rel_err(lambda t: 1 / (1 + t), sgh, mp.mpf(0), tmax), 3))
