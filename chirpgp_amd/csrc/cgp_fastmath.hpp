@@ -426,10 +426,12 @@ constexpr double kLog1pOverTHigh[3] = {0.9999999976293401, -0.4999936650358292, 
 constexpr double kSigmoidHigh[5] = {0.9999999999999734, -0.9999999998020426, 0.999999764797864, -0.9999021072027222, 0.9833379103966127};
 struct SpecRegsHigh {
     double ex[7], lq[3], sg[5];
-    CGP_DEV void init(double scale) {
+    // `scale` rides in the coefficients of log1p(t) / t, `dscale` in those of 1 / (1 + t) (the EKF wants the derivative times a
+    // per-lane factor of its Jacobian: one multiply less)
+    CGP_DEV void init(double scale, double dscale = 1.0) {
         CGP_UNROLL for (int i = 0; i < 7; i++) ex[i] = FastMathRegs::pin(kExpHigh[i]);
         CGP_UNROLL for (int i = 0; i < 3; i++) lq[i] = FastMathRegs::pin(kLog1pOverTHigh[i] * scale);
-        CGP_UNROLL for (int i = 0; i < 5; i++) sg[i] = FastMathRegs::pin(kSigmoidHigh[i]);
+        CGP_UNROLL for (int i = 0; i < 5; i++) sg[i] = FastMathRegs::pin(kSigmoidHigh[i] * dscale);
     }
 };
 // exp(-x) with the degree-6 polynomial (log2e and ln2 from the lean set R)
@@ -444,7 +446,7 @@ CGP_DEV double exp_neg_high(const Regs& R, const SpecRegsHigh& H, double x) {
     const double b0 = horner(a1, r2, a0), b1 = horner(H.ex[6], r2, a2);
     return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
 }
-// scale * log1p(t) / t and 1 / (1 + t) for t <= exp(-5)
+// scale * log1p(t) / t and dscale / (1 + t) for t <= exp(-5)
 CGP_DEV void softplus_tail_high(const SpecRegsHigh& H, double t, double& q_scaled, double& dsp) {
     q_scaled = horner(horner(H.lq[2], t, H.lq[1]), t, H.lq[0]);
     dsp = horner(horner(horner(horner(H.sg[4], t, H.sg[3]), t, H.sg[2]), t, H.sg[1]), t, H.sg[0]);

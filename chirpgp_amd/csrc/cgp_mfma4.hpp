@@ -84,9 +84,9 @@ struct Ekf4State {
 // v_readlane) is three instructions shorter but one matrix instruction deeper, and measured 2.64 against 2.60 ms -- the
 // linear filter, whose step is the tail alone, takes that form and gains 4 % (kf4_mfma_trial).
 template <int E1 = 0>
-CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, double dsp, Ekf4State& x, double& S, double& innov) {
+// kjd = (kj ang) x the softplus derivative: this lane's factor of the Jacobian column d f / d u2
+CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, double kjd, Ekf4State& x, double& S, double& innov) {
     const double f_r = mfma4(J0T, x.ur, 0.0), f_q = mfma4(x.ur, J0T, 0.0);
-    const double kjd = K.kja * dsp;
     const double RJT = fma(kjd, dpp_f64<kQuadSwap1>(f_q), J0T);
     double Pp, PHr, PHq;
     if constexpr (E1 != 0) {
@@ -126,7 +126,7 @@ CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, do
 template <int E1 = 0>
 CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, double s1, double dsp, Ekf4State& x, double& S, double& innov) {
     const double J0T = fma(K.kcr, c1, fma(K.ksr, s1, K.kk));           // rho (kc cos + ks sin) + kk: rho rides in kcr, ksr
-    ekf4_mfma_finish_j<E1>(K, y, J0T, dsp, x, S, innov);
+    ekf4_mfma_finish_j<E1>(K, y, J0T, K.kja * dsp, x, S, innov);
 }
 
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
@@ -208,7 +208,7 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
     a.th += d; a.A = A; a.B = B;
-    ekf4_mfma_finish_j<E1>(K, y, A, dsp, x, S, innov);
+    ekf4_mfma_finish_j<E1>(K, y, A, HIGH ? dsp : K.kja * dsp, x, S, innov);          // HIGH: K.kja rides in the polynomial (SpecRegsHigh::init)
 }
 
 // Tried with it and dropped (all measured on the bench configuration, same box, A/B): the max-ILP scheduling strategy for this
@@ -275,7 +275,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     SpecRegs R;
     R.init(K.angm);
     SpecRegsHigh RH;
-    RH.init(K.angm);
+    RH.init(K.angm, K.kja);
     // (S, innovation) of each step are parked in LDS -- every lane writes the same pair to the step's slot, a plain
     // fire-and-forget ds_write -- and picked up per lane at the 64-step NLL flush (no compare / select on the chain)
     constexpr int kParkStride = 2;                                          // 32-byte slots (measured against 16: 3.35 against 3.39 ms a pass)
