@@ -341,7 +341,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
                 return verdict.template uncommon<HIGH>();
             };
-            // A chunk that starts at u2 >= 5.5 is tried in the HIGH regime first (the bench records: 80 % of the chunks, 0.2 % of
+            // A chunk that starts at u2 >= 5.5 is tried in the HIGH regime first (the bench records: 79 % of the chunks, 2 % of
             // them fall out of it); one that leaves it is repeated from its saved state in the common regime.
             // (Not for an NLL-only launch: that is the objective of a maximum-likelihood fit, differentiated by finite differences --
             // a chunk that changes regime between two probes would put a 1e-13 step into it, and the optimiser's path with it.)
