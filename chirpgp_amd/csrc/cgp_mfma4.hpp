@@ -211,7 +211,10 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     ekf4_mfma_finish_j<E1>(K, y, A, HIGH ? dsp : K.kja * dsp, x, S, innov);          // HIGH: K.kja rides in the polynomial (SpecRegsHigh::init)
 }
 
-// Tried with it and dropped (all measured on the bench configuration, same box, A/B): the max-ILP scheduling strategy for this
+// Tried with it and dropped (all measured on the bench configuration, same box, A/B): a third, FLAT regime for chunks that start
+// at u2 >= 38 (exp(-u2) < 2^-54: softplus is the identity to the last bit -- no exp, no polynomial; 2.38 -> 2.22 ms on a 30 - 75 Hz
+// sweep, but the third unrolled variant cost the bench records, which never get there, 2.5 %: 2.16 -> 2.21 ms), the max-ILP
+// scheduling strategy for this
 // kernel once it is unrolled (2.72 against 2.65 ms; the other matrix-core kernels keep it; iterative-ilp / -minreg / -maxocc and
 // no post-RA scheduler: 2.64 - 2.73 against 2.59), unrolling by 2 / 3 / 8 / 16 (2.70 / 2.70 / 2.65 / 2.68 ms), the four steps as
 // one block in the order of a latency-driven list scheduler, pinned with scheduling barriers (tools/sched/ekf4_sched.py: 2.69
