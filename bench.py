@@ -40,13 +40,14 @@ PMC_PROFILE = 'profiles/r03_ekf_pmc.json'
 ISSUE_TABLE = 'profiles/r03_issue_table.json'
 
 
-def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0):
+def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0, offset=8.0, meow=500.0):
     """Synthetic toy chirp of SURVEY.md 8d: meow frequency law (toymodels.py:226-268) tiled in 3141-step windows,
-    constant magnitude 1, y = chirp + sqrt(Xi) N(0, 1); trial i uses numpy default_rng(seed + i)."""
+    constant magnitude 1, y = chirp + sqrt(Xi) N(0, 1); trial i uses numpy default_rng(seed + i).  (offset, meow) = (8, 500) is
+    the reference's law (8 - 13 Hz); (3, 200) the low-frequency record set of "C2_low_freq" (3 - 5 Hz)."""
     k = np.arange(T)
     window = 3141
     local = (k % window + 1) * dt
-    phase = (k // window) * (8.0 * window * dt) + 500.0 * np.exp(-5.0 / np.sin(local)) + 8.0 * local
+    phase = (k // window) * (offset * window * dt) + meow * np.exp(-5.0 / np.sin(local)) + offset * local
     if num_harmonics == 0:
         clean = np.sin(2 * math.pi * phase)
     else:
@@ -63,7 +64,10 @@ def make_workload(B, T, seed=0, kind='ekf'):
     from chirpgp_amd import models as pm
     from chirpgp_amd.quadratures import SigmaPoints
     params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
-    wl = dict(kind=kind, dt=1e-3, Xi=0.1, B=B, T=T)
+    low = kind == 'ekf_low'                  # C2 on a 3 - 5 Hz record set, initial frequency state 3: every chunk in the common regime
+    if low:
+        kind, params[5] = 'ekf', 3.
+    wl = dict(kind=kind, dt=1e-3, Xi=0.1, B=B, T=T, low=low)
     if kind == 'kf':
         wl['F'], wl['Sigma'] = frozen_frequency_linear_model(params, wl['dt'])
     if kind in ('harmonic', 'harmonic_ekf'):
@@ -71,7 +75,8 @@ def make_workload(B, T, seed=0, kind='ekf'):
         wl.update(ys=chirp_batch(B, T, seed, num_harmonics=3), sgps=SigmaPoints.cubature(8), d=8)
     else:
         drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
-        wl.update(ys=chirp_batch(B, T, seed), sgps=SigmaPoints.gauss_hermite(4, 3), d=4)
+        wl.update(ys=chirp_batch(B, T, seed, offset=3.0, meow=200.0) if low else chirp_batch(B, T, seed),
+                  sgps=SigmaPoints.gauss_hermite(4, 3), d=4)
     wl.update(drift=drift, disp=disp, disc=disc, m0=m0, P0=P0, H=H)
     return wl
 
@@ -218,7 +223,8 @@ N_SIMDS = 1024
 # op by op on the reference's formulas -- what a non-redundant evaluation has to do.  The executed-FLOP figure of the
 # valu_f64 roofline counts all 64 lanes of every instruction, i.e. also the work replicated across lanes / MFMA blocks.
 ALGORITHMIC_FLOP = {'kf': 1.2e3, 'ekf': 1.5e3, 'sgp': 25e3, 'cd_sgp': 110e3, 'harmonic': 25e3}
-OTHER_CONFIGS = (('C1', 'kf'), ('C3', 'sgp'), ('C4', 'cd_sgp'), ('C5', 'harmonic'))
+# C2_low_freq: C2 on records of 3 - 5 Hz (frequency state below 5 throughout): the headline kernel with every chunk in its common regime
+OTHER_CONFIGS = (('C1', 'kf'), ('C2_low_freq', 'ekf_low'), ('C3', 'sgp'), ('C4', 'cd_sgp'), ('C5', 'harmonic'))
 
 
 def parse_args(argv=None):
@@ -301,14 +307,17 @@ def roofline_of(kind, B, T, d, filt_ms, smooth_ms, bench_shape=False):
     # sigma-point / RK4 workloads: 80-220 flop per byte against a machine balance of ~10, so the
     # float64 vector pipe is the roof; the HBM fraction stays beside it.  `frac` = EXECUTED flop (all 64 lanes of every
     # instruction: issue occupancy, replicated work included); `algorithmic_frac` = useful flop of SURVEY.md 8d.
-    iss = valu_issue(kind, dom[0], units, dom[1]) if dom[1] else None
+    # (the committed instruction counts were profiled at the workload's DEFAULT batch per GPU: a shard of another size takes other
+    # launch shapes -- the time-split smoother doubles the executed work -- so the executed figures are withheld there)
+    profiled_shape = B == WORKLOADS[kind][1]
+    iss = valu_issue(kind, dom[0], units, dom[1]) if (dom[1] and profiled_shape) else None
     return {"bound": "valu_f64", "kernel": dom[0],
             "achieved": iss["executed_tflops"] if iss else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": iss["executed_tflops"] / F64_VALU_PEAK_TFLOPS if iss else None,
             "frac_counts": "executed wave-instructions x 64 lanes (replicated lanes included): issue occupancy, not useful work",
             "algorithmic_tflops": algo_tflops, "algorithmic_frac": hbm["algorithmic_frac"],
             "algorithmic_flop_per_trial_step": algo,
-            "executed_flop_source": iss["source"] if iss else None,
+            "executed_flop_source": iss["source"] if iss else (None if profiled_shape else f"withheld: profiled at B = {WORKLOADS[kind][1]} per GPU, this launch has B = {B}"),
             "valu_per_step": iss["valu_per_step"] if iss else None, "f64_per_step": iss["f64_per_step"] if iss else None,
             "cycles_per_step": iss["cycles_per_step"] if iss else None,
             "waves_per_simd": hbm["waves_per_simd"], "avg_launch_ms": dom[1], "traffic": None, "traffic_source": None,
@@ -418,6 +427,19 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         _engine.kernel_events = None
+        regimes = None
+        if wl['kind'] == 'ekf' and B > 0:
+            # which regimes of its speculative step the filter ran the 64-step chunks of THESE records in: one more, untimed,
+            # launch with the context's counters switched on (include/chirpgp_hip.h: cgp_debug_set / cgp_debug_counters)
+            _engine.debug_set(_engine.DBG_COUNT_REGIMES, 1)
+            _engine.debug_counters(reset=True)
+            step()
+            regimes = _engine.debug_counters(reset=True)
+            _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
+            chunks = B * ((T + 63) // 64)
+            regimes['chunks'] = chunks
+            regimes['high_share'] = regimes['high'] / chunks if chunks else None
+            regimes['kernel'] = 'ekf4_mfma_kernel (one trial per wavefront)' if (regimes['high'] + regimes['common'] + regimes['redone'] + regimes['checked']) else 'not counted by this launch shape'
         filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
         smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
         mine = [elapsed, float(np.mean(filt)) if filt else 0.0, float(np.mean(smooth)) if smooth else 0.0]
@@ -439,8 +461,41 @@ def main():
             assert out.shape[0] == B_total
         del f, s, ys_dev
         torch.cuda.empty_cache()
-        return dict(wl=wl, kind=kind, T=T, steps=steps, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
-                    filt_ms=mine[1], smooth_ms=mine[2], filt_ms_max=filt_max, smooth_ms_max=smooth_max)
+        return dict(wl=wl, kind=wl['kind'], T=T, steps=steps, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
+                    filt_ms=mine[1], smooth_ms=mine[2], filt_ms_max=filt_max, smooth_ms_max=smooth_max, regimes=regimes)
+
+    def measure_crlb(B, T, steps):
+        """The reference's only batched use of the path (tetralith/jobs/crlb_ekf.py:59-79): EKF over B simulated chirp-SDE
+        records of T steps, dt = 0.01, filter only -- with the means alone (what the job keeps) and with full outputs."""
+        from chirpgp_amd import tools
+        from chirpgp_amd.models import model_chirp, disc_chirp_lcd
+        _, _, m0, P0, H = model_chirp(0.1, 0.1, 1.0, 1.0, 0.1)
+        mc = disc_chirp_lcd(0.1, 0.1, 1.0, 1.0)
+        _, yss = tools.simulate_measurements(mc, H, 0.1, m0, P0, 0.01, T, 666 + rank, batch=B, states=False)
+        out = {"workload": "CRLB job shape: ekf filter only, chirp LCD model, dt = 0.01 (tetralith/jobs/crlb_ekf.py:59-79)", "d": 4, "T": T,
+               "batch_per_gpu": B, "steps": steps, "data": "simulated on the device (cgp_simulate)"}
+        for tag, want, nbytes in (("means_only", (True, False, False), 8 + 32), ("full_outputs", (True, True, True), 176)):
+            for _ in range(2):
+                r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want)
+            sync()
+            events = _engine.kernel_events = []
+            for _ in range(steps):
+                r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want)
+            sync()
+            _engine.kernel_events = None
+            ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
+            t = coll(torch.tensor([ms], dtype=torch.float64, device='cuda'))
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t[0])
+            out[tag] = {"filter_ms": ms, "value": B * world * T / (ms * 1e-3), "unit": "trial-steps/s",
+                        "algorithmic_bytes_per_trial_step": nbytes, "achieved_GBs": nbytes * B * T / (ms * 1e-3) / 1e9,
+                        "hbm_frac": nbytes * B * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del r
+            torch.cuda.empty_cache()
+        del yss
+        torch.cuda.empty_cache()
+        return out
 
     label, B_default, T_default, scaling_default, bound = WORKLOADS[args.workload]
     scaling = 'strong' if args.strong else (args.scaling or scaling_default)
@@ -454,11 +509,13 @@ def main():
     # The other BASELINE configurations under the same clock: a few passes each after the headline loop, their own default
     # sizes and scaling (C3 / C5: 1000 trials sharded; C4: 512 x 50 000 per GPU; C1: one record per rank).
     others = {}
+    crlb = None
     default_shape = args.workload == 'ekf' and args.batch is None and args.T is None and not args.flags
     if default_shape and not args.no_other_configs:
         for tag, kind in OTHER_CONFIGS:
-            _, Bo, To, mode_o, _ = WORKLOADS[kind]
+            _, Bo, To, mode_o, _ = WORKLOADS[kind if kind != 'ekf_low' else 'ekf']
             others[tag] = measure(kind, mode_o, Bo, To, args.other_steps, 1, {})
+        crlb = measure_crlb(262144, 500, args.other_steps)
 
     if use_dist:
         dist.destroy_process_group()       # ranks other than 0 are done: rank 0 times the host CPU with nobody spinning beside it
@@ -493,6 +550,10 @@ def main():
                         "filter_GBs": bf * units / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
                         "smoother_GBs": bs * units / (smooth_ms * 1e-3) / 1e9 if smooth_ms else None},
             "gather_ms": m['gather_ms'],
+            # chunks of 64 steps by the regime the filter's speculative step ran them in (counted by one untimed launch on the
+            # timed records): the HIGH regime is 6 % faster, so the headline depends on the records' frequency range --
+            # other_configs["C2_low_freq"] is the same pass on records that never enter it
+            "regimes": m['regimes'],
         }
         if other is not None:
             result["strong"] = {"value": other['B_total'] * T * args.steps / other['elapsed'], "unit": "trial-steps/s",
@@ -509,15 +570,24 @@ def main():
                 bfo, bso = bytes_per_trial_step(do)
                 tot = o['B_total'] * o['T']
                 per_pass = o['elapsed'] / o['steps']
+                if o['wl'].get('low'):
+                    lab += " -- record set of 3 - 5 Hz, initial frequency state 3 (all chunks in the common regime)"
                 oc[tag] = {"workload": lab, "d": do, "T": o['T'], "batch_per_gpu": o['B'], "global_batch": o['B_total'], "scaling": mode_o,
                            "steps": o['steps'], "filter_ms": o['filt_ms_max'], "smoother_ms": o['smooth_ms_max'],
                            "ms_per_pass": per_pass * 1e3, "value": tot / per_pass, "unit": "trial-steps/s",
                            "hbm_frac_per_gpu": (bfo + bso) * tot / per_pass / 1e9 / world / HBM_PEAK_GBS,
                            "roofline": roofline_of(o['kind'], o['B'], o['T'], do, o['filt_ms'], o['smooth_ms'])}
+                if o.get('regimes'):
+                    oc[tag]["regimes"] = o['regimes']
+            if crlb:
+                oc["CRLB_ekf"] = crlb
             result["other_configs"] = oc
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wl)
-            if result["cpu_baseline"]:
+            try:                                        # the GPU figures above are printed whatever happens to the host-side build / run
+                result["cpu_baseline"] = cpu_baseline(wl)
+            except Exception as exc:                    # noqa: BLE001 -- gcc missing, OpenMP failing, ...: report it, keep the line
+                result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}", "kind": "port", "value": None}
+            if result["cpu_baseline"].get("value"):
                 result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
                 result["gpu_over_cpu_one_core"] = result["value"] / result["cpu_baseline"]["one_core"]["value"]
         print(json.dumps(result))

@@ -49,7 +49,8 @@ class CgpInit(C.Structure):
 
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
-           'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox')
+           'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
+           'cgp_debug_set', 'cgp_debug_counters')
 
 _lib = None
 _lock = threading.Lock()
@@ -91,6 +92,10 @@ def load_library():
         lib.cgp_add_noise.restype = C.c_int
         lib.cgp_add_noise.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]
         lib.cgp_debug_philox.restype = C.c_int
+        lib.cgp_debug_set.restype = C.c_int
+        lib.cgp_debug_set.argtypes = [_vp, C.c_int, C.c_int64]
+        lib.cgp_debug_counters.restype = C.c_int
+        lib.cgp_debug_counters.argtypes = [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]
         lib.cgp_debug_philox.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, _vp]
         _lib = lib
         return lib
@@ -488,3 +493,22 @@ def debug_philox(ctr, key):
     rc = load_library().cgp_debug_philox(ctx, _ptr(c), _ptr(k), c.shape[0], _ptr(out), _stream())
     _check(ctx, rc, 'cgp_debug_philox')
     return out.cpu().numpy().view(np.uint32)
+
+
+DBG_WALK_SEGMENTS, DBG_COUNT_REGIMES = 1, 2
+REGIME_COUNTERS = ('high', 'common', 'redone', 'checked', 'high_left')
+
+
+def debug_set(key, value, device_index=None):
+    """Per-context tuning / measurement knob (include/chirpgp_hip.h: cgp_debug_set)."""
+    ctx = context(device_index)
+    _check(ctx, load_library().cgp_debug_set(ctx, int(key), int(value)), 'cgp_debug_set')
+
+
+def debug_counters(reset=True, device_index=None):
+    """The context's regime counters as a dict (waits for the current stream): chunks of 64 steps the d = 4 matrix-core EKF kept from
+    its HIGH / common regime, repeated with the checked step, ran on the checked step afterwards, and tried in HIGH but left it."""
+    ctx = context(device_index)
+    out = (C.c_uint64 * 8)()
+    _check(ctx, load_library().cgp_debug_counters(ctx, out, 1 if reset else 0, _stream()), 'cgp_debug_counters')
+    return {k: int(out[i]) for i, k in enumerate(REGIME_COUNTERS)}

@@ -140,7 +140,49 @@ int cgp_create(cgp_ctx** out, int device) {
     return CGP_OK;
 }
 
-void cgp_destroy(cgp_ctx* ctx) { delete ctx; }
+void cgp_destroy(cgp_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->counters_mem) {
+        DeviceScope on_device(ctx->device);
+        (void)hipFree(ctx->counters_mem);
+    }
+    delete ctx;
+}
+
+int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value) {
+    if (!ctx) return CGP_E_ARG;
+    switch (key) {
+    case CGP_DBG_WALK_SEGMENTS:
+        if (value < 0 || value > 4096) return fail(ctx, CGP_E_ARG, "CGP_DBG_WALK_SEGMENTS outside 0..4096");
+        ctx->walk_segments = (int)value;
+        return CGP_OK;
+    case CGP_DBG_COUNT_REGIMES: {
+        if (value != 0 && !ctx->counters_mem) {
+            DeviceScope on_device(ctx->device);
+            if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+            if (hipMalloc(&ctx->counters_mem, 8 * sizeof(unsigned long long)) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipMalloc of the counters failed");
+            if (hipMemset(ctx->counters_mem, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipMemset of the counters failed");
+        }
+        ctx->counters = value != 0 ? ctx->counters_mem : nullptr;
+        return CGP_OK;
+    }
+    default: return fail(ctx, CGP_E_ARG, "unknown cgp_debug_set key");
+    }
+}
+
+int cgp_debug_counters(cgp_ctx* ctx, uint64_t* out, int reset, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (!out) return fail(ctx, CGP_E_ARG, "out is NULL");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!ctx->counters_mem) return CGP_OK;
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(out, ctx->counters_mem, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(ctx, CGP_E_HIP, "copy of the counters failed");
+    if (reset && hipMemsetAsync(ctx->counters_mem, 0, 8 * sizeof(uint64_t), st) != hipSuccess) return fail(ctx, CGP_E_HIP, "reset of the counters failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipStreamSynchronize failed");
+    return CGP_OK;
+}
 
 const char* cgp_last_error(const cgp_ctx* ctx) {
     if (!ctx) return "null context";
@@ -174,6 +216,7 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.m0 = init->m0; io.m0_stride = init->m0_stride;
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
+    io.counters = ctx->counters;
     const ModelArgs ma = model_args(model, sigma, dt, flags);
     // which lane-cooperative kernel (if any) a wave-per-trial launch of this call would take decides the crossover
     const bool spec = !(flags & CGP_GENERIC_KERNEL);
@@ -241,10 +284,10 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
     // Time-split form of the discrete wave-per-trial smoothers: when the batch leaves two thirds of the SIMDs idle (or on
-    // request).  CGP_WALK_SEGMENTS in the environment caps the number of segments (tuning aid).
+    // request).  cgp_debug_set(CGP_DBG_WALK_SEGMENTS) caps the number of segments of this context (tuning aid).
     io.num_cus = ctx->num_cus;
     {
-        static const long env_segs = getenv("CGP_WALK_SEGMENTS") ? atol(getenv("CGP_WALK_SEGMENTS")) : 0;
+        const long env_segs = ctx->walk_segments;
         const bool forced = (flags & CGP_TIME_SPLIT) != 0;
         if ((flags & CGP_NO_TIME_SPLIT) || (!forced && 3 * B > (int64_t)ctx->num_cus * 4)) io.segs = 1;      // measured: x3 at B = 125, x1.6 at 250, x0.9 at 500
         else io.segs = env_segs > 1 ? (int)env_segs : (env_segs == 1 ? 1 : 0);

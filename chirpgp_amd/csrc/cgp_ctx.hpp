@@ -6,6 +6,9 @@
 struct cgp_ctx {
     int device;
     int num_cus;
+    int walk_segments = 0;                       // cgp_debug_set(CGP_DBG_WALK_SEGMENTS): 0 = choose, 1 = off, n = cap
+    unsigned long long* counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): eight device counters, NULL = off
+    unsigned long long* counters_mem = nullptr;  // the allocation (kept while counting is switched off)
 };
 
 namespace cgp {

@@ -27,6 +27,7 @@ struct FilterIO {
     double* __restrict__ Pfs;
     double* __restrict__ nll;
     uint32_t flags;
+    unsigned long long* __restrict__ counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): regime counters of the context, or NULL
     // The measurement record of a trial (include/chirpgp_hip.h, cgp_filter): trial b reads record ys_index[b / ys_repeat]
     // (b / ys_repeat without an index) -- a parameter sweep or the 2 P + 1 probes of a difference gradient read ONE copy.
     __device__ __forceinline__ const double* record(int64_t trial) const {

@@ -286,6 +286,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
     int checked_left = 0;
+    unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0;      // chunks by regime (scalars; cgp_debug_counters)
     // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
     // start exposes the whole memory latency (and, vmcnt counting in order, the drain of every store still in flight) once per
     // 64 steps -- 2.7 us of a 16 us chunk
@@ -353,13 +354,16 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             uncommon = 1;
             if (high) {
                 uncommon = chunk(std::true_type{});
-                if (uncommon != 0) x = x0;
+                if (uncommon != 0) { x = x0; n_high_left++; } else n_high++;
             }
-            if (uncommon != 0) uncommon = chunk(std::false_type{});
+            if (uncommon != 0) {
+                uncommon = chunk(std::false_type{});
+                if (uncommon == 0) n_common++;
+            }
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
-            if (redo) { x = x0; checked_left = kCheckedChunks; }
+            if (redo) { x = x0; checked_left = kCheckedChunks; n_redo++; } else n_checked++;
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
@@ -377,6 +381,11 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+    if (io.counters && lane == 0) {
+        atomicAdd(io.counters + 0, (unsigned long long)n_high); atomicAdd(io.counters + 1, (unsigned long long)n_common);
+        atomicAdd(io.counters + 2, (unsigned long long)n_redo); atomicAdd(io.counters + 3, (unsigned long long)n_checked);
+        atomicAdd(io.counters + 4, (unsigned long long)n_high_left);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- linear model, d = 4: kf

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 110          /* 0.1.1: measurement records may be shared between trials (cgp_filter) */
+#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters) */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -218,6 +218,20 @@ int cgp_debug_philox(cgp_ctx* ctx, const uint32_t* ctr, const uint32_t* key, int
  *     lean softplus pair (valid for 1.5 <= x < 700 only; ~1e-11), 9 reciprocal with one Newton step.
  *     out1 may be NULL for one-output ops. */
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream);
+
+/* Tuning / measurement hooks of ONE context (nothing process-wide, no environment variable is read by the library).
+ *   CGP_DBG_WALK_SEGMENTS   cap on the number of segments of the time-split smoothers (CGP_TIME_SPLIT): 0 = chosen from
+ *                           (B, T, CUs) (default), 1 = never split, n > 1 = at most n
+ *   CGP_DBG_COUNT_REGIMES   1: the d = 4 matrix-core EKF (one trial per wavefront) adds, per launch, the number of 64-step chunks
+ *                           it ran in each regime of its speculative step to the context's counters; 0 (default): it does not */
+#define CGP_DBG_WALK_SEGMENTS  1
+#define CGP_DBG_COUNT_REGIMES  2
+int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value);
+/* Waits for `stream`, copies the context's eight counters to the HOST array `out` and, with reset != 0, zeroes them.
+ *   out[0] chunks kept from the HIGH regime (frequency state >= 5 throughout)      out[1] chunks kept from the common regime (>= 1.5)
+ *   out[2] chunks repeated with the checked step (left the common regime)           out[3] chunks run on the checked step after such a repeat
+ *   out[4] chunks that were tried in the HIGH regime, left it and were repeated in the common regime      out[5..7] reserved (0) */
+int cgp_debug_counters(cgp_ctx* ctx, uint64_t* out, int reset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,18 @@ def test_default_line_carries_the_other_baseline_configs():
     r = _run('--steps', '3', '--warmup', '1', '--other-steps', '1', '--no-cpu-baseline')
     assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000 and r['roofline']['traffic'] is not None
     oc = r['other_configs']
-    assert set(oc) == {'C1', 'C3', 'C4', 'C5'}
+    assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf'}
+    # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
+    rg = r['regimes']
+    assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['checked'] == rg['chunks']
+    assert 0.7 < rg['high_share'] < 0.85 and rg['high_left'] < 0.05 * rg['chunks'] and rg['redone'] < 0.01 * rg['chunks']
+    low = oc['C2_low_freq']
+    assert (low['batch_per_gpu'], low['T'], low['d']) == (1000, 10000, 4) and low['filter_ms'] > 0 and low['smoother_ms'] > 0
+    assert low['regimes']['high'] == 0 and low['regimes']['common'] > 0.98 * low['regimes']['chunks']
+    crlb = oc['CRLB_ekf']
+    assert (crlb['batch_per_gpu'], crlb['T']) == (262144, 500)
+    for k in ('means_only', 'full_outputs'):
+        assert crlb[k]['filter_ms'] > 0 and 0 < crlb[k]['hbm_frac'] < 1
     assert (oc['C1']['batch_per_gpu'], oc['C1']['T'], oc['C1']['d']) == (1, 1000, 4)
     assert (oc['C3']['batch_per_gpu'], oc['C3']['T']) == (1000, 10000) and oc['C3']['scaling'] == 'strong'
     assert (oc['C4']['batch_per_gpu'], oc['C4']['T']) == (512, 50000)
@@ -84,5 +95,6 @@ def test_two_rank_rehearsal_of_the_default_line():
     oc = r['other_configs']
     assert oc['C3']['batch_per_gpu'] == 500 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 500
     assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 1024 and oc['C1']['global_batch'] == 2
-    assert all(v['value'] > 0 and v['filter_ms'] > 0 for v in oc.values())
+    assert all(v['value'] > 0 and v['filter_ms'] > 0 for k, v in oc.items() if k != 'CRLB_ekf')
+    assert oc['CRLB_ekf']['full_outputs']['filter_ms'] > 0
     assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0

@@ -5,6 +5,9 @@ import torch, bench
 from chirpgp_amd import filters_smoothers as fs
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 125
 kind = sys.argv[2] if len(sys.argv) > 2 else 'ekf'
+if len(sys.argv) > 3:                 # cap on the time-split segments of this context (cgp_debug_set)
+    from chirpgp_amd import _engine
+    _engine.debug_set(_engine.DBG_WALK_SEGMENTS, int(sys.argv[3]))
 wl = bench.make_workload(B, 10000, kind=kind)
 ys = torch.from_numpy(wl['ys']).cuda()
 if kind in ('ekf', 'harmonic_ekf'):

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 B=$1; KIND=$2; shift 2
 for S in "$@"; do
     D=gpurun_out/ts_prof_${KIND}_$S
-    CGP_WALK_SEGMENTS=$S rocprofv3 --kernel-trace --stats -d $D -o p --output-format csv -- python tools/ts_probe.py $B $KIND > /dev/null 2> $D.log
+    rocprofv3 --kernel-trace --stats -d $D -o p --output-format csv -- python tools/ts_probe.py $B $KIND $S > /dev/null 2> $D.log
     echo "segs $S"
     python - "$D" <<'PY'
 import csv, glob, sys
