@@ -289,7 +289,13 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     {
         const long env_segs = ctx->walk_segments;
         const bool forced = (flags & CGP_TIME_SPLIT) != 0;
-        if ((flags & CGP_NO_TIME_SPLIT) || (!forced && 3 * B > (int64_t)ctx->num_cus * 4)) io.segs = 1;      // measured: x3 at B = 125, x1.6 at 250, x0.9 at 500
+        // Not by default for the LINEAR model (rts): its F is the caller's, and composing the affine maps of hundreds of steps
+        // (C = Pf - G Pp G^T, A <- G A) is only as accurate as those products are well conditioned -- 1e-11 of the whole-record
+        // walk for the chirp family's gains (d = 4 ... 8, every parameter set of the tests), but 1e-7 for a random F at d = 6,
+        // where partial products of the gains grow in directions the true carry never excites.  The split is exact in exact
+        // arithmetic either way; for a linear model it is the caller's choice (CGP_TIME_SPLIT).
+        const bool own_model = model->model_id != CGP_M_LINEAR;
+        if ((flags & CGP_NO_TIME_SPLIT) || (!forced && (!own_model || 3 * B > (int64_t)ctx->num_cus * 4))) io.segs = 1;      // measured: x3 at B = 125, x1.6 at 250, x0.9 at 500
         else io.segs = env_segs > 1 ? (int)env_segs : (env_segs == 1 ? 1 : 0);
         io.min_tiles = forced ? 1 : 4;
     }

@@ -147,7 +147,10 @@ typedef struct cgp_init {
 #define CGP_ONE_TRIAL_PER_WAVE   0x400u /* ... one trial per wavefront whatever the batch                                      */
 #define CGP_TIME_SPLIT        0x800u  /* discrete smoothers (rts, eks, sgp_smoother), one wavefront per trial: cut every record into segments
                                         walked by different wavefronts (two passes: compose the segments' affine maps, then walk with the
-                                        right carry) whatever the batch -- default when the batch leaves two thirds of the SIMDs idle    */
+                                        right carry) whatever the batch -- default when the batch leaves two thirds of the SIMDs idle and
+                                        the model is one of the chirp family (eks, sgp_smoother); NOT default for CGP_M_LINEAR (rts): the
+                                        composed maps are exact in exact arithmetic but only as accurate as products of the caller's gains
+                                        are well conditioned (1e-11 of the one-wave walk for the chirp models, 1e-7 seen for a random F)   */
 #define CGP_NO_TIME_SPLIT     0x1000u /* ... never                                                                                      */
 #define CGP_SIM_FIXED_X0      0x20u  /* cgp_simulate: x_0 = m0 exactly, P0 unused (simulate_sde_init, simulate_lgssm)       */
 

@@ -65,7 +65,7 @@ def test_equivalence_on_linear_models(idx):
         npt.assert_allclose(rts_results[i], eks_results[i])
         npt.assert_allclose(rts_results[i], ghks_results[i])
         npt.assert_allclose(rts_results[i], cd_eks_results[i], atol=1e-1)
-        npt.assert_allclose(cd_eks_results[i], cd_ghks_results[i], rtol=1e-6)
+        npt.assert_allclose(cd_eks_results[i], cd_ghks_results[i])
     npt.assert_array_equal(rts_results[0][-1], kf_results[0][-1])
     npt.assert_array_equal(rts_results[1][-1], kf_results[1][-1])
 
@@ -325,16 +325,20 @@ def test_full_size_properties_and_parity():
     # smoothing never increases the marginal variance (up to rounding)
     dvar = torch.diagonal(Pfs - Pss, dim1=-2, dim2=-1)
     assert float(dvar.min()) > -1e-9 * float(torch.diagonal(Pfs, dim1=-2, dim2=-1).abs().max())
-    sel = np.arange(0, B, 8)
-    w_f = port.filter(port.F_EKF, wl['disc'], None, wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], wl['ys'][sel])
-    w_s = port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], w_f[0], w_f[1])
-    idx = torch.from_numpy(sel).cuda()
-    for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
-        cs.assert_close(g.cpu().numpy(), w, RTOL, f'full.{n}')
-        err = cs.max_rel_err(g.cpu().numpy(), w)
-        print(n, f'{err:.2e}')
-        # the bench kernels spend accuracy nobody asked for on a shorter chain (lean softplus polynomials, one Newton step on
-        # the reciprocals: cgp_fastmath.hpp) -- but no more than this: 1e-9 relative over the whole record, every 8th trial checked (125 of 1000)
+    # EVERY trial against the port (slabs of 250 trials bound the host memory; the port runs all 1000 x 10 000 in about a second)
+    worst = dict.fromkeys(('mfs', 'Pfs', 'nll', 'mss', 'Pss'), 0.0)
+    for lo in range(0, B, 250):
+        sl = slice(lo, lo + 250)
+        w_f = port.filter(port.F_EKF, wl['disc'], None, wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], wl['ys'][sl])
+        w_s = port.smoother(port.S_EKS, wl['disc'], None, wl['dt'], w_f[0], w_f[1])
+        for g, w, n in zip((mfs[sl], Pfs[sl], nll[sl], mss[sl], Pss[sl]), w_f + w_s, worst):
+            g = g.cpu().numpy()
+            cs.assert_close(g, w, RTOL, f'full.{n}')
+            worst[n] = max(worst[n], cs.max_rel_err(g, w))
+    print({n: f'{e:.2e}' for n, e in worst.items()})
+    # the bench kernels spend accuracy nobody asked for on a shorter chain (lean softplus polynomials, one Newton step on
+    # the reciprocals: cgp_fastmath.hpp) -- but no more than this: 1e-9 relative over the whole record, ALL 1000 trials checked
+    for n, err in worst.items():
         assert err <= 1e-9, (n, err)
 
 
@@ -741,18 +745,22 @@ def test_harmonic_models_per_trial_everything_and_nan(nh, kw):
 
 
 # ------------------------------------------------------------------ BASELINE configs C3, C4, C5 at their full per-GPU size
-@pytest.mark.parametrize('kind,every', [pytest.param('sgp', 50, id='C3_gh3_d4_1000x10000'), pytest.param('harmonic', 50, id='C5_cubature_d8_1000x10000'),
-                                        pytest.param('cd_sgp', 64, id='C4_cd_gh3_d4_512x50000')])
-def test_full_size_sigma_point_configs(kind, every):
+@pytest.mark.parametrize('kind,every,batch', [pytest.param('sgp', 1, None, id='C3_gh3_d4_1000x10000'), pytest.param('harmonic', 1, None, id='C5_cubature_d8_1000x10000'),
+                                              pytest.param('cd_sgp', 1, None, id='C4_cd_gh3_d4_512x50000'),
+                                              pytest.param('cd_sgp', 64, 4096, id='C4_whole_on_one_gpu_4096x50000')])
+def test_full_size_sigma_point_configs(kind, every, batch):
     """The sigma-point configurations at the size bench.py times them (B x T per GPU of BASELINE.json), results resident in HBM:
-    every `every`-th trial against the C port over the whole record, plus the size-independent properties on all trials
-    (finite; last smoothing row == last filtering row bit for bit; the discrete smoothers do not increase the marginal variance)."""
+    EVERY trial against the C port over the whole record (every == 1), plus the size-independent properties on all trials
+    (finite; last smoothing row == last filtering row bit for bit; the discrete smoothers do not increase the marginal variance).
+    C4 also whole on one GPU (4096 x 50 000: DESIGN.md section 7's recipe for fewer than eight GPUs): the properties on all 4096
+    trials, every 64th against the port."""
     import copy
     import torch
     import bench
     from oracle import port
     fs = _fs()
     label, B, T, _, _ = bench.WORKLOADS[kind]
+    B = batch or B
     wl = bench.make_workload(B, T, seed=0, kind=kind)
     ys = torch.from_numpy(wl['ys']).cuda()
     a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'])
@@ -769,20 +777,26 @@ def test_full_size_sigma_point_configs(kind, every):
     if kind != 'cd_sgp':      # exact for the discrete smoothers; the RK4-integrated backward ODE keeps it only to its own truncation error
         dvar = torch.diagonal(Pfs - Pss, dim1=-2, dim2=-1)
         assert float(dvar.min()) > -1e-9 * float(torch.diagonal(Pfs, dim1=-2, dim2=-1).abs().max())
-    sel = np.arange(0, B, every)
-    if kind == 'cd_sgp':
-        dg = copy.copy(wl['drift'])
-        dg.gamma = wl['disp'].outer()
-        w_f = port.filter(port.F_CD_SGP, dg, wl['sgps'], *a, wl['ys'][sel])
-        w_s = port.smoother(port.S_CD_SGP, dg, wl['sgps'], wl['dt'], w_f[0], w_f[1])
-    else:
-        w_f = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a, wl['ys'][sel])
-        w_s = port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], w_f[0], w_f[1])
-    idx = torch.from_numpy(sel).cuda()
-    for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, ('mfs', 'Pfs', 'nll', 'mss', 'Pss')):
-        cs.assert_close(g.cpu().numpy(), w, RTOL, f'{kind} full size: {n}')
-        err = cs.max_rel_err(g.cpu().numpy(), w)
-        print(kind, n, f'{err:.2e}')
+    sel_all = np.arange(0, B, every)
+    worst = dict.fromkeys(('mfs', 'Pfs', 'nll', 'mss', 'Pss'), 0.0)
+    slab = 128 if kind != 'sgp' else 250                     # trials per port call: bounds the host memory (d = 8: 1.2 MB a trial-record)
+    for lo in range(0, len(sel_all), slab):
+        sel = sel_all[lo:lo + slab]
+        if kind == 'cd_sgp':
+            dg = copy.copy(wl['drift'])
+            dg.gamma = wl['disp'].outer()
+            w_f = port.filter(port.F_CD_SGP, dg, wl['sgps'], *a, wl['ys'][sel])
+            w_s = port.smoother(port.S_CD_SGP, dg, wl['sgps'], wl['dt'], w_f[0], w_f[1])
+        else:
+            w_f = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a, wl['ys'][sel])
+            w_s = port.smoother(port.S_SGP, wl['disc'], wl['sgps'], wl['dt'], w_f[0], w_f[1])
+        idx = torch.from_numpy(sel).cuda()
+        for g, w, n in zip((mfs[idx], Pfs[idx], nll[idx], mss[idx], Pss[idx]), w_f + w_s, worst):
+            g = g.cpu().numpy()
+            cs.assert_close(g, w, RTOL, f'{kind} full size: {n}')
+            worst[n] = max(worst[n], cs.max_rel_err(g, w))
+    print(kind, B, {n: f'{e:.2e}' for n, e in worst.items()})
+    for n, err in worst.items():
         assert err <= 1e-7, (kind, n, err)
 
 
@@ -919,7 +933,9 @@ def test_bat_call_parameters_track_the_sweep():
         for k in ('sgp_filter', 'sgp_smoother'):
             for gv, wv in zip(got[k][:2], want[k][:2]):
                 assert np.isfinite(gv).all()
-                assert np.max(np.abs(gv - wv)) <= 1e-2 * np.max(np.abs(wv))
+                err = np.max(np.abs(gv - wv)) / np.max(np.abs(wv))
+                print(kw, k, f'{err:.2e}')
+                assert err <= 1e-4           # above the 6e-6 by which the two CPU oracles disagree on this ill-conditioned start
         mss, Pss = got['sgp_smoother']
         est = gaussian_expectation(ms=mss[:, -2], chol_Ps=np.sqrt(Pss[:, -2, -2]), func=g, force_shape=True)[:, 0] * 1e4
         assert np.max(np.abs(est[T // 3:] / truth[T // 3:] - 1.0)) < 0.05, 'smoothed frequency off the sweep'

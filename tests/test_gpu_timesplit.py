@@ -228,3 +228,25 @@ def test_small_batch_takes_the_time_split_form_by_default_and_is_faster():
     for a, b in zip(auto, whole):
         cs.assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-11, 'auto vs whole')
     assert t_auto < 0.5 * t_whole, (t_auto, t_whole)
+
+
+def test_linear_models_split_on_request_only():
+    """`rts` on a caller-supplied F never takes the time-split form by default (its accuracy depends on the conditioning of products
+    of the caller's gains: 1e-7 for the random F of test_random_record_lengths_split_equals_whole): at the small batch where `eks`
+    splits, the default `rts` launch equals the one-wave-per-trial form bit for bit, and CGP_TIME_SPLIT still switches it on."""
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    from chirpgp_amd import models as pm
+    d, B, T = 6, 16, 2000
+    rng = np.random.default_rng(77)
+    F = np.eye(d) * 0.97 + 0.02 * rng.standard_normal((d, d))
+    S = np.eye(d) * 0.05
+    lin = pm.linear_cond_m_cov(F, S)
+    f = port.filter(port.F_EKF, lin, None, np.ones(d), 0.1, np.zeros(d), np.eye(d), 0., rng.standard_normal((B, T)))
+    auto = fs.rts(F, S, f[0], f[1])
+    whole = fs.rts(F, S, f[0], f[1], flags=NO_TIME_SPLIT)
+    split = fs.rts(F, S, f[0], f[1], **SPLIT)
+    for a, w, s in zip(auto, whole, split):
+        assert np.array_equal(a, w)
+        assert not np.array_equal(s, w)
+        cs.assert_close(s, w, 1e-6, 'rts split on request')
