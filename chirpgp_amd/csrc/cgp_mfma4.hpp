@@ -95,14 +95,23 @@ CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, do
         auto bcast1 = [](double v) { if constexpr (E1 == 2) return row_bcast_f64<1>(v); else return dpp_f64<kQuadBcast1>(v); };
         const double Q = mfma4(x.P, RJT, 0.0);
         const double Pa = bcast1(Q);                                   // (P a)[r] = Q[r][1], a = J^T H = row 1 of J
+#ifdef CGP_EKF4_S_BCAST
+        PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q]
+        Pp = mfma4(RJT, Q, K.Sig);
+#else
         Pp = mfma4(RJT, Q, K.Sig);
         PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q], beside Pp
+#endif
         PHr = bcast1(Pp);                                              // Pp[r][1]
         if constexpr (E1 == 1) {
             const double a = dpp_f64<kQuadBcast1>(RJT);                // a[r] = J[1][r]
             S = mfma4(a, Pa, K.c0);                                    // a . (P a) + Sigma_11 + Xi, per MFMA block
         } else {
+#ifdef CGP_EKF4_S_BCAST
+            S = bcast1(PHq) + K.Xi;                                    // Pp[1][1] is entry 1 of (H Pp) by column: one row broadcast
+#else
             S = readlane_f64(Pp, 17) + K.Xi;                           // lane (r, b, q) = (1, 0, 1)
+#endif
         }
         innov = y - bcast1(f_q);                                       // H . f = f[1]
     } else {
@@ -181,6 +190,21 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 // compiler pairs into v_max3_u32 across steps; round 3 first had them as v_cmp + s_or_b64 pairs: five instructions a step):
 // u = the largest offset of u2's high word from that of 1.5 (NaN, inf, negative and out-of-range values land above the
 // offset of 700 as unsigned numbers), d = the largest high word of |d| (NaN above everything).
+#ifdef CGP_EKF4_VERDICT_MINMAX
+// Four running extremes of raw high words (v_max3_u32 / v_min3_u32 / v_max3_i32 pair two steps each): no per-step offset or mask
+//   umax / umin   unsigned extremes of u2's high word: a negative, NaN or infinite u2 lands above 700's word
+//   d, di         unsigned and signed maximum of d's high word: the unsigned one is ruled by the negative increments (sign bit),
+//                 the signed one by the positive ones; masked with 0x7FFFFFFF each is the magnitude of the largest of its sign
+struct Ekf4Verdict {
+    unsigned u = 0u, umin = 0xFFFFFFFFu, d = 0u;
+    int di = 0;
+    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {
+        constexpr unsigned lo = HIGH ? 0x40140000u : 0x3FF80000u;
+        return __builtin_amdgcn_ballot_w64(u > 0x4085DFFFu || umin < lo) |
+               __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= 0x3F800000u || ((unsigned)di & 0x7FFFFFFFu) >= 0x3F800000u);
+    }
+};
+#else
 struct Ekf4Verdict {
     unsigned u = 0u, d = 0u;
     // HIGH: the chunk ran on the short polynomials of the regime u2 >= 5 (cgp_fastmath.hpp: SpecRegsHigh)
@@ -189,6 +213,7 @@ struct Ekf4Verdict {
         return __builtin_amdgcn_ballot_w64(u > span) | __builtin_amdgcn_ballot_w64(d >= 0x3F800000u);      // ... or |d| >= 2^-7
     }
 };
+#endif
 template <int E1, bool HIGH = false>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
                                   double& S, double& innov, Ekf4Verdict& verdict) {
@@ -199,14 +224,39 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);
     else softplus_tail_lean(R, t, qa, dsp);                                          // qa = ang log1p(t) / t
     const double d = fma(qa, t, lin);
+#if defined(CGP_EKF4_SHEAR)
+    // the rotation by d as three shears (exact for tau = tan(d / 2), s = sin d; det = 1 for any tau, s):
+    //     A1 = A + tau B,   B' = B - s A1,   A' = A1 + tau B'          tau = d (1/2 + d^2 / 24), s = d (1 - d^2 / 6)
+    // eight operations where cos / sin of d and the four products take ten
+    const double d2 = d * d;
+    const double tau = d * fma(d2, R.c4, 0.5);
+    const double sn = d * fma(d2, R.s3, 1.0);
+    const double A1 = fma(tau, a.B, a.A);
+    const double B = fma(-sn, A1, a.B);
+    const double A = fma(tau, B, A1);
+#elif defined(CGP_EKF4_CDHORNER)
+    const double d2 = d * d;
+    const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
+    const double cd = fma(d2, fma(d2, R.c4, -0.5), 1.0);                             // 1 - d^2/2 + d^4/24, Horner: one multiplication less
+    const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
+#else
     const double d2 = d * d, d4 = d2 * d2;
     const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
     const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
     const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
+#endif
+#ifdef CGP_EKF4_VERDICT_MINMAX
+    const unsigned hx = (unsigned)__double2hiint(u2), hd = (unsigned)__double2hiint(d);
+    verdict.u = verdict.u > hx ? verdict.u : hx;
+    verdict.umin = verdict.umin < hx ? verdict.umin : hx;
+    verdict.d = verdict.d > hd ? verdict.d : hd;
+    verdict.di = verdict.di > (int)hd ? verdict.di : (int)hd;
+#else
     const unsigned hx = (unsigned)__double2hiint(u2) - (HIGH ? 0x40140000u : 0x3FF80000u);  // 5 (1.5) -> 0, 700 -> the span above
     const unsigned hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
+#endif
     a.th += d; a.A = A; a.B = B;
     ekf4_mfma_finish_j<E1>(K, y, A, HIGH ? dsp : K.kja * dsp, x, S, innov);          // HIGH: K.kja rides in the polynomial (SpecRegsHigh::init)
 }

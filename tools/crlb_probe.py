@@ -1,0 +1,24 @@
+"""tools/crlb_probe.py B T flags want: the EKF of the CRLB job's shape (tetralith/jobs/crlb_ekf.py:59-79) a few times, for rocprofv3.
+want = means | full;  flags = CGP_* launch-shape bits (0 = default, 4 = one lane per trial, 0x200 = four trials per wave)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from chirpgp_amd import filters_smoothers as fs, tools, _engine
+from chirpgp_amd.models import model_chirp, disc_chirp_lcd
+B, T, flags = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3], 0)
+want = (True, False, False) if sys.argv[4] == 'means' else (True, True, True)
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+_, _, m0, P0, H = model_chirp(0.1, 0.1, 1.0, 1.0, 0.1)
+mc = disc_chirp_lcd(0.1, 0.1, 1.0, 1.0)
+_, yss = tools.simulate_measurements(mc, H, 0.1, m0, P0, 0.01, T, 666, batch=B, states=False)
+kw = dict(flags=flags) if flags else {}
+r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want, **kw)
+torch.cuda.synchronize()
+ev = _engine.kernel_events = []
+for _ in range(reps):
+    r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want, **kw)
+torch.cuda.synchronize()
+_engine.kernel_events = None
+ms = min(a.elapsed_time(b) for _, a, b in ev)
+nb = (40 if sys.argv[4] == 'means' else 176) * B * T
+print(f'B={B} T={T} flags={flags:#x} {sys.argv[4]}: {ms:.3f} ms  {nb / ms / 1e6:.0f} GB/s algorithmic')
