@@ -32,13 +32,6 @@ CGP_DEV double horner(double p, double x, double c) {
     return d;
 }
 
-// p 2^k for a NORMAL result: k added into the exponent field (one v_lshl_add_u32 on the high word) -- kf = k + 1.5 2^52 carries k
-// in its low word.  Replaces v_cvt_i32_f64 + v_ldexp_f64 where the result cannot leave the normal range (x < 700).
-CGP_DEV double scale_pow2_bits(double p, double kf) {
-    return __hiloint2double(__double2hiint(p) + (__double2loint(kf) << 20), __double2loint(p));
-}
-constexpr double kRoundMagic = 6755399441055744.0;      // 1.5 2^52: fma(x, c, magic) - magic = rint(x c) for |x c| < 2^51
-
 // 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
 CGP_DEV double rcp_nr(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -362,17 +355,16 @@ constexpr double kLog1pOverTLean[8] = {0.999999999990116, -0.49999999432118947, 
 // step wants the rotation angle scale * softplus, so the scale rides in the coefficients: one multiply less on the chain).
 struct SpecRegs {
     double ex[8], lq[8];
-    double log2e, ln2hi, ln2lo, ln2, magic;
-    double s3, s5, c4, c6;       // -1/6, 1/120, 1/24, -1/720
+    double log2e, ln2hi, ln2lo, ln2;
+    double s3, c4;               // -1/6, 1/24: the rotation increment's sin d = d (1 + s3 d^2), tan(d / 2) = d (1/2 + c4 d^2)
     // PIN = false leaves the values as ordinary constants the compiler may rematerialise: fewer live registers, a few
     // more moves -- the trade for a kernel that wants two waves per SIMD rather than the shortest chain
     template <bool PIN = true> CGP_DEV void init(double scale = 1.0) {
         auto keep = [](double v) { return PIN ? FastMathRegs::pin(v) : v; };
         CGP_UNROLL for (int i = 0; i < 8; i++) ex[i] = keep(kExpLean[i]);
         CGP_UNROLL for (int i = 0; i < 8; i++) lq[i] = keep(kLog1pOverTLean[i] * scale);
-        log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo); ln2 = keep(kLn2Hi + kLn2Lo); magic = keep(kRoundMagic);
-        s3 = keep(-1.0 / 6.0); s5 = keep(1.0 / 120.0);
-        c4 = keep(1.0 / 24.0); c6 = keep(-1.0 / 720.0);
+        log2e = keep(kLog2e); ln2hi = keep(kLn2Hi); ln2lo = keep(kLn2Lo); ln2 = keep(kLn2Hi + kLn2Lo);
+        s3 = keep(-1.0 / 6.0); c4 = keep(1.0 / 24.0);
     }
 };
 // exp(-x) for |x| < 700 with the lean polynomial: x = -(k ln2 + r), three Estrin levels, v_ldexp_f64.
@@ -395,23 +387,14 @@ CGP_DEV double exp_neg_lean(const Regs& R, double x) {
 template <class Regs>
 CGP_DEV double exp_neg_lean1(const Regs& R, double x) {
     const double nx = -x;
-#ifdef CGP_EKF4_EXPADD
-    const double kf = fma(nx, R.log2e, R.magic);
-    const double k = kf - R.magic;
-#else
     const double k = __builtin_rint(nx * R.log2e);
-#endif
     const double r = fma(-k, R.ln2, nx);
     const double r2 = r * r;
     const double a0 = horner(R.ex[1], r, R.ex[0]), a1 = horner(R.ex[3], r, R.ex[2]);
     const double a2 = horner(R.ex[5], r, R.ex[4]), a3 = horner(R.ex[7], r, R.ex[6]);
     const double r4 = r2 * r2;
     const double b0 = horner(a1, r2, a0), b1 = horner(a3, r2, a2);
-#ifdef CGP_EKF4_EXPADD
-    return scale_pow2_bits(horner(b1, r4, b0), kf);
-#else
     return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
-#endif
 }
 // scale * log1p(t) / t  (scale folded into R.lq) and the softplus derivative 1 / (1 + t), t = exp(-x) <= exp(-1.5).
 template <class Regs>
@@ -454,22 +437,13 @@ struct SpecRegsHigh {
 template <class Regs>
 CGP_DEV double exp_neg_high(const Regs& R, const SpecRegsHigh& H, double x) {
     const double nx = -x;
-#ifdef CGP_EKF4_EXPADD
-    const double kf = fma(nx, R.log2e, R.magic);
-    const double k = kf - R.magic;
-#else
     const double k = __builtin_rint(nx * R.log2e);
-#endif
     const double r = fma(-k, R.ln2, nx);
     const double r2 = r * r;
     const double a0 = horner(H.ex[1], r, H.ex[0]), a1 = horner(H.ex[3], r, H.ex[2]), a2 = horner(H.ex[5], r, H.ex[4]);
     const double r4 = r2 * r2;
     const double b0 = horner(a1, r2, a0), b1 = horner(H.ex[6], r2, a2);
-#ifdef CGP_EKF4_EXPADD
-    return scale_pow2_bits(horner(b1, r4, b0), kf);
-#else
     return __builtin_amdgcn_ldexp(horner(b1, r4, b0), (int)k);
-#endif
 }
 // scale * log1p(t) / t and dscale / (1 + t) for t <= exp(-5)
 CGP_DEV void softplus_tail_high(const SpecRegsHigh& H, double t, double& q_scaled, double& dsp) {

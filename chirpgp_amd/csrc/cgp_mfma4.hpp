@@ -69,7 +69,7 @@ struct Ekf4State {
 //     (Pp H)[r] = Pp[r][1]  by row                      one quad broadcast of Pp
 //     (H Pp)[q] = Pp[1][q]  by column                   mfma(A = P a, B = RJT, C = Sigma[1][q]) = (J P a)[q] + Sigma[1][q]: a lane
 //                                                        cannot fetch another ROW cheaply; issued beside Pp, not behind it
-//     S = Pp[1][1] + Xi                                 E1 == 2 (one trial per wavefront): a v_readlane pair of lane (1, 1);
+//     S = Pp[1][1] + Xi                                 E1 == 2 (one trial per wavefront): entry 1 of (H Pp) by column, one row broadcast;
 //                                                        E1 == 1 (one trial per MFMA block, the x4 kernel): mfma(A = a, B = P a, C = Sigma_11 + Xi)
 //     H f = f[1]                                        one quad broadcast of f by column
 // -- FIVE matrix instructions a step (f by row, f by column, Q, Pp, H Pp) where the general form has eight.  What this kernel
@@ -95,23 +95,16 @@ CGP_DEV void ekf4_mfma_finish_j(const Ekf4MfmaConst& K, double y, double J0T, do
         auto bcast1 = [](double v) { if constexpr (E1 == 2) return row_bcast_f64<1>(v); else return dpp_f64<kQuadBcast1>(v); };
         const double Q = mfma4(x.P, RJT, 0.0);
         const double Pa = bcast1(Q);                                   // (P a)[r] = Q[r][1], a = J^T H = row 1 of J
-#ifdef CGP_EKF4_S_BCAST
-        PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q]
-        Pp = mfma4(RJT, Q, K.Sig);
-#else
-        Pp = mfma4(RJT, Q, K.Sig);
         PHq = mfma4(Pa, RJT, K.SigHq);                                 // (J P a)[q] + Sigma[1][q] = Pp[1][q], beside Pp
-#endif
+        Pp = mfma4(RJT, Q, K.Sig);
         PHr = bcast1(Pp);                                              // Pp[r][1]
         if constexpr (E1 == 1) {
             const double a = dpp_f64<kQuadBcast1>(RJT);                // a[r] = J[1][r]
             S = mfma4(a, Pa, K.c0);                                    // a . (P a) + Sigma_11 + Xi, per MFMA block
         } else {
-#ifdef CGP_EKF4_S_BCAST
-            S = bcast1(PHq) + K.Xi;                                    // Pp[1][1] is entry 1 of (H Pp) by column: one row broadcast
-#else
-            S = readlane_f64(Pp, 17) + K.Xi;                           // lane (r, b, q) = (1, 0, 1)
-#endif
+            // Pp[1][1] is entry 1 of (H Pp) by column: ONE row broadcast (round 4; a v_readlane pair of lane (1, 1) of Pp
+            // before: 16 issue cycles against 5 -- 2.19 -> 2.16 ms)
+            S = bcast1(PHq) + K.Xi;
         }
         innov = y - bcast1(f_q);                                       // H . f = f[1]
     } else {
@@ -153,15 +146,15 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // cgp_fastmath.hpp (ang rides in q's coefficients), valid for u2 >= 1.5.  Rotation: (cos, sin)(theta) is advanced
 // INCREMENTALLY from the previous step's,
 //     (cos, sin)(theta) = rotation of (cos, sin)(theta_prev) by d = theta - theta_prev,
-// with sin d, cos d to d^3 / d^4 (remainders < 2.4e-13 d while |d| <= 2^-7): 6 dependent operations instead of the 13 of a
+// as three shears with tan(d / 2), sin d to d^3 (remainders < 7.6e-15 d while |d| <= 2^-8): 6 dependent operations instead of the 13 of a
 // fresh sincos.  d is formed as ang q t + (ang u2 - theta_prev), whose second term does not wait for the polynomials; what
 // accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
-// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-7 (or NaN) marks
+// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-8 (or NaN) marks
 // the chunk's verdict (Ekf4Verdict) and the whole chunk is repeated with the checked step.
 //
 // What is rotated is not (cos, sin) but this lane's entry of J0 itself and its quarter-turn partner,
-//     A = rho (kc cos + ks sin) + kk = J0[q][r],     B = rho (ks cos - kc sin):     A' = cd A + sd B,   B' = cd B - sd A:
-// four operations give the next J0 entry directly, where rotating (cos, sin) and then forming the entry took six.  In the
+//     A = rho (kc cos + ks sin) + kk = J0[q][r],     B = rho (ks cos - kc sin):     A' = cd A + sd B,   B' = cd B - sd A
+// gives the next J0 entry directly, where rotating (cos, sin) and then forming the entry took two operations more.  In the
 // lanes outside the rotation block (A = kk or 0, B = 0) the increment d is ZERO, hence sd = 0, cd = 1 and A' = A: the angle
 // scale rides in per-lane coefficients (K.angm and the polynomial of SpecRegs::init(K.angm)) that vanish there, at no cost.
 // (The verdict on |d| is taken over the wavefront, so the lanes of the rotation block speak for it.)
@@ -190,30 +183,20 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 // compiler pairs into v_max3_u32 across steps; round 3 first had them as v_cmp + s_or_b64 pairs: five instructions a step):
 // u = the largest offset of u2's high word from that of 1.5 (NaN, inf, negative and out-of-range values land above the
 // offset of 700 as unsigned numbers), d = the largest high word of |d| (NaN above everything).
-#ifdef CGP_EKF4_VERDICT_MINMAX
-// Four running extremes of raw high words (v_max3_u32 / v_min3_u32 / v_max3_i32 pair two steps each): no per-step offset or mask
+// Round 4: four running extremes of RAW high words (v_max3_u32 / v_min3_u32 / v_max3_i32 pair two steps each): no per-step offset or mask
 //   umax / umin   unsigned extremes of u2's high word: a negative, NaN or infinite u2 lands above 700's word
 //   d, di         unsigned and signed maximum of d's high word: the unsigned one is ruled by the negative increments (sign bit),
 //                 the signed one by the positive ones; masked with 0x7FFFFFFF each is the magnitude of the largest of its sign
+constexpr unsigned kIncrementBound = 0x3F700000u;      // high word of 2^-8
 struct Ekf4Verdict {
     unsigned u = 0u, umin = 0xFFFFFFFFu, d = 0u;
     int di = 0;
     template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {
         constexpr unsigned lo = HIGH ? 0x40140000u : 0x3FF80000u;
-        return __builtin_amdgcn_ballot_w64(u > 0x4085DFFFu || umin < lo) |
-               __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= 0x3F800000u || ((unsigned)di & 0x7FFFFFFFu) >= 0x3F800000u);
+        return __builtin_amdgcn_ballot_w64(u > 0x4085DFFFu || umin < lo) |                                                  // u2 outside [lo, 700)
+               __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound);   // |d| >= 2^-8
     }
 };
-#else
-struct Ekf4Verdict {
-    unsigned u = 0u, d = 0u;
-    // HIGH: the chunk ran on the short polynomials of the regime u2 >= 5 (cgp_fastmath.hpp: SpecRegsHigh)
-    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {          // wave mask of the lanes that left the speculative regime
-        constexpr unsigned span = HIGH ? 0x4085DFFFu - 0x40140000u : 0x4085DFFFu - 0x3FF80000u;      // u2 in [5, 700) / [1.5, 700)
-        return __builtin_amdgcn_ballot_w64(u > span) | __builtin_amdgcn_ballot_w64(d >= 0x3F800000u);      // ... or |d| >= 2^-7
-    }
-};
-#endif
 template <int E1, bool HIGH = false>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
                                   double& S, double& innov, Ekf4Verdict& verdict) {
@@ -224,39 +207,22 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);
     else softplus_tail_lean(R, t, qa, dsp);                                          // qa = ang log1p(t) / t
     const double d = fma(qa, t, lin);
-#if defined(CGP_EKF4_SHEAR)
-    // the rotation by d as three shears (exact for tau = tan(d / 2), s = sin d; det = 1 for any tau, s):
-    //     A1 = A + tau B,   B' = B - s A1,   A' = A1 + tau B'          tau = d (1/2 + d^2 / 24), s = d (1 - d^2 / 6)
-    // eight operations where cos / sin of d and the four products take ten
+    // The rotation by d as three shears (round 4) -- exact for tau = tan(d / 2), s = sin d, and of determinant 1 for ANY tau, s:
+    //     A1 = A + tau B,   B' = B - s A1,   A' = A1 + tau B',        tau = d (1/2 + d^2 / 24),   s = d (1 - d^2 / 6)
+    // eight operations where cos d, sin d and the four products of the plain rotation took ten (2.19 -> 2.15 ms).  Dropped terms:
+    // d^5 / 240 in tau, d^5 / 120 in s -- below 7.6e-15 relative while |d| <= 2^-8, the verdict's bound (2^-7 in round 3, where
+    // 64 steps at the bound could add up to 1.5e-11; the bench records' largest increment is 3.4e-3 = 2^-8.2).
     const double d2 = d * d;
     const double tau = d * fma(d2, R.c4, 0.5);
     const double sn = d * fma(d2, R.s3, 1.0);
     const double A1 = fma(tau, a.B, a.A);
     const double B = fma(-sn, A1, a.B);
     const double A = fma(tau, B, A1);
-#elif defined(CGP_EKF4_CDHORNER)
-    const double d2 = d * d;
-    const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
-    const double cd = fma(d2, fma(d2, R.c4, -0.5), 1.0);                             // 1 - d^2/2 + d^4/24, Horner: one multiplication less
-    const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
-#else
-    const double d2 = d * d, d4 = d2 * d2;
-    const double sd = fma(d * d2, R.s3, d);                                          // d - d^3/6
-    const double cd = fma(d4, R.c4, fma(-0.5, d2, 1.0));                             // 1 - d^2/2 + d^4/24
-    const double A = fma(cd, a.A, sd * a.B), B = fma(cd, a.B, -(sd * a.A));
-#endif
-#ifdef CGP_EKF4_VERDICT_MINMAX
     const unsigned hx = (unsigned)__double2hiint(u2), hd = (unsigned)__double2hiint(d);
     verdict.u = verdict.u > hx ? verdict.u : hx;
     verdict.umin = verdict.umin < hx ? verdict.umin : hx;
     verdict.d = verdict.d > hd ? verdict.d : hd;
     verdict.di = verdict.di > (int)hd ? verdict.di : (int)hd;
-#else
-    const unsigned hx = (unsigned)__double2hiint(u2) - (HIGH ? 0x40140000u : 0x3FF80000u);  // 5 (1.5) -> 0, 700 -> the span above
-    const unsigned hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
-    verdict.u = verdict.u > hx ? verdict.u : hx;
-    verdict.d = verdict.d > hd ? verdict.d : hd;
-#endif
     a.th += d; a.A = A; a.B = B;
     ekf4_mfma_finish_j<E1>(K, y, A, HIGH ? dsp : K.kja * dsp, x, S, innov);          // HIGH: K.kja rides in the polynomial (SpecRegsHigh::init)
 }
