@@ -43,7 +43,7 @@ ISSUE_TABLE = 'profiles/r03_issue_table.json'
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0, offset=8.0, meow=500.0):
     """Synthetic toy chirp of SURVEY.md 8d: meow frequency law (toymodels.py:226-268) tiled in 3141-step windows,
     constant magnitude 1, y = chirp + sqrt(Xi) N(0, 1); trial i uses numpy default_rng(seed + i).  (offset, meow) = (8, 500) is
-    the reference's law (8 - 13 Hz); (3, 200) the low-frequency record set of "C2_low_freq" (3 - 5 Hz)."""
+    the reference's law (8 - 13 Hz); (3.5, 100) the low-frequency record set of "C2_low_freq" (3.5 - 4.5 Hz)."""
     k = np.arange(T)
     window = 3141
     local = (k % window + 1) * dt
@@ -64,9 +64,9 @@ def make_workload(B, T, seed=0, kind='ekf'):
     from chirpgp_amd import models as pm
     from chirpgp_amd.quadratures import SigmaPoints
     params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
-    low = kind == 'ekf_low'                  # C2 on a 3 - 5 Hz record set, initial frequency state 3: every chunk in the common regime
+    low = kind == 'ekf_low'                  # C2 on a 3.5 - 4.5 Hz record set, initial frequency state 3.5: every chunk in the common regime
     if low:
-        kind, params[5] = 'ekf', 3.
+        kind, params[5] = 'ekf', 3.5
     wl = dict(kind=kind, dt=1e-3, Xi=0.1, B=B, T=T, low=low)
     if kind == 'kf':
         wl['F'], wl['Sigma'] = frozen_frequency_linear_model(params, wl['dt'])
@@ -75,7 +75,7 @@ def make_workload(B, T, seed=0, kind='ekf'):
         wl.update(ys=chirp_batch(B, T, seed, num_harmonics=3), sgps=SigmaPoints.cubature(8), d=8)
     else:
         drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
-        wl.update(ys=chirp_batch(B, T, seed, offset=3.0, meow=200.0) if low else chirp_batch(B, T, seed),
+        wl.update(ys=chirp_batch(B, T, seed, offset=3.5, meow=100.0) if low else chirp_batch(B, T, seed),
                   sgps=SigmaPoints.gauss_hermite(4, 3), d=4)
     wl.update(drift=drift, disp=disp, disc=disc, m0=m0, P0=P0, H=H)
     return wl
@@ -223,7 +223,7 @@ N_SIMDS = 1024
 # op by op on the reference's formulas -- what a non-redundant evaluation has to do.  The executed-FLOP figure of the
 # valu_f64 roofline counts all 64 lanes of every instruction, i.e. also the work replicated across lanes / MFMA blocks.
 ALGORITHMIC_FLOP = {'kf': 1.2e3, 'ekf': 1.5e3, 'sgp': 25e3, 'cd_sgp': 110e3, 'harmonic': 25e3}
-# C2_low_freq: C2 on records of 3 - 5 Hz (frequency state below 5 throughout): the headline kernel with every chunk in its common regime
+# C2_low_freq: C2 on records of 3.5 - 4.5 Hz (frequency state between 1.8 and 4.9 throughout): the headline kernel with every chunk in its common regime
 OTHER_CONFIGS = (('C1', 'kf'), ('C2_low_freq', 'ekf_low'), ('C3', 'sgp'), ('C4', 'cd_sgp'), ('C5', 'harmonic'))
 
 
@@ -571,7 +571,7 @@ def main():
                 tot = o['B_total'] * o['T']
                 per_pass = o['elapsed'] / o['steps']
                 if o['wl'].get('low'):
-                    lab += " -- record set of 3 - 5 Hz, initial frequency state 3 (all chunks in the common regime)"
+                    lab += " -- record set of 3.5 - 4.5 Hz, initial frequency state 3.5 (all chunks in the common regime)"
                 oc[tag] = {"workload": lab, "d": do, "T": o['T'], "batch_per_gpu": o['B'], "global_batch": o['B_total'], "scaling": mode_o,
                            "steps": o['steps'], "filter_ms": o['filt_ms_max'], "smoother_ms": o['smooth_ms_max'],
                            "ms_per_pass": per_pass * 1e3, "value": tot / per_pass, "unit": "trial-steps/s",

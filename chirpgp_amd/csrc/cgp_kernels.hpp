@@ -177,9 +177,16 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
     constexpr int D = Pred::D;
     constexpr bool WAVE = Pred::WAVE;
     constexpr bool TILED = !WAVE && D % 2 == 0;      // one lane per trial: rows go through an LDS transpose
+    // ... and, for d = 2 and 4, everything that is NOT a whole 128-byte line per trial and step is STAGED until it is one
+    // (round 4, below): measurements and cumulative NLL in groups of 16 steps, filtered means in groups of 16 / d steps
+    constexpr bool STAGED = TILED && (D == 2 || D == 4);
+    constexpr int kTileDoubles = !TILED ? 1 : (STAGED && RowTile<D * D>::DOUBLES < RowTile<16>::DOUBLES ? RowTile<16>::DOUBLES : RowTile<D * D>::DOUBLES);
     __shared__ double lds[Pred::USES_LDS ? kFanLdsDoubles : 1];
-    __shared__ double tile[TILED ? RowTile<D * D>::DOUBLES : 1];
+    __shared__ double tile[kTileDoubles];
     __shared__ __attribute__((aligned(16))) double rowpark[WAVE ? WaveRow<D>::DOUBLES : 1];
+    constexpr int kYPitch = 17;                      // 16 steps + 1: an odd pitch keeps the per-lane and the per-line accesses conflict-free
+    __shared__ double ytile[STAGED ? 64 * kYPitch : 1];
+    __shared__ const double* recs[STAGED ? 64 : 1];
     const int lane = threadIdx.x;
     int64_t trial = WAVE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 64 + lane;
     const int64_t block_first = (int64_t)blockIdx.x * 64;
@@ -245,6 +252,65 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
                 v = wave_inclusive_scan(v) + cum;
                 if (nll && lane < nsteps) nll[t0 + lane] = v;
                 cum = readlane_f64(v, nsteps - 1);
+            }
+        }
+    } else if constexpr (STAGED) {
+        // One lane per trial at d = 2 / 4, whole lines only.  Per trial and step the filter reads 8 bytes of measurement and
+        // writes 8 bytes of NLL and 8 d bytes of mean -- pieces of 128-byte lines that 64 lanes x several waves per SIMD keep
+        // half-filled in L2 for many steps: at 262 144 x 500 (the reference's CRLB job, tetralith/jobs/crlb_ekf.py:59-79) the
+        // counters showed 40.9 GB of HBM traffic for 23.1 GB of algorithmic bytes (the measurements fetched seven times over, the
+        // means and the NLL written in 32-byte pieces; profiles/r04_ekf_large_*).  So:
+        //   * measurements: 64 trials x 16 steps per cooperative load (every load instruction covers four whole lines), parked
+        //     in LDS, one ds_read per lane and step; the step's cumulative NLL takes the consumed measurement's slot, and the
+        //     tile leaves as whole lines after the 16 steps;
+        //   * filtered means: held for 16 / d steps in registers (a lane-uniform select per slot) and stored as ONE 128-byte
+        //     row per trial through the same LDS transpose as the covariance rows.
+        constexpr int MS = 16 / D;                                   // steps of means per 128-byte line
+        recs[lane] = io.record(block_first + (lane < nvalid ? lane : nvalid - 1));
+        const int64_t T_lines = T - T % MS;                          // steps whose means leave as whole lines; the rest row by row
+        double mh[16];
+        CGP_UNROLL for (int i = 0; i < 16; i++) mh[i] = 0.0;
+        for (int64_t t0 = 0; t0 < T; t0 += 16) {
+            wave_lds_fence();
+            CGP_UNROLL for (int k = 0; k < 16; k++) {
+                const int g = k * 64 + lane, tr = g >> 4, e = g & 15;
+                ytile[tr * kYPitch + e] = (t0 + e < T) ? recs[tr][t0 + e] : 0.0;
+            }
+            wave_lds_fence();
+            const int nst = (T - t0 < 16) ? (int)(T - t0) : 16;
+            for (int k = 0; k < nst; k++) {
+                const int64_t t = t0 + k;
+                const double y = ytile[lane * kYPitch + k];
+                Vec<D> mp; Sym<D> Pp;
+                double S, innov;
+                pred.predict(lane, lds, mf, Pf, mp, Pp);
+                Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+                if (want_nll) {
+                    cum += nll_increment(S, innov);
+                    ytile[lane * kYPitch + k] = cum;
+                }
+                if (io.mfs) {
+                    if (t < T_lines) {
+                        const int slot = (int)(t % MS);
+                        CGP_UNROLL for (int s = 0; s < MS; s++)
+                            CGP_UNROLL for (int i = 0; i < D; i++) mh[s * D + i] = (slot == s) ? mf.v[i] : mh[s * D + i];
+                        if (slot == MS - 1) block_store_rows<16>(tile, lane, mh, io.mfs + (block_first * T + (t - (MS - 1))) * D, T * D, nvalid);
+                    } else {
+                        block_store_rows<D>(tile, lane, mf.v, io.mfs + (block_first * T + t) * D, T * D, nvalid);
+                    }
+                }
+                if (io.Pfs) {
+                    double row[D * D];
+                    sym_to_row<D>(Pf, row);
+                    block_store_rows<D * D>(tile, lane, row, io.Pfs + (block_first * T + t) * D * D, T * D * D, nvalid);
+                }
+            }
+            if (nll) {
+                wave_lds_fence();
+                CGP_UNROLL for (int k = 0; k < 16; k++) {
+                    const int g = k * 64 + lane, tr = g >> 4, e = g & 15;
+                    if (tr < nvalid && t0 + e < T) io.nll[(block_first + tr) * T + t0 + e] = ytile[tr * kYPitch + e];
+                }
             }
         }
     } else {

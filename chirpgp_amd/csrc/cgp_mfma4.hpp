@@ -146,10 +146,10 @@ CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State&
 // cgp_fastmath.hpp (ang rides in q's coefficients), valid for u2 >= 1.5.  Rotation: (cos, sin)(theta) is advanced
 // INCREMENTALLY from the previous step's,
 //     (cos, sin)(theta) = rotation of (cos, sin)(theta_prev) by d = theta - theta_prev,
-// as three shears with tan(d / 2), sin d to d^3 (remainders < 7.6e-15 d while |d| <= 2^-8): 6 dependent operations instead of the 13 of a
+// as three shears with tan(d / 2), sin d to d^3 (remainders < 5.8e-14 d while |d| <= 1.5 x 2^-8): 6 dependent operations instead of the 13 of a
 // fresh sincos.  d is formed as ang q t + (ang u2 - theta_prev), whose second term does not wait for the polynomials; what
 // accumulates is one rounding per step in the rotation, and the pair is re-anchored with the full sincos at the start
-// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 2^-8 (or NaN) marks
+// of every 64-step chunk (relative error <= 64 x 2e-16).  A step with u2 outside [1.5, 700) or |d| >= 1.5 x 2^-8 (or NaN) marks
 // the chunk's verdict (Ekf4Verdict) and the whole chunk is repeated with the checked step.
 //
 // What is rotated is not (cos, sin) but this lane's entry of J0 itself and its quarter-turn partner,
@@ -187,14 +187,26 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 //   umax / umin   unsigned extremes of u2's high word: a negative, NaN or infinite u2 lands above 700's word
 //   d, di         unsigned and signed maximum of d's high word: the unsigned one is ruled by the negative increments (sign bit),
 //                 the signed one by the positive ones; masked with 0x7FFFFFFF each is the magnitude of the largest of its sign
-constexpr unsigned kIncrementBound = 0x3F700000u;      // high word of 2^-8
+// The increment bound: 1.5 x 2^-8 = 5.9e-3 (the high word resolves it).  The kernel's time is that of its SLOWEST wavefront, and a
+// chunk that fails a verdict is repeated with the checked step: with 2^-8 eleven of the bench's 1000 records (largest increment
+// 4.8e-3) repeated a chunk -- and, then still sticky, ran sixteen more on the checked step: 2.10 -> 2.33 ms for the whole launch.
+constexpr unsigned kIncrementBound = 0x3F780000u;
 struct Ekf4Verdict {
     unsigned u = 0u, umin = 0xFFFFFFFFu, d = 0u;
     int di = 0;
-    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {
+    template <bool HIGH = false> CGP_DEV bool state_in_regime() const {
         constexpr unsigned lo = HIGH ? 0x40140000u : 0x3FF80000u;
-        return __builtin_amdgcn_ballot_w64(u > 0x4085DFFFu || umin < lo) |                                                  // u2 outside [lo, 700)
-               __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound);   // |d| >= 2^-8
+        return u <= 0x4085DFFFu && umin >= lo;
+    }
+    // 1: the frequency state left the regime, 2: an increment beyond the bound (bits of a wave-uniform code; 0 = the chunk stands)
+    template <bool HIGH = false> CGP_DEV unsigned code() const {
+        const bool state = __builtin_amdgcn_ballot_w64(!state_in_regime<HIGH>()) != 0;
+        const bool jump = __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound) != 0;
+        return (state ? 1u : 0u) | (jump ? 2u : 0u);
+    }
+    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {
+        return __builtin_amdgcn_ballot_w64(!state_in_regime<HIGH>()) |                                                      // u2 outside [lo, 700)
+               __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound);   // |d| >= 1.5 2^-8
     }
 };
 template <int E1, bool HIGH = false>
@@ -210,8 +222,8 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     // The rotation by d as three shears (round 4) -- exact for tau = tan(d / 2), s = sin d, and of determinant 1 for ANY tau, s:
     //     A1 = A + tau B,   B' = B - s A1,   A' = A1 + tau B',        tau = d (1/2 + d^2 / 24),   s = d (1 - d^2 / 6)
     // eight operations where cos d, sin d and the four products of the plain rotation took ten (2.19 -> 2.15 ms).  Dropped terms:
-    // d^5 / 240 in tau, d^5 / 120 in s -- below 7.6e-15 relative while |d| <= 2^-8, the verdict's bound (2^-7 in round 3, where
-    // 64 steps at the bound could add up to 1.5e-11; the bench records' largest increment is 3.4e-3 = 2^-8.2).
+    // d^5 / 240 in tau, d^5 / 120 in s -- below 5.8e-14 relative while |d| <= 1.5 x 2^-8, the verdict's bound (2^-7 in round 3:
+    // 2.4e-13 a step; the bench records' largest increment is 4.8e-3, whose dropped terms are 2e-14).
     const double d2 = d * d;
     const double tau = d * fma(d2, R.c4, 0.5);
     const double sn = d * fma(d2, R.s3, 1.0);
@@ -316,7 +328,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         ynext = (t0 + 64 + lane < T) ? ys[t0 + 64 + lane] : 0.0;
         const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
         const Ekf4State x0 = x;
-        unsigned long long uncommon = 0;
+        unsigned uncommon = 0;                                              // Ekf4Verdict::code of the chunk's last speculative pass
         if (checked_left == 0) {
             Ekf4Anchor anchor0;
             ekf4_anchor(K, x.u2(), anchor0);
@@ -359,14 +371,15 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                     ya = na; yb = nb;
                 }
                 for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
-                return verdict.template uncommon<HIGH>();
+                return verdict.template code<HIGH>();
             };
-            // A chunk that starts at u2 >= 5.5 is tried in the HIGH regime first (the bench records: 79 % of the chunks, 2 % of
-            // them fall out of it); one that leaves it is repeated from its saved state in the common regime.
+            // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
+            // which falls out of it; with 5.5, round 3's threshold, 77 % and 1.7 % repeated: 1.4 % more time in all); one that
+            // leaves it is repeated from its saved state in the common regime.
             // (Not for an NLL-only launch: that is the objective of a maximum-likelihood fit, differentiated by finite differences --
             // a chunk that changes regime between two probes would put a 1e-13 step into it, and the optimiser's path with it.)
             bool high = false;
-            if constexpr (E1) high = !nll_final && (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x40160000u < 0x4085DFFFu - 0x40160000u;
+            if constexpr (E1) high = !nll_final && (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x401A0000u < 0x4085DFFFu - 0x401A0000u;
             uncommon = 1;
             if (high) {
                 uncommon = chunk(std::true_type{});
@@ -379,7 +392,9 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
-            if (redo) { x = x0; checked_left = kCheckedChunks; n_redo++; } else n_checked++;
+            // a record whose frequency state left the regime probably stays outside: the next chunks go straight to the checked
+            // step; a single jump of the angle (code 2 alone) says nothing about the next chunk
+            if (redo) { x = x0; checked_left = (uncommon & 1u) ? kCheckedChunks : 1; n_redo++; } else n_checked++;
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
                 ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
