@@ -942,7 +942,7 @@ def test_bat_call_parameters_track_the_sweep():
 
 
 def test_high_frequency_regime_of_the_matrix_core_ekf():
-    """Chunks that start with the frequency state at 5.5 or above run on the short polynomials of the regime u2 >= 5
+    """Chunks that start with the frequency state at 6.5 or above run on the short polynomials of the regime u2 >= 5
     (exp to degree 6, log1p(t) / t to degree 2, 1 / (1 + t) to degree 3 without a reciprocal: cgp_fastmath.hpp, SpecRegsHigh)
     and are repeated in the common regime when a step dips below 5.  Records that live inside that regime, one that hovers
     around its two thresholds, one that sweeps through it: within 1e-9 of the C port (the polynomials are good for 1e-13 rad
@@ -963,3 +963,36 @@ def test_high_frequency_regime_of_the_matrix_core_ekf():
     u2 = want['ekf'][0][:, :, 2]
     assert (u2[0, 300:] > 5.5).all() and (u2[1, 300:] > 20).all() and (u2[2] < 5.0).any() and (u2[2] > 5.5).any() and (u2[3] < 4.0).any()
     bk.compare(got, want, 1e-9, 'high-frequency regime')
+
+
+def test_rotation_increments_at_the_admitted_bound():
+    """The speculative step advances the Jacobian's rotation entries by the angle increment d with tan(d / 2), sin d to d^3, which it
+    admits up to |d| < 1.5 x 2^-8 (cgp_mfma4.hpp: kIncrementBound); a chunk with a larger one is repeated with the checked step
+    (full sincos) -- that chunk alone.  Records whose largest increments sit just below and just above the bound (a wide
+    frequency prior, sigma = 2.5 and 3: the gain moves the frequency state by up to 1 Hz a step): both sides of the bound within
+    1e-9 of the C port, the kernel's own counters showing that chunks below it were kept and chunks above it repeated."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm, _engine
+    from oracle import port
+    bound = 1.5 * 2.0 ** -8
+    c = cs.chirp_case(T=2000, seed=77)
+    ys = c.ys[None, :] + 0.05 * np.random.default_rng(5).standard_normal((8, c.ys.size))
+    seen = {}
+    for sigma in (2.5, 3.0):
+        _, _, disc, m0, P0, H = pm.build_chirp_model(np.array([0.1, 0.1, 0.1, 1., sigma, 7.]))
+        want = port.filter(port.F_EKF, disc, None, H, c.Xi, m0, P0, c.dt, ys)
+        u2 = np.concatenate([np.full((8, 1), m0[2]), want[0][:, :-1, 2]], axis=1)
+        d = np.abs(np.diff(c.dt * 2 * np.pi * np.log1p(np.exp(u2)), axis=1)) / bound          # increment of step k + 1, in units of the bound
+        _engine.debug_set(_engine.DBG_COUNT_REGIMES, 1)
+        _engine.debug_counters(reset=True)
+        got = fs.ekf(disc, H, c.Xi, m0, P0, c.dt, ys, **WAVE)
+        counters = _engine.debug_counters(reset=True)
+        _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
+        for g_, w_, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+            err = cs.max_rel_err(g_, w_)
+            assert err <= 1e-9, (sigma, n, err)
+        seen[sigma] = (d.max(axis=1), counters)
+        print(sigma, np.round(d.max(axis=1), 3), counters)
+    near, c25 = seen[2.5]
+    over, c30 = seen[3.0]
+    assert (near > 0.85).sum() >= 4 and (near > 1.0).sum() <= 2 and c25['redone'] <= 3       # increments at 0.85 .. 1 of the bound: kept
+    assert (over > 1.0).sum() >= 5 and 3 <= c30['redone'] <= 16 and c30['checked'] == 0      # beyond it: that chunk repeated, nothing sticky
