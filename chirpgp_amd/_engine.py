@@ -20,6 +20,7 @@ NLL_FINAL_ONLY, WAVE_PER_TRIAL, THREAD_PER_TRIAL, SEQUENTIAL_SCAN, GENERIC_KERNE
 LITERAL_SIGMA_SUM, DPP_KERNEL, FOUR_TRIALS_PER_WAVE, ONE_TRIAL_PER_WAVE = 0x40, 0x80, 0x200, 0x400
 TIME_SPLIT, NO_TIME_SPLIT = 0x800, 0x1000
 SIGMA_STANDARD = 0x1
+SIGMA_AXIAL = 0x2
 MAX_D = 12            # include/chirpgp_hip.h: CGP_MAX_D (9 .. 12: the harmonic LCD model with 4 or 5 harmonics)
 
 
@@ -270,6 +271,8 @@ def _sigma_struct(sgps, d, keep, nonlinear_coord=None):
             starts = np.flatnonzero(np.r_[True, inv[1:] != inv[:-1], True]).astype(np.int32)
             gs = torch.from_numpy(starts).cuda()
             sflags = SIGMA_STANDARD if _is_standard(xi_h, w_h, starts, v) else 0
+            if sflags and (np.count_nonzero(xi_h[:, :d - 1], axis=1) <= 1).all():
+                sflags |= SIGMA_AXIAL            # cubature: every point on one axis (include/chirpgp_hip.h)
         if len(_sigma_cache) >= 64:
             _sigma_cache.clear()
         hit = _sigma_cache[key] = (dev(xi_h), dev(w_h), gs, sflags)

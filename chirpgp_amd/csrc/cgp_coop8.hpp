@@ -113,7 +113,12 @@ CGP_DEV void coop8_update(double Pp, double mp, double HR, double HC, double XiC
     innov_out = innov;
 }
 
-template <int NH>
+// AXIAL (round 4): the caller asserts CGP_SIGMA_AXIAL -- every point has at most ONE non-zero coordinate among xi_0..d-2, true of
+// every cubature rule (xi = +- sqrt(d) e_k, quadratures.py:138-150).  Then xs = xi . sqrt(diag D') needs one square root per lane,
+//     xs_c = sgn(xi_c) sqrt(sum_c xi_c^2 dv_c),
+// instead of one per pivot: 20 instead of 49 operations (and one v_rsq_f64 instead of seven) of a step that is bound by
+// instruction issue.
+template <int NH, bool AXIAL>
 __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma) {
     constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
     static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
@@ -145,6 +150,12 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
         }
     }
 
+    double xi2[D - 1], xsg[D - 1], xz = 1.0;                             // AXIAL: xi_c^2, sgn(xi_c), 1 where the lane's point sits on the mean
+    CGP_UNROLL for (int c = 0; c < D - 1; c++) {
+        xi2[c] = xi[c] * xi[c];
+        xsg[c] = (xi[c] > 0.0) ? 1.0 : (xi[c] < 0.0 ? -1.0 : 0.0);
+        if (xi[c] != 0.0) xz = 0.0;
+    }
     // ---- per-lane constants
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
     const double HR = (i < D) ? Hp[i] : 0.0;                             // H[4 I + r]
@@ -220,7 +231,14 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             const double poison = bad ? __builtin_nan("") : 0.0;
             // ---- this lane's point: displacement d = L xi (xi_0..D-2), rotating pairs, propagated linear pair
             double xs[D - 1];
-            CGP_UNROLL for (int c = 0; c < D - 1; c++) xs[c] = fma(xi[c], sqrt_fast(dv[c]), poison);
+            if constexpr (AXIAL) {
+                double dvx = fma(xi2[0], dv[0], xz);                     // xi_c^2 dv_c of the lane's axis c (1 for the point on the mean)
+                CGP_UNROLL for (int c = 1; c < D - 1; c++) dvx = fma(xi2[c], dv[c], dvx);
+                const double rt = sqrt_fast(dvx);
+                CGP_UNROLL for (int c = 0; c < D - 1; c++) xs[c] = fma(xsg[c], rt, poison);
+            } else {
+                CGP_UNROLL for (int c = 0; c < D - 1; c++) xs[c] = fma(xi[c], sqrt_fast(dv[c]), poison);
+            }
             double dd[D];
             CGP_UNROLL for (int a = 0; a < D; a++) {
                 double s = (a <= D - 2) ? xs[a] : 0.0;                   // unit diagonal; xi_{D-1} does not take part
@@ -416,7 +434,8 @@ template <int NH>
 inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (io.T * ((2 * NH + 2) * (2 * NH + 2) * 8) > kOobMaxBytes) return CGP_E_UNSUPPORTED;        // output windows (OobWindow)
-    hipLaunchKernelGGL((sgp8_coop_kernel<NH>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    if (ma.sg.flags & CGP_SIGMA_AXIAL) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

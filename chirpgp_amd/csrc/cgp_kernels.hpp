@@ -172,8 +172,13 @@ CGP_DEV void wave_store_step(double* park, int lane, const Vec<D>& m, const Sym<
     wave_lds_fence();
 }
 
+// (one lane per trial, EKF at d <= 4: at least two wavefronts per SIMD -- 256 registers; left alone the staged form below takes 371
+// and runs one wavefront per SIMD, which leaves its LDS round trips and memory latencies uncovered: 262 144 x 500, full outputs,
+// 5.81 -> 5.58 ms, means only 3.15 -> 2.25 ms.  The sigma-point predictions spill under that cap -- 8.6 -> 13.3 ms -- and keep all
+// registers: Pred::LANE_TWO_WAVES)
 template <class Pred, class Meas>
-__global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!Pred::WAVE && Pred::D <= 4 && Pred::D % 2 == 0 && Pred::LANE_TWO_WAVES) ? 2 : 1)))
+filter_kernel(FilterIO io, ModelArgs ma) {
     constexpr int D = Pred::D;
     constexpr bool WAVE = Pred::WAVE;
     constexpr bool TILED = !WAVE && D % 2 == 0;      // one lane per trial: rows go through an LDS transpose
@@ -272,7 +277,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
         CGP_UNROLL for (int i = 0; i < 16; i++) mh[i] = 0.0;
         for (int64_t t0 = 0; t0 < T; t0 += 16) {
             wave_lds_fence();
-            CGP_UNROLL for (int k = 0; k < 16; k++) {
+            _Pragma("unroll 4") for (int k = 0; k < 16; k++) {           // (four loads in flight: more only costs registers)
                 const int g = k * 64 + lane, tr = g >> 4, e = g & 15;
                 ytile[tr * kYPitch + e] = (t0 + e < T) ? recs[tr][t0 + e] : 0.0;
             }
@@ -307,7 +312,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterIO io, ModelArgs ma) {
             }
             if (nll) {
                 wave_lds_fence();
-                CGP_UNROLL for (int k = 0; k < 16; k++) {
+                _Pragma("unroll 4") for (int k = 0; k < 16; k++) {
                     const int g = k * 64 + lane, tr = g >> 4, e = g & 15;
                     if (tr < nvalid && t0 + e < T) io.nll[(block_first + tr) * T + t0 + e] = ytile[tr * kYPitch + e];
                 }

@@ -96,15 +96,17 @@ CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef
     }
 }
 
-template <class DM, bool TWO>
-__global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
+// E1 (round 4): the measurement vector is e_1, as in every chirp / La Scala builder of the reference (models.py:118) -- H then PICKS
+// entries of Pp (cgp_mfma4.hpp: ekf4_mfma_finish_j): Pp H by row is a row broadcast of Pp, S = Pp_11 + Xi a row broadcast of
+// (H Pp) by column, H . mp = mp_1 -- one matrix instruction where the general update has three, and no dot product.
+template <class DM, bool TWO, bool E1>
+CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     static_assert(DM::D == 4, "d = 4 kernel");
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
     __shared__ double ybuf[64 + 2];                                      // the chunk's measurements (+ the read-ahead past the last)
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int64_t trial = blockIdx.x;
-    if (trial >= io.B) return;
 
     DM model;
     model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
@@ -196,9 +198,16 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
             const double Pp = fma(-Fr, mq * F, Y) + fma(l33sq, K1, Sig);
             // ---- update (filters_smoothers.py:55-68)
             const double PHc = mfma4x4(Hk, Pp, 0.0);                     // sum_k H[k] Pp[k][q]: (Pp H^T)[q] in every row
-            const double PHr = mfma4x4(Pp, Hk, 0.0);                     // sum_k Pp[k][r] H[k]: (Pp H^T)[r] in every column
-            const double S = mfma4x4(Hk, PHr, Xi);                       // H Pp H^T + Xi
-            const double pred = fma(H3, f3, fma(H2, f2, fma(H1, f1, H0 * f0)));
+            double PHr, S, pred;
+            if constexpr (E1) {
+                PHr = row_bcast_f64<1>(Pp);                              // Pp[r][1]
+                S = row_bcast_f64<1>(PHc) + Xi;                          // Pp[1][1] + Xi
+                pred = f1;
+            } else {
+                PHr = mfma4x4(Pp, Hk, 0.0);                              // sum_k Pp[k][r] H[k]: (Pp H^T)[r] in every column
+                S = mfma4x4(Hk, PHr, Xi);                                // H Pp H^T + Xi
+                pred = fma(H3, f3, fma(H2, f2, fma(H1, f1, H0 * f0)));
+            }
             const double innov = y - pred;
             const double rS = rcp_nr1(S);
             P = fma(-(PHr * rS), PHc, Pp);                               // Pf = Pp - K (Pp H)^T
@@ -220,6 +229,15 @@ __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma
         }
     }
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+}
+template <class DM, bool TWO>
+__global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
+    const int64_t trial = blockIdx.x;
+    if (trial >= io.B) return;
+    const double* __restrict__ Hp = io.H + trial * io.H_stride;
+    const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;      // a wave-uniform choice
+    if (e1) sgp4_mfma_trial<DM, TWO, true>(io, ma);
+    else sgp4_mfma_trial<DM, TWO, false>(io, ma);
 }
 
 // The matrix-core kernel takes collapsible sets of at most 32 groups whose output windows fit a raw buffer.

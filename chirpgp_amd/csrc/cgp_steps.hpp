@@ -502,6 +502,7 @@ struct ModelArgs {
 // ekf (filters_smoothers.py:251-261) and, with a linear model, kf (:174-181)
 template <class DM, bool WAVE_> struct EkfPredict {
     static constexpr bool USES_SIGMA = false;
+    static constexpr bool LANE_TWO_WAVES = true;      // one lane per trial: fits 256 registers (cgp_kernels.hpp: filter_kernel)
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
@@ -514,6 +515,7 @@ template <class DM, bool WAVE_> struct EkfPredict {
 // sgp_filter (filters_smoothers.py:480-487)
 template <class DM, bool WAVE_, bool COLL = false> struct SgpPredict {
     static constexpr bool USES_SIGMA = true;
+    static constexpr bool LANE_TWO_WAVES = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = WAVE; }
@@ -526,6 +528,7 @@ template <class DM, bool WAVE_, bool COLL = false> struct SgpPredict {
 // cd_ekf (filters_smoothers.py:384-394): dm = a(m), dP = P J^T + J P + gamma
 template <class SM, bool WAVE_> struct CdEkfPredict {
     static constexpr bool USES_SIGMA = false;
+    static constexpr bool LANE_TWO_WAVES = false;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     SM model; Sym<D> gamma; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {
@@ -548,6 +551,7 @@ template <class SM, bool WAVE_> struct CdEkfPredict {
 // cd_sgp_filter (filters_smoothers.py:569-579)
 template <class SM, bool WAVE_> struct CdSgpPredict {
     static constexpr bool USES_SIGMA = true;
+    static constexpr bool LANE_TWO_WAVES = false;
     static constexpr int D = SM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = WAVE_;
     SM model; Sym<D> gamma; SigmaSet sg; double dt;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) {

@@ -124,6 +124,10 @@ typedef struct cgp_sigma {
  * most 16 groups (every cubature rule), the d = 6 / 8 tile-layout kernels take this form; CGP_LITERAL_SIGMA_SUM forces
  * the literal sums. */
 #define CGP_SIGMA_STANDARD    0x1u
+/* cgp_sigma.flags bit: additionally, every point has at most ONE non-zero coordinate among xi_0 .. xi_{d-2} (every cubature rule:
+ * xi = +- sqrt(d) e_k, quadratures.py:138-150).  The d = 6 / 8 tile-layout filter then takes one square root per lane and step
+ * instead of one per pivot of chol(Pf).  Only read together with CGP_SIGMA_STANDARD. */
+#define CGP_SIGMA_AXIAL       0x2u
 
 /* Measurement model and initial condition of a filter. */
 typedef struct cgp_init {

@@ -996,3 +996,31 @@ def test_rotation_increments_at_the_admitted_bound():
     over, c30 = seen[3.0]
     assert (near > 0.85).sum() >= 4 and (near > 1.0).sum() <= 2 and c25['redone'] <= 3       # increments at 0.85 .. 1 of the bound: kept
     assert (over > 1.0).sum() >= 5 and 3 <= c30['redone'] <= 16 and c30['checked'] == 0      # beyond it: that chunk repeated, nothing sticky
+
+
+@pytest.mark.parametrize('nh', [2, 3])
+def test_tile_layout_sigma_filter_axial_and_rotated_cubature(nh):
+    """The d = 6 / 8 tile-layout sigma-point filter takes ONE square root per lane and step when every sigma point sits on one axis
+    (CGP_SIGMA_AXIAL, asserted by the host for cubature rules) and one per pivot otherwise.  Both paths against the C port: the
+    cubature rule as is, and the same rule rotated by 30 degrees in the plane of the first two coordinates -- still unit weight,
+    zero mean, identity second moment, groups differing in the last coordinate only (CGP_SIGMA_STANDARD), but no longer axial."""
+    from chirpgp_amd import _engine
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    c = cs.harmonic_case(T=400, seed=61, nh=nh)
+    d = 2 * nh + 2
+    sg = SigmaPoints.cubature(d)
+    rot = np.eye(d)
+    a = np.pi / 6
+    rot[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    sg_rot = SigmaPoints(d, sg.n_points, sg.w, None, sg.xi @ rot.T)
+    keep = []
+    assert _engine._sigma_struct(sg, d, keep, d - 2).flags == (_engine.SIGMA_STANDARD | _engine.SIGMA_AXIAL)
+    assert _engine._sigma_struct(sg_rot, d, keep, d - 2).flags == _engine.SIGMA_STANDARD
+    ys = c.ys[None, :] + 0.05 * np.random.default_rng(3).standard_normal((4, c.ys.size))
+    for s_ in (sg, sg_rot):
+        want = port.filter(port.F_SGP, c.disc, s_, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        got = fs.sgp_filter(c.disc, s_, c.H, c.Xi, c.m0, c.P0, c.dt, ys, **WAVE)
+        for g_, w_, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+            cs.assert_close(g_, w_, 1e-9, f'nh={nh} axial={s_ is sg}: {n}')
