@@ -549,9 +549,14 @@ CGP_DEV void fast_sincos_uniform(const FastMathRegs& R, double x, double& sn, do
 
 // Negative log-likelihood increment of a scalar Gaussian measurement, in the arithmetic of
 // jax.scipy.stats.norm.logpdf(y, pred, sqrt(S)) (filters_smoothers.py:44-45, 68).
+// Round 4: with the engine's own square root, logarithm and reciprocal root (5e-15, 1 ulp) instead of the library's sqrt, log and
+// divide -- 593 cycles of dependent latency and ~ 100 instructions per call (tools/ubench/f64_issue.hip), paid once per trial-step
+// by the lane-per-trial kernels and once per 64-step chunk, on the critical path, by the wave-per-trial ones.  S <= 0 or NaN -> NaN.
 CGP_DEV double nll_increment(double S, double innov) {
-    const double sc = sqrt(S), s2 = sc * sc;
-    return 0.5 * (log(kTwoPi * s2) + innov * innov / s2);
+    double sc, isc;
+    sqrt_rsqrt(S, sc, isc);                            // scale = sqrt(S), as the reference passes it to logpdf
+    const double z = innov * isc;
+    return 0.5 * (fast_log_ge1(kTwoPi * (sc * sc)) + z * z);
 }
 
 }  // namespace cgp

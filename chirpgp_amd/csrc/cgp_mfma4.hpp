@@ -315,6 +315,11 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     double cum = 0.0;
     int checked_left = 0;
     unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0;      // chunks by regime (scalars; cgp_debug_counters)
+    // The rotation pair is re-anchored with the full softplus and sincos (a dependent chain of ~ 70 operations) every FOURTH
+    // accepted chunk only (round 4): an accepted chunk hands its last (theta, A, B) to the next one -- one rounding per step in the
+    // rotation, 256 steps at most: 3e-14.
+    Ekf4Anchor anchor_live;
+    int anchor_age = -1;                                                    // < 0: no anchor carried over
     // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
     // start exposes the whole memory latency (and, vmcnt counting in order, the drain of every store still in flight) once per
     // 64 steps -- 2.7 us of a 16 us chunk
@@ -330,8 +335,9 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         const Ekf4State x0 = x;
         unsigned uncommon = 0;                                              // Ekf4Verdict::code of the chunk's last speculative pass
         if (checked_left == 0) {
-            Ekf4Anchor anchor0;
-            ekf4_anchor(K, x.u2(), anchor0);
+            Ekf4Anchor anchor0, anchor_end;
+            if (anchor_age < 0 || anchor_age >= 4) { ekf4_anchor(K, x.u2(), anchor0); anchor_age = 0; }
+            else anchor0 = anchor_live;
             // The step's measurement: the chunk's 64 values go to LDS once, and every group of steps reads its own with
             // broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
             // (tools/ubench/issue_costs.hip)
@@ -371,6 +377,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                     ya = na; yb = nb;
                 }
                 for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
+                anchor_end = anchor;
                 return verdict.template code<HIGH>();
             };
             // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
@@ -389,6 +396,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 uncommon = chunk(std::false_type{});
                 if (uncommon == 0) n_common++;
             }
+            if (uncommon == 0) { anchor_live = anchor_end; anchor_age++; } else anchor_age = -1;
         }
         const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
         if (checked_left > 0 || redo) {
