@@ -45,13 +45,24 @@ struct Fan4Groups {
 };
 
 // chol(P) = l sqrt(diag(dv)) for a covariance held in the matrix-core layout (lane (r, b, q): P[r][q]): 10 entries
-// gathered with v_readlane, the factorisation replicated in every lane as L D L^T -- the square roots sd = sqrt(dv_0..2)
+// gathered through LDS, the factorisation replicated in every lane as L D L^T -- the square roots sd = sqrt(dv_0..2)
 // stay off the pivot-to-pivot chain (cgp_coop8.hpp); dv[3] is returned as is (the collapsed quadratures use L_33 squared
 // or not at all).
 CGP_DEV void mfma4_factor(double P, Sym<4>& l, double (&sd)[3], double (&dv)[4]) {
     Sym<4> Pr; bool bad;
-    CGP_UNROLL for (int i = 0; i < 4; i++)
-        CGP_UNROLL for (int j = 0; j <= i; j++) Pr(i, j) = readlane_f64(P, 16 * i + j);
+    // The gather through LDS (round 4; twenty v_readlane before: C3 filter 6.15 -> 6.03 ms, C4 smoother 97.5 -> 94.5 ms): every lane
+    // parks its entry (the four blocks are replicas: same slot, same value), the lower triangle comes back as six broadcast reads --
+    // the LDS operations of one wavefront execute in order, so nothing waits between them
+    __shared__ __attribute__((aligned(16))) double fbuf[16];
+    const int lane = threadIdx.x;
+    fbuf[4 * (lane >> 4) + (lane & 3)] = P;
+    wave_lds_fence();
+    const double2 r0 = *reinterpret_cast<const double2*>(fbuf), r1 = *reinterpret_cast<const double2*>(fbuf + 4);
+    const double2 r2a = *reinterpret_cast<const double2*>(fbuf + 8), r2b = *reinterpret_cast<const double2*>(fbuf + 10);
+    const double2 r3a = *reinterpret_cast<const double2*>(fbuf + 12), r3b = *reinterpret_cast<const double2*>(fbuf + 14);
+    wave_lds_fence();
+    Pr(0, 0) = r0.x; Pr(1, 0) = r1.x; Pr(1, 1) = r1.y; Pr(2, 0) = r2a.x; Pr(2, 1) = r2a.y; Pr(2, 2) = r2b.x;
+    Pr(3, 0) = r3a.x; Pr(3, 1) = r3a.y; Pr(3, 2) = r3b.x; Pr(3, 3) = r3b.y;
     ldl_lower<4>(Pr, l, dv, bad);
     CGP_UNROLL for (int c = 0; c < 3; c++) sd[c] = sqrt_fast(dv[c]);
 }
