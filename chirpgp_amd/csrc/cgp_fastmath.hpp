@@ -23,13 +23,18 @@ constexpr double kPio2_2 = 6.077100506303966e-11;    // 33 bits
 constexpr double kPio2_3 = 2.0222662487959506e-21;
 constexpr double kSqrtHalf = 0.70710678118654752440;
 
-// p * x + c as a three-address v_fma_f64.  hipcc selects the two-address v_fmac_f64 for fma(p, x, CONSTANT) and then has to
+// p * x + c as a three-address v_fma_f64 (a translation unit whose coefficients are all pinned in registers may define
+// CGP_HORNER_PLAIN and take the compiler's own fma: cgp_inst_ekf4.hip).  hipcc selects the two-address v_fmac_f64 for fma(p, x, CONSTANT) and then has to
 // copy the loop-invariant constant into the destination first (v_mov_b64 + v_fmac_f64 per Horner step, seen in the
 // ISA of the v2 kernels); the explicit form keeps every coefficient in its own VGPR pair and issues one instruction.
 CGP_DEV double horner(double p, double x, double c) {
+#ifdef CGP_HORNER_PLAIN
+    return fma(p, x, c);
+#else
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "v"(c));
     return d;
+#endif
 }
 
 // 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
