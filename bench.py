@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
-PMC_PROFILE = 'profiles/r03_ekf_pmc.json'
-ISSUE_TABLE = 'profiles/r03_issue_table.json'
+PMC_PROFILE = 'profiles/r04_ekf_pmc.json'
+ISSUE_TABLE = 'profiles/r04_issue_table.json'
 
 
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0, offset=8.0, meow=500.0):
