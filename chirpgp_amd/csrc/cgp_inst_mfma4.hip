@@ -6,8 +6,7 @@
 #include "cgp_mfma4_sigma.hpp"
 #include "cgp_mfma4_cd.hpp"
 namespace cgp {
-int dispatch_filter_mfma4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_sgp4_mfma<HarmonicLCD<1>>(io, ma, st); }
-int dispatch_filter_mfma4_cdsgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgp4_mfma<HarmonicSDE<1>>(io, ma, st); }
+// (the two sigma-point FILTERS are instantiated in cgp_inst_mfma4_sgpf.hip)
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgps4_mfma<HarmonicSDE<1>>(io, ma, st); }
 int dispatch_filter_mfma4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdekf4_mfma(io, ma, st); }
 int dispatch_smoother_mfma4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdeks4_mfma(io, ma, st); }

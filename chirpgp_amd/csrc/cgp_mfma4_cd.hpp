@@ -297,6 +297,7 @@ CGP_DEV void cd4_ekf_eval(const SoftplusRegs& R, const Cd4LaneCoef& K, const Cd4
     JT = fma(Jc.cb, w, fma(Jc.cg0, jv0, fma(Jc.cg1, jv1, Jc.ck)));
 }
 
+#ifndef CGP_NO_CD_EKF_KERNELS       // the two non-template kernels below live in ONE translation unit (cgp_inst_mfma4.hip)
 __global__ void __launch_bounds__(64) cdekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
     const int lane = threadIdx.x;
@@ -450,6 +451,7 @@ inline int launch_cdeks4_mfma(const SmootherIO& io, const ModelArgs& ma, hipStre
     hipLaunchKernelGGL(cdeks4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
+#endif  // CGP_NO_CD_EKF_KERNELS
 
 template <class SM>
 inline int launch_cdsgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
