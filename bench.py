@@ -192,6 +192,19 @@ def cpu_baseline(wl, target_seconds=10.0):
             n, steps = n0, max(64, int(budget / n0))
         once(n, steps)
         best = min(once(n, steps, reps) for _ in range(3))
+        # a calibration that caught the thread pool cold undersizes the sample (seen: 0.09 s for 128 cores -> 1.4e7 instead of 5e7):
+        # grow it until one repetition lasts a good fraction of the budget
+        for _ in range(4):
+            if best >= target_seconds / 12.0:
+                break
+            grow = int(min(8, max(2, (target_seconds / 6.0) / max(best, 1e-6))))
+            if steps == T and n < ys.shape[0]:
+                n2 = int(min(ys.shape[0], n * grow))
+                grow = max(1, grow // max(1, n2 // n))
+                n = n2
+                once(n, steps)
+            reps *= grow
+            best = min(once(n, steps, reps) for _ in range(3))
         return n * steps * reps / best, (f"{n} of {ys.shape[0]} trials x {steps} of T={T} steps" + (f" x {reps} passes" if reps > 1 else "")
                                           + f", best of 3 ({best:.2f} s)")
 

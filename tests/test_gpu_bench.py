@@ -81,8 +81,11 @@ def test_default_line_carries_the_other_baseline_configs():
         rf = oc[tag]['roofline']
         assert rf['bound'] == 'valu_f64' and 0 < rf['algorithmic_frac'] < 1 and oc[tag]['value'] > 0
         assert oc[tag]['filter_ms'] > 0 and oc[tag]['smoother_ms'] > 0
+        # (`frac` counts the executed f64 FMA / MUL / ADD / MFMA flop of the dominant kernel; `algorithmic_frac` prices SURVEY 8d's op
+        # count of filter + smoother, a transcendental at 30 flop-equivalents -- the engine's lean polynomials execute fewer, so since
+        # round 4 the algorithmic figure of C3 exceeds the executed one: the two are reported side by side, not ordered)
         if rf['frac'] is not None:
-            assert rf['algorithmic_frac'] <= rf['frac'] * 1.05       # useful work cannot exceed what was executed
+            assert 0 < rf['frac'] < 1
 
 
 def test_two_rank_rehearsal_of_the_default_line():
