@@ -1,12 +1,13 @@
 #!/bin/bash
-# tools/profile_crlb.sh <tag>: rocprofv3 evidence for the large-batch EKF (262 144 x 500, the CRLB job's shape) in both launch shapes:
+# tools/profile_crlb.sh <tag>: rocprofv3 evidence for the large-batch EKF (262 144 x 500, the CRLB job's shape) in the default launch shape
+# (one lane per trial at this size) and with four trials per wavefront forced (ekf4_mfma_x4_kernel<true>):
 # kernel-trace stats, then one --pmc pass per counter group (nothing else enabled) -> gpurun_out/crlb_<tag>/{shape}/pmc.json
 set -e
 TAG=${1:-run}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd "$ROOT"
-for SHAPE in "x4:0" "lane:4"; do
+for SHAPE in ${CRLB_SHAPES:-"default:0" "four_trials_per_wave:0x200"}; do
     NAME=${SHAPE%%:*}; FLAGS=${SHAPE##*:}
     for WANT in full means; do
         OUT=$ROOT/gpurun_out/crlb_$TAG/${NAME}_$WANT
