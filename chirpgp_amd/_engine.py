@@ -51,7 +51,7 @@ class CgpInit(C.Structure):
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
-           'cgp_debug_set', 'cgp_debug_counters')
+           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn')
 
 _lib = None
 _lock = threading.Lock()
@@ -85,6 +85,8 @@ def load_library():
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
+        lib.cgp_gaussian_expectation_fn.restype = C.c_int
+        lib.cgp_gaussian_expectation_fn.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_debug_math.restype = C.c_int
         lib.cgp_debug_math.argtypes = [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp]
         lib.cgp_simulate.restype = C.c_int
@@ -385,8 +387,11 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
         return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
 
 
-def gaussian_expectation(ms, chol_Ps, xi, w):
-    """E[softplus(V)] for scalar marginals on the device -> (n, 1) like the reference's force_shape=True call."""
+FN_SOFTPLUS, FN_EXP, FN_IDENTITY, FN_SQUARE = 0, 1, 2, 3
+
+
+def gaussian_expectation(ms, chol_Ps, xi, w, func=FN_SOFTPLUS):
+    """E[f(V)] for scalar marginals on the device (f enumerated: FN_*) -> (n, 1) like the reference's force_shape=True call."""
     torch = _torch()
     like_numpy = not _is_torch(ms)
     m, s = dev(ms).reshape(-1), dev(chol_Ps).reshape(-1)
@@ -396,9 +401,9 @@ def gaussian_expectation(ms, chol_Ps, xi, w):
         ctx = context(m.device.index)
         xi_d, w_d = dev(xi).reshape(-1), dev(w).reshape(-1)
         out = torch.empty_like(m)
-        rc = load_library().cgp_gaussian_expectation(ctx, _ptr(m), _ptr(s), m.numel(), 1, _ptr(xi_d), _ptr(w_d), xi_d.numel(),
-                                                     _ptr(out), _stream())
-        _check(ctx, rc, 'cgp_gaussian_expectation')
+        rc = load_library().cgp_gaussian_expectation_fn(ctx, int(func), _ptr(m), _ptr(s), m.numel(), 1, _ptr(xi_d), _ptr(w_d), xi_d.numel(),
+                                                        _ptr(out), _stream())
+        _check(ctx, rc, 'cgp_gaussian_expectation_fn')
         out = out.reshape(-1, 1)
         return out.cpu().numpy() if like_numpy else out
 

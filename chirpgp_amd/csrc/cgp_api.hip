@@ -75,13 +75,22 @@ static ModelArgs model_args(const cgp_model* m, const cgp_sigma* sg, double dt, 
     return a;
 }
 
+template <int FN>
 __global__ void __launch_bounds__(256) gaussian_expectation_kernel(const double* __restrict__ ms, const double* __restrict__ sd,
                                                                    int64_t n, int64_t stride, const double* __restrict__ xi,
                                                                    const double* __restrict__ w, int order, double* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double m = ms[i * stride], s = sd[i * stride];
         double acc = 0.0;
-        for (int p = 0; p < order; p++) acc = fma(w[p], log(exp(fma(s, xi[p], m)) + 1.0), acc);
+        for (int p = 0; p < order; p++) {
+            const double x = fma(s, xi[p], m);
+            double f;
+            if constexpr (FN == CGP_FN_SOFTPLUS) f = log(exp(x) + 1.0);        // models.py:50, the naive form as is
+            else if constexpr (FN == CGP_FN_EXP) f = exp(x);
+            else if constexpr (FN == CGP_FN_SQUARE) f = x * x;
+            else f = x;
+            acc = fma(w[p], f, acc);
+        }
         out[i] = acc;
     }
 }
@@ -345,7 +354,13 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
 
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
                              const double* xi, const double* w, int32_t order, double* out, void* stream) {
+    return cgp_gaussian_expectation_fn(ctx, CGP_FN_SOFTPLUS, ms, sd, n, in_stride, xi, w, order, out, stream);
+}
+
+int cgp_gaussian_expectation_fn(cgp_ctx* ctx, int func, const double* ms, const double* sd, int64_t n, int64_t in_stride,
+                                const double* xi, const double* w, int32_t order, double* out, void* stream) {
     if (!ctx) return CGP_E_ARG;
+    if (func < CGP_FN_SOFTPLUS || func > CGP_FN_SQUARE) return fail(ctx, CGP_E_ARG, "unknown integrand");
     if (n < 0 || order < 1) return fail(ctx, CGP_E_ARG, "bad n or order");
     if (n == 0) return CGP_OK;
     if (!ms || !sd || !xi || !w || !out) return fail(ctx, CGP_E_ARG, "NULL pointer");
@@ -353,7 +368,13 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     const int64_t blocks = (n + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
-    hipLaunchKernelGGL(gaussian_expectation_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ms, sd, n, in_stride, xi, w, order, out);
+    hipStream_t st = (hipStream_t)stream;
+    switch (func) {
+    case CGP_FN_EXP:      hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_EXP>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
+    case CGP_FN_IDENTITY: hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_IDENTITY>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
+    case CGP_FN_SQUARE:   hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_SQUARE>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
+    default:              hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_SOFTPLUS>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
+    }
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
 }
 

@@ -85,15 +85,30 @@ class SigmaPoints(NamedTuple):
         return np.tensordot(self.w, np.asarray(evals_of_integrand), axes=(0, 0))
 
 
-def gaussian_expectation(ms, chol_Ps, func=None, d: int = 1, order: int = 10, force_shape: bool = False):
-    """E[g(V_t)] for scalar Gaussian marginals by 1-D Gauss-Hermite, on the device (quadratures.py:234-274).
+def identity(x):
+    """The identity as an integrand of gaussian_expectation (a named function, so that the device path can recognise it)."""
+    return x
 
-    Only the reference's own use is supported: d = 1 and func = g (softplus), which is what every driver calls
-    (demos/ekfs_mle.py:73-75).  Returns an array of shape (T, 1) like the reference.
+
+def gaussian_expectation(ms, chol_Ps, func=None, d: int = 1, order: int = 10, force_shape: bool = False):
+    """E[func(V_t)] for scalar Gaussian marginals by 1-D Gauss-Hermite, on the device (quadratures.py:234-274).
+
+    d = 1 only (the reference's own use: "in this chirp application the dimension of V is 1", :257-259).  `func` is one of the
+    integrands the kernel knows: ``models.g`` (the softplus every driver passes, demos/ekfs_mle.py:73-75; also the default),
+    ``numpy.exp`` (the reference's test of this function, test/test_utils.py:84-95), ``numpy.square``, ``quadratures.identity`` --
+    or their names 'g', 'exp', 'square', 'identity'.  Any other callable raises: it cannot run inside a HIP kernel and there is
+    no CPU fallback.  Returns an array of shape (T, 1) like the reference.
     """
     from chirpgp_amd import models as _models
     from chirpgp_amd import _engine
-    if d != 1 or (func is not None and func is not _models.g):
-        raise NotImplementedError('the device kernel implements d = 1, func = g (the reference drivers\' only use)')
+    if d != 1:
+        raise NotImplementedError('the device kernel implements d = 1 (the reference drivers\' only use)')
+    known = {None: _engine.FN_SOFTPLUS, _models.g: _engine.FN_SOFTPLUS, 'g': _engine.FN_SOFTPLUS, np.exp: _engine.FN_EXP, 'exp': _engine.FN_EXP,
+             np.square: _engine.FN_SQUARE, 'square': _engine.FN_SQUARE, identity: _engine.FN_IDENTITY, 'identity': _engine.FN_IDENTITY}
+    try:
+        fn = known[func]
+    except (KeyError, TypeError):
+        raise NotImplementedError('func must be one of models.g, numpy.exp, numpy.square, quadratures.identity (or their names): an '
+                                  'arbitrary Python callable cannot run inside the HIP kernel') from None
     sg = SigmaPoints.gauss_hermite(1, order)
-    return _engine.gaussian_expectation(ms, chol_Ps, sg.xi[:, 0], sg.w)
+    return _engine.gaussian_expectation(ms, chol_Ps, sg.xi[:, 0], sg.w, fn)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters) */
+#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters), cgp_gaussian_expectation_fn */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -196,6 +196,15 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
  * (nodes xi[order], weights w[order] already in the reference's scaling): quadratures.py:234-274 with func = g. */
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,
                              const double* xi, const double* w, int32_t order, double* out, void* stream);
+/* The same for an enumerated integrand (the reference takes any callable, quadratures.py:234-274; a callable cannot cross this
+ * boundary): E[f(V)], f = softplus (= cgp_gaussian_expectation), exp (the reference's own test of this function,
+ * test/test_utils.py:84-95), the identity, the square. */
+#define CGP_FN_SOFTPLUS  0
+#define CGP_FN_EXP       1
+#define CGP_FN_IDENTITY  2
+#define CGP_FN_SQUARE    3
+int cgp_gaussian_expectation_fn(cgp_ctx* ctx, int func, const double* ms, const double* sd, int64_t n, int64_t in_stride,
+                                const double* xi, const double* w, int32_t order, double* out, void* stream);
 
 /* ---- input side: Monte-Carlo data generated in HBM ------------------------------------
  * Random numbers are counter-based (Philox4x32-10 keyed by `seed`, counter = (global trial number, index, stream),

@@ -1024,3 +1024,20 @@ def test_tile_layout_sigma_filter_axial_and_rotated_cubature(nh):
         got = fs.sgp_filter(c.disc, s_, c.H, c.Xi, c.m0, c.P0, c.dt, ys, **WAVE)
         for g_, w_, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
             cs.assert_close(g_, w_, 1e-9, f'nh={nh} axial={s_ is sg}: {n}')
+
+
+def test_gaussian_expectation_integrands():
+    """The reference's own test of gaussian_expectation (test/test_utils.py:84-95: E[exp(V)] = exp(m + P / 2), default tolerance)
+    on the device path, and the other enumerated integrands against their closed forms; an arbitrary callable is refused."""
+    from chirpgp_amd.quadratures import gaussian_expectation, identity
+    rng = np.random.default_rng(111)
+    ms = rng.standard_normal((100, 1))
+    Ps = rng.uniform(0.1, 1., size=(100, 1, 1))
+    npt.assert_allclose(gaussian_expectation(ms, np.sqrt(Ps), func=np.exp, d=1, order=10), np.exp(ms + Ps[:, 0] / 2))
+    npt.assert_allclose(gaussian_expectation(ms, np.sqrt(Ps), func='exp', force_shape=True), np.exp(ms + Ps[:, 0] / 2))
+    npt.assert_allclose(gaussian_expectation(ms, np.sqrt(Ps), func=identity), ms, rtol=1e-13, atol=1e-15)
+    npt.assert_allclose(gaussian_expectation(ms, np.sqrt(Ps), func=np.square), ms ** 2 + Ps[:, 0], rtol=1e-13)
+    with pytest.raises(NotImplementedError):
+        gaussian_expectation(ms, np.sqrt(Ps), func=lambda x: np.sin(x))
+    with pytest.raises(NotImplementedError):
+        gaussian_expectation(np.zeros((4, 2)), np.zeros((4, 2, 2)), d=2)
