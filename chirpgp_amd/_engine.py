@@ -51,7 +51,7 @@ class CgpInit(C.Structure):
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
-           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn')
+           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split')
 
 _lib = None
 _lock = threading.Lock()
@@ -80,6 +80,10 @@ def load_library():
         lib.cgp_filter.restype = C.c_int
         lib.cgp_filter.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.POINTER(CgpInit), C.c_double,
                                    _vp, C.c_int64, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_filter_time_split.restype = C.c_int
+        lib.cgp_filter_time_split.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.POINTER(CgpInit), C.c_double,
+                                              _vp, C.c_int64, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32,
+                                              C.c_int64, C.c_int64, _vp, _vp]
         lib.cgp_smoother.restype = C.c_int
         lib.cgp_smoother.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
@@ -308,14 +312,23 @@ def _out(t, like_numpy, squeeze):
     return t.cpu().numpy() if like_numpy else t
 
 
+last_junction_error = None      # device tensor [B] of the most recent time-split filter call (cgp_filter_time_split)
+
+
 def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, flags=0, want=(True, True, True),
-               trials_per_record=None, record_index=None):
+               trials_per_record=None, record_index=None, time_split=None, split_tol=None):
     """cgp_filter with NumPy / torch marshalling.  ys (T,) or (B, T) -> (mfs, Pfs, nll) with matching leading axes.
 
     Shared records (include/chirpgp_hip.h, cgp_filter): with ``trials_per_record = k`` every record of ys -- (T,) or (R, T) --
     serves k consecutive trials (k parameter vectors of a sweep, the 2 P + 1 probes of a difference gradient), B = R k, and
     the results always carry the batch axis; ``record_index`` (n,) picks and orders the records first (B = n k).  The
-    record is read from ONE copy in HBM: nothing is replicated."""
+    record is read from ONE copy in HBM: nothing is replicated.
+
+    ``time_split = (segments, burn_in)``: the time-split filter with burn-in (include/chirpgp_hip.h, cgp_filter_time_split) -- several
+    wavefronts per trial for batches that leave most SIMDs idle; the per-trial junction mismatch is left in
+    ``_engine.last_junction_error`` (device tensor), and with ``split_tol`` the call checks it (one device synchronisation) and
+    falls back to the sequential filter if any junction is further off."""
+    global last_junction_error
     torch = _torch()
     like_numpy = not _is_torch(ys)
     ys_d = dev(ys)
@@ -353,10 +366,21 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
         fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
         lib, st = load_library(), _stream()
-        rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                                     C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
-                                                     _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
-        _check(ctx, rc, 'cgp_filter')
+        if time_split is not None:
+            segments, burn_in = (int(v) for v in time_split)
+            err = torch.empty((B,), **opts)
+            rc = _timed('filter', lambda: lib.cgp_filter_time_split(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                                    C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
+                                                                    _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, segments, burn_in, _ptr(err), st))
+            _check(ctx, rc, 'cgp_filter_time_split')
+            last_junction_error = err
+            if split_tol is not None and not bool((err <= float(split_tol)).all()):      # NaN / inf / too far: the sequential filter
+                time_split = None
+        if time_split is None:
+            rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
+                                                         C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
+                                                         _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
+            _check(ctx, rc, 'cgp_filter')
         return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
 
 

@@ -127,6 +127,52 @@ __global__ void __launch_bounds__(64) debug_math_uniform_kernel(int op, const do
     }
 }
 
+// Whether a d = 4 sigma-point launch takes the matrix-core kernel (cgp_inst_coop4.hip: sigma_mfma) -- the one that knows segments.
+static bool sigma_mfma_taken(uint32_t flags, int64_t T, const ModelArgs& ma) {
+    return !(flags & CGP_DPP_KERNEL) && (ma.sg.flags & CGP_SIGMA_STANDARD) && ma.sg.group_start && ma.sg.n_groups >= 1 && ma.sg.n_groups <= 32 && T * 128 <= 0x7FFFFF00LL;
+}
+
+// Fix-up pass of a time-split filter launch (one workgroup per trial):
+//   * junction_err[b] = the largest relative mismatch, over the junctions of trial b, between the state a segment's burn-in arrived
+//     at and the state the segment before it ended with (max |difference| / max |reference|, mean and covariance separately) --
+//     everything the segment wrote afterwards is at most this far from the sequential filter's rows (the filter forgets its
+//     initial condition; the caller decides what mismatch it accepts);
+//   * the cumulative NLL of segment s > 0 starts at 0: add the totals of the segments before it (or, NLL-final mode, sum the totals).
+__global__ void __launch_bounds__(64) filter_split_fixup_kernel(FilterIO io, int d, double* __restrict__ junction_err) {
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = d + d * d;
+    const double* __restrict__ rec = io.seg_state + b * io.segs * io.seg_stride;
+    double worst = 0.0;
+    for (int s = 1; s < io.segs; s++) {
+        const double* start = rec + s * io.seg_stride;                   // (m, P) after the burn-in of segment s
+        const double* end = rec + (s - 1) * io.seg_stride + n;           // (m, P) after the last step of segment s - 1
+        double dm = 0.0, rm = 0.0, dp = 0.0, rp = 0.0;
+        bool nan = false;
+        for (int i = 0; i < n; i++) {
+            const double a = start[i], r = end[i], e = fabs(a - r);
+            nan = nan || !(e == e);
+            if (i < d) { dm = fmax(dm, e); rm = fmax(rm, fabs(r)); } else { dp = fmax(dp, e); rp = fmax(rp, fabs(r)); }
+        }
+        double err = fmax(rm > 0.0 ? dm / rm : dm, rp > 0.0 ? dp / rp : dp);
+        if (nan) err = __builtin_inf();                                  // a NaN on either side of a junction: the split run is not the sequential one
+        worst = fmax(worst, err);
+    }
+    if (lane == 0) junction_err[b] = worst;
+    if (!io.nll) return;
+    const int tot = 2 * n;
+    if (io.flags & CGP_NLL_FINAL_ONLY) {
+        if (lane == 0) { double sum = 0.0; for (int s = 0; s < io.segs; s++) sum += rec[s * io.seg_stride + tot]; io.nll[b] = sum; }
+        return;
+    }
+    double offset = 0.0;
+    for (int s = 1; s < io.segs; s++) {
+        offset += rec[(s - 1) * io.seg_stride + tot];
+        const int64_t t0 = (int64_t)s * io.seg_len, t1 = (t0 + io.seg_len < io.T) ? t0 + io.seg_len : io.T;
+        for (int64_t t = t0 + lane; t < t1; t += 64) io.nll[b * io.T + t] += offset;
+    }
+}
+
 }  // namespace cgp
 
 using namespace cgp;
@@ -199,9 +245,10 @@ const char* cgp_last_error(const cgp_ctx* ctx) {
     return e.ctx == ctx ? e.msg.c_str() : "";
 }
 
-int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
-               double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
-               int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream) {
+static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+                       double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+                       int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream,
+                       int64_t segments, int64_t burn_in, double* junction_err) {
     if (!ctx) return CGP_E_ARG;
     if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
     if (B == 0 || T == 0) return CGP_OK;
@@ -226,6 +273,27 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     io.counters = ctx->counters;
+    // ---- time-split with burn-in (cgp_filter_time_split): segments of whole 64-step chunks, one wavefront each
+    const bool split = segments > 1;
+    double* seg_ws = nullptr;
+    if (split) {
+        if (burn_in < 0) return fail(ctx, CGP_E_ARG, "burn_in must be >= 0");
+        if (!junction_err) return fail(ctx, CGP_E_ARG, "junction_err must be set: a time-split filter is only as good as its junctions");
+        const bool chirp4_sgp = method == CGP_F_SGP && model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
+        if (!chirp4_sgp || (flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_THREAD_PER_TRIAL)))
+            return fail(ctx, CGP_E_UNSUPPORTED, "time-split filters are built for sgp_filter on the d = 4 chirp / La Scala models (matrix-core kernel) only");
+        int64_t seg_len = ((T + segments - 1) / segments + 63) / 64 * 64;
+        const int64_t segs = (T + seg_len - 1) / seg_len;                  // without the empty ones
+        io.segs = (int)segs; io.seg_len = seg_len; io.burn_in = (burn_in + 63) / 64 * 64;
+        io.seg_stride = 2 * (model->d + model->d * model->d) + 1;
+        if (segs > 1) {
+            if (hipMallocAsync((void**)&seg_ws, sizeof(double) * (size_t)io.seg_stride * (size_t)B * (size_t)segs, (hipStream_t)stream) != hipSuccess)
+                return fail(ctx, CGP_E_HIP, "hipMallocAsync of the segment records failed");
+            io.seg_state = seg_ws;
+            flags |= CGP_WAVE_PER_TRIAL;
+            io.flags = flags;
+        } else io.segs = 1;
+    }
     const ModelArgs ma = model_args(model, sigma, dt, flags);
     // which lane-cooperative kernel (if any) a wave-per-trial launch of this call would take decides the crossover
     const bool spec = !(flags & CGP_GENERIC_KERNEL);
@@ -269,9 +337,32 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
     case CGP_M_KPT:          rc = dispatch_filter_kpt(model->n_harm, wave, io, ma, st); break;
     default: rc = CGP_E_ARG;
     }
+    if (split) {
+        if (rc == CGP_OK) {
+            if (io.segs > 1) {
+                if (!sigma_mfma_taken(flags, T, ma)) rc = CGP_E_UNSUPPORTED;        // the launch fell back to a kernel that ignores the segments
+                else hipLaunchKernelGGL(filter_split_fixup_kernel, dim3((unsigned)B), dim3(64), 0, st, io, model->d, junction_err);
+            } else if (hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, st) != hipSuccess) rc = CGP_E_HIP;
+        }
+        if (seg_ws && hipFreeAsync(seg_ws, st) != hipSuccess && rc == CGP_OK) rc = CGP_E_HIP;
+    }
     if (rc == CGP_E_UNSUPPORTED) return fail(ctx, rc, "this (method, model, dimension) combination is not compiled in");
     if (rc == CGP_E_HIP) return fail(ctx, rc, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return rc;
+}
+
+int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+               double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+               int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream) {
+    return filter_impl(ctx, method, model, sigma, init, dt, ys, ys_stride, ys_repeat, ys_index, B, T, mfs, Pfs, nll, flags, stream, 1, 0, nullptr);
+}
+
+int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+                          double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+                          int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags,
+                          int64_t segments, int64_t burn_in, double* junction_err, void* stream) {
+    if (ctx && segments < 1) return fail(ctx, CGP_E_ARG, "segments must be >= 1");
+    return filter_impl(ctx, method, model, sigma, init, dt, ys, ys_stride, ys_repeat, ys_index, B, T, mfs, Pfs, nll, flags, stream, segments, burn_in, junction_err);
 }
 
 int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,

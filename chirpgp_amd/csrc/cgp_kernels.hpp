@@ -28,6 +28,14 @@ struct FilterIO {
     double* __restrict__ nll;
     uint32_t flags;
     unsigned long long* __restrict__ counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): regime counters of the context, or NULL
+    // Time-split filters with burn-in (cgp_filter_time_split; round 4): `segs` wavefronts per trial.  Wavefront (b, s) filters the
+    // steps [s seg_len - burn_in, (s + 1) seg_len) of trial b from (m0, P0), writes rows from s seg_len on, and leaves in
+    // seg_state[(b segs + s) seg_stride ..] its state at the junction (after its last burn-in step), its state after its last step
+    // and its NLL total: (m, P) | (m, P) | nll.  seg_len and burn_in are multiples of 64 (the kernels' chunk).  segs <= 1: off.
+    int segs = 1;
+    int64_t seg_len = 0, burn_in = 0;
+    double* __restrict__ seg_state = nullptr;
+    int seg_stride = 0;
     // The measurement record of a trial (include/chirpgp_hip.h, cgp_filter): trial b reads record ys_index[b / ys_repeat]
     // (b / ys_repeat without an index) -- a parameter sweep or the 2 P + 1 probes of a difference gradient read ONE copy.
     __device__ __forceinline__ const double* record(int64_t trial) const {
@@ -37,6 +45,24 @@ struct FilterIO {
         return ys + g * ys_stride;
     }
 };
+
+// The span of time steps of workgroup v of a (possibly time-split) filter launch.
+struct FilterSpan {
+    int64_t trial, t_begin, t_out, t_end;      // filters [t_begin, t_end), writes rows [t_out, t_end)
+    int seg;
+    double* state;                             // this segment's record in FilterIO::seg_state, or NULL
+};
+__device__ __forceinline__ FilterSpan filter_span(const FilterIO& io, int64_t v) {
+    if (io.segs <= 1) return {v, 0, 0, io.T, 0, nullptr};
+    const int64_t b = (int64_t)((uint64_t)v / (uint64_t)io.segs);
+    const int s = (int)(v - b * io.segs);
+    const int64_t t_out = (int64_t)s * io.seg_len;
+    int64_t t_begin = s > 0 ? t_out - io.burn_in : 0;
+    if (t_begin < 0) t_begin = 0;
+    int64_t t_end = t_out + io.seg_len;
+    if (t_end > io.T) t_end = io.T;
+    return {b, t_begin, t_out, t_end, s, io.seg_state ? io.seg_state + (b * io.segs + s) * io.seg_stride : nullptr};
+}
 
 struct SmootherIO {
     const double* __restrict__ mfs;

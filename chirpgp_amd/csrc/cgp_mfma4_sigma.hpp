@@ -117,7 +117,9 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double ybuf[64 + 2];                                      // the chunk's measurements (+ the read-ahead past the last)
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    // (time-split launches, cgp_filter_time_split: this wavefront is one SEGMENT of its trial's record -- cgp_kernels.hpp: FilterSpan)
+    const FilterSpan span = filter_span(io, blockIdx.x);
+    const int64_t trial = span.trial;
 
     DM model;
     model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
@@ -169,10 +171,17 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const bool want_nll = io.nll != nullptr;
 
     double cum = 0.0;
-    for (int64_t t0 = 0; t0 < T; t0 += 64) {
-        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+    for (int64_t t0 = span.t_begin; t0 < span.t_end; t0 += 64) {
+        double ychunk = (t0 + lane < span.t_end) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
-        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
+        // a segment's burn-in chunks (whole chunks: t_out is a multiple of 64) write nothing: their rows belong to the segment before
+        const bool burn = t0 < span.t_out;
+        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        if (span.state && span.seg > 0 && t0 == span.t_out) {          // the junction: the state the burn-in arrived at
+            if (lane == 0) { span.state[0] = u0; span.state[1] = u1; span.state[2] = u2; span.state[3] = u3; }
+            if (b == 0) span.state[4 + 4 * r + q] = P;
+        }
         // the chunk's measurements go through LDS: one broadcast ds_read_b64 per step, issued a step ahead, where a v_readlane
         // pair costs 24 issue cycles (tools/ubench/issue_costs.hip)
         ybuf[lane] = ychunk;
@@ -228,22 +237,25 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             u2 = fma(row_bcast_f64<2>(PHc), g, f2);
             u3 = fma(row_bcast_f64<3>(PHc), g, f3);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
-            wP.store(P, t * 128u + offP);
-            wm.store2(u0, u1, t * 32u + offm);
-            wm.store2(u2, u3, t * 32u + 16u + offm);
+            wP.store(P, t * 128u + offP_c);
+            wm.store2(u0, u1, t * 32u + offm_c);
+            wm.store2(u2, u3, t * 32u + 16u + offm_c);
         }
-        if (want_nll) {
+        if (want_nll && !burn) {
             wave_lds_fence();
             const double2 si = park[lane < nsteps ? lane : 0];
             cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
             wave_lds_fence();
         }
     }
-    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+    if (span.state) {                                                   // the segment's last state and its NLL total, for the fix-up pass
+        if (lane == 0) { span.state[20] = u0; span.state[21] = u1; span.state[22] = u2; span.state[23] = u3; span.state[40] = cum; }
+        if (b == 0) span.state[24 + 4 * r + q] = P;
+    } else if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 template <class DM, bool TWO>
 __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
-    const int64_t trial = blockIdx.x;
+    const int64_t trial = filter_span(io, blockIdx.x).trial;
     if (trial >= io.B) return;
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
     const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;      // a wave-uniform choice
@@ -259,8 +271,9 @@ template <class DM>
 inline int launch_sgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (!sgp4_mfma_fits(io, ma)) return CGP_E_UNSUPPORTED;
-    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((sgp4_mfma_kernel<DM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
-    else hipLaunchKernelGGL((sgp4_mfma_kernel<DM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
+    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((sgp4_mfma_kernel<DM, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((sgp4_mfma_kernel<DM, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

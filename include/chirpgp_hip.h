@@ -187,6 +187,22 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
                double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
                int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
 
+/* Time-split filter with burn-in (round 4) -- for batches that leave most SIMDs idle.  A filter cannot be cut in time exactly (step t
+ * linearises at the filtered mean of step t - 1), but it FORGETS its initial condition: the record is cut into `segments`
+ * pieces of whole 64-step chunks, and wavefront s > 0 starts `burn_in` steps BEFORE its piece from (m0, P0), writes nothing
+ * until its piece begins, and carries on like the sequential filter from there.  junction_err[b] (DEVICE array, [B], required)
+ * receives, per trial, the largest relative mismatch at a junction between the state a burn-in arrived at and the state the
+ * previous segment ended with: every row a segment wrote is at most about that far from the sequential filter's (inf if a NaN
+ * sits at a junction).  The caller picks burn_in for its model (the chirp models of the reference lose a decade per ~ 450 steps
+ * after the first ~ 1000: 3000 steps for 1e-7) and checks junction_err against its own tolerance -- cgp_filter remains the
+ * reference's sequential recursion.  Cumulative NLL rows are made continuous across segments by a fix-up pass.  Built for
+ * sgp_filter / cd_sgp_filter / ekf on the d = 4 chirp / La Scala models and sgp_filter at d = 6 / 8 (matrix-core / tile-layout
+ * kernels); CGP_E_UNSUPPORTED otherwise.  segments = 1: the same as cgp_filter (junction_err = 0). */
+int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, const cgp_init* init,
+                          double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
+                          int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags,
+                          int64_t segments, int64_t burn_in, double* junction_err, void* stream);
+
 /* Smoothers: reads mfs / Pfs, writes mss / Pss (row T-1 is the filtering row T-1). */
 int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
                  double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,

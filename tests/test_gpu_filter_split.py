@@ -1,0 +1,95 @@
+"""Time-split filters with burn-in (cgp_filter_time_split): several wavefronts per trial for batches that leave most SIMDs idle.
+Not the sequential recursion -- a filter cannot be cut in time exactly -- but as close to it as the reported junction mismatch says:
+checked here against the sequential launch of the same kernels, with the mismatch the launch itself reports as the yardstick."""
+import numpy as np
+import pytest
+
+from tests import cases as cs
+
+pytestmark = pytest.mark.gpu
+
+
+def _noisy(c, B, seed):
+    return c.ys[None, :] + 0.05 * np.random.default_rng(seed).standard_normal((B, c.ys.size))
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize('T,segments,burn_in', [(6000, 4, 3000), (5003, 3, 2500), (4100, 8, 4000)])
+def test_sgp_filter_time_split_is_as_close_as_its_junctions_say(T, segments, burn_in):
+    """Ragged T (the last segment shorter, T not a multiple of 64), a burn-in longer than a segment (clipped at the record's start):
+    every output within a small multiple of the reported junction mismatch of the sequential filter, cumulative NLL continuous."""
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    c = cs.chirp_case(T=3000, seed=81)
+    c.ys = np.tile(c.ys, 3)[:T] if T > 3000 else c.ys[:T]
+    ys = _noisy(c, 5, T)
+    seq = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    got = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(segments, burn_in))
+    err = float(_engine.last_junction_error.max())
+    print(T, segments, burn_in, 'junction mismatch', err, [f'{_rel(g, s):.1e}' for g, s in zip(got, seq)])
+    assert 0 < err < 1e-4
+    for g, s, n in zip(got, seq, ('mfs', 'Pfs', 'nll')):
+        assert np.isfinite(g).all()
+        assert _rel(g, s) <= 5 * err, (n, _rel(g, s), err)
+    seg_len = -(-(-(-T // segments)) // 64) * 64
+    assert np.array_equal(got[0][:, :seg_len], seq[0][:, :seg_len])               # the first segment IS the sequential filter
+    last = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(segments, burn_in), nll_final_only=True, want=(False, False, True))[2]
+    assert _rel(last, seq[2][:, -1]) <= 5 * err
+
+
+def test_one_segment_is_the_sequential_filter_and_unsupported_methods_say_so():
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    c = cs.chirp_case(T=700, seed=82)
+    ys = _noisy(c, 3, 1)
+    seq = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    one = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(1, 640))
+    assert all(np.array_equal(a, b) for a, b in zip(one, seq)) and float(_engine.last_junction_error.max()) == 0.0
+    short = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys[:, :50], time_split=(4, 640))      # one chunk: nothing to split
+    assert np.array_equal(short[0], seq[0][:, :50])
+    h = cs.harmonic_case(T=300, seed=83, nh=2)
+    with pytest.raises(RuntimeError, match='time-split'):
+        fs.cd_ekf(c.drift, c.disp, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(2, 128))
+    del h
+
+
+def test_a_nan_at_a_junction_is_reported_and_the_tolerance_falls_back():
+    """A NaN measurement in the first segment: the sequential filter is NaN from there on, a segment that starts afresh is not --
+    the junction says so (inf), and with split_tol the call returns the sequential result."""
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    c = cs.chirp_case(T=3000, seed=84)
+    ys = _noisy(c, 4, 2)
+    ys[2, 700] = np.nan
+    seq = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    got = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(3, 1000))
+    err = _engine.last_junction_error.cpu().numpy()
+    assert np.isinf(err[2]) and np.isfinite(err[[0, 1, 3]]).all()
+    assert np.isfinite(got[0][2, 1024:]).all() and np.isnan(seq[0][2, 700:]).all()          # which is why the junction matters
+    safe = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(3, 1000), split_tol=1e-3)
+    for a, b in zip(safe, seq):
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+def test_small_batch_time_split_is_faster():
+    """BASELINE C3's shard on one of 8 GPUs (125 x 10 000): eight segments with 3008 steps of burn-in against the sequential launch."""
+    import torch
+    import bench
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    wl = bench.make_workload(125, 10000, kind='sgp')
+    ys = torch.from_numpy(wl['ys']).cuda()
+    a = (wl['disc'], wl['sgps'], wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys)
+
+    def timed(**kw):
+        out = fs.sgp_filter(*a, **kw); torch.cuda.synchronize()
+        ev = _engine.kernel_events = []
+        for _ in range(3):
+            out = fs.sgp_filter(*a, **kw)
+        torch.cuda.synchronize(); _engine.kernel_events = None
+        return out, min(x.elapsed_time(y) for n, x, y in ev if n == 'filter')
+    seq, t_seq = timed()
+    got, t_split = timed(time_split=(8, 3008))
+    err = float(_engine.last_junction_error.max())
+    worst = max(float((g - s).abs().max() / s.abs().max()) for g, s in zip(got, seq))
+    print(f'sgp_filter 125 x 10000: sequential {t_seq:.3f} ms, 8 segments + 3008 burn-in {t_split:.3f} ms, junction mismatch {err:.1e}, worst output difference {worst:.1e}')
+    assert err < 1e-6 and worst <= 5 * err and t_split < 0.6 * t_seq
