@@ -29,7 +29,7 @@ def test_sgp_filter_time_split_is_as_close_as_its_junctions_say(T, segments, bur
     got = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(segments, burn_in))
     err = float(_engine.last_junction_error.max())
     print(T, segments, burn_in, 'junction mismatch', err, [f'{_rel(g, s):.1e}' for g, s in zip(got, seq)])
-    assert 0 < err < 1e-4
+    assert (0 < err < 1e-4) if burn_in < T // 2 else err == 0.0       # a burn-in that reaches the record's start IS the sequential filter
     for g, s, n in zip(got, seq, ('mfs', 'Pfs', 'nll')):
         assert np.isfinite(g).all()
         assert _rel(g, s) <= 5 * err, (n, _rel(g, s), err)
