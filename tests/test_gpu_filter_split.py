@@ -29,11 +29,12 @@ def test_sgp_filter_time_split_is_as_close_as_its_junctions_say(T, segments, bur
     got = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(segments, burn_in))
     err = float(_engine.last_junction_error.max())
     print(T, segments, burn_in, 'junction mismatch', err, [f'{_rel(g, s):.1e}' for g, s in zip(got, seq)])
-    assert (0 < err < 1e-4) if burn_in < T // 2 else err == 0.0       # a burn-in that reaches the record's start IS the sequential filter
+    seg_len = -(-(-(-T // segments)) // 64) * 64
+    exact = -(-burn_in // 64) * 64 >= (-(-T // seg_len) - 1) * seg_len       # every burn-in reaches the record's start: the sequential filter
+    assert err == 0.0 if exact else 0 < err < 1e-4
     for g, s, n in zip(got, seq, ('mfs', 'Pfs', 'nll')):
         assert np.isfinite(g).all()
         assert _rel(g, s) <= 5 * err, (n, _rel(g, s), err)
-    seg_len = -(-(-(-T // segments)) // 64) * 64
     assert np.array_equal(got[0][:, :seg_len], seq[0][:, :seg_len])               # the first segment IS the sequential filter
     last = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(segments, burn_in), nll_final_only=True, want=(False, False, True))[2]
     assert _rel(last, seq[2][:, -1]) <= 5 * err
