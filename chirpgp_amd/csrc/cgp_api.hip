@@ -362,6 +362,10 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
                           int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags,
                           int64_t segments, int64_t burn_in, double* junction_err, void* stream) {
     if (ctx && segments < 1) return fail(ctx, CGP_E_ARG, "segments must be >= 1");
+    if (ctx && segments == 1 && junction_err && B > 0) {                 // nothing is split: no junction, no mismatch
+        DeviceScope on_device(ctx->device);
+        if (!on_device.ok || hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, (hipStream_t)stream) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipMemsetAsync failed");
+    }
     return filter_impl(ctx, method, model, sigma, init, dt, ys, ys_stride, ys_repeat, ys_index, B, T, mfs, Pfs, nll, flags, stream, segments, burn_in, junction_err);
 }
 
