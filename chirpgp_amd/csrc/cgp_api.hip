@@ -273,15 +273,25 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T; io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags;
     io.counters = ctx->counters;
+    const ModelArgs ma = model_args(model, sigma, dt, flags);
     // ---- time-split with burn-in (cgp_filter_time_split): segments of whole 64-step chunks, one wavefront each
     const bool split = segments > 1;
     double* seg_ws = nullptr;
     if (split) {
         if (burn_in < 0) return fail(ctx, CGP_E_ARG, "burn_in must be >= 0");
         if (!junction_err) return fail(ctx, CGP_E_ARG, "junction_err must be set: a time-split filter is only as good as its junctions");
-        const bool chirp4_sgp = method == CGP_F_SGP && model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
-        if (!chirp4_sgp || (flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_THREAD_PER_TRIAL)))
-            return fail(ctx, CGP_E_UNSUPPORTED, "time-split filters are built for sgp_filter on the d = 4 chirp / La Scala models (matrix-core kernel) only");
+        // the kernels that know segments, under the conditions the dispatch below sends a launch to them
+        const bool lcd4 = model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
+        bool known = false;
+        if (!(flags & (CGP_GENERIC_KERNEL | CGP_DPP_KERNEL | CGP_THREAD_PER_TRIAL | CGP_FOUR_TRIALS_PER_WAVE))) {
+            if (method == CGP_F_SGP && lcd4) known = sigma_mfma_taken(flags, T, ma);
+            else if (method == CGP_F_SGP && model->model_id == CGP_M_HARMONIC_LCD) known = coop8_filter_sgp_ok(model->n_harm, T, ma);
+            else if (method == CGP_F_CD_SGP && model->model_id == CGP_M_HARMONIC_SDE && model->n_harm == 1) known = sigma_mfma_taken(flags, T, ma);
+            else if (method == CGP_F_EKF && lcd4) known = T * 128 <= 0x7FFFFF00LL;
+        }
+        if (!known)
+            return fail(ctx, CGP_E_UNSUPPORTED, "time-split filters are built for ekf / sgp_filter / cd_sgp_filter on the d = 4 chirp and La Scala models "
+                                                "and sgp_filter on the 2- / 3-harmonic model (matrix-core and tile-layout kernels, standard sigma sets)");
         int64_t seg_len = ((T + segments - 1) / segments + 63) / 64 * 64;
         const int64_t segs = (T + seg_len - 1) / seg_len;                  // without the empty ones
         io.segs = (int)segs; io.seg_len = seg_len; io.burn_in = (burn_in + 63) / 64 * 64;
@@ -294,7 +304,6 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
             io.flags = flags;
         } else io.segs = 1;
     }
-    const ModelArgs ma = model_args(model, sigma, dt, flags);
     // which lane-cooperative kernel (if any) a wave-per-trial launch of this call would take decides the crossover
     const bool spec = !(flags & CGP_GENERIC_KERNEL);
     const bool chirp4 = spec && model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD);
@@ -339,10 +348,8 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     }
     if (split) {
         if (rc == CGP_OK) {
-            if (io.segs > 1) {
-                if (!sigma_mfma_taken(flags, T, ma)) rc = CGP_E_UNSUPPORTED;        // the launch fell back to a kernel that ignores the segments
-                else hipLaunchKernelGGL(filter_split_fixup_kernel, dim3((unsigned)B), dim3(64), 0, st, io, model->d, junction_err);
-            } else if (hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, st) != hipSuccess) rc = CGP_E_HIP;
+            if (io.segs > 1) hipLaunchKernelGGL(filter_split_fixup_kernel, dim3((unsigned)B), dim3(64), 0, st, io, model->d, junction_err);
+            else if (hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, st) != hipSuccess) rc = CGP_E_HIP;
         }
         if (seg_ws && hipFreeAsync(seg_ws, st) != hipSuccess && rc == CGP_OK) rc = CGP_E_HIP;
     }

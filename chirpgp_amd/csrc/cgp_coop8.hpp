@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
     const int i = 4 * I + r, j = 4 * J + q;                              // this lane's covariance entry
-    const int64_t trial = blockIdx.x;
+    const FilterSpan span = filter_span(io, blockIdx.x);                 // (a time-split launch: one SEGMENT of the trial's record)
+    const int64_t trial = span.trial;
     if (trial >= io.B) return;
 
     HarmonicLCD<NH> model;
@@ -197,10 +198,17 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     const unsigned offm = mean_lane ? (unsigned)i * 8u : kOobOffset;
 
     double cum = 0.0;
-    for (int64_t t0 = 0; t0 < T; t0 += 64) {
-        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+    constexpr int kN = D + D * D;                                        // doubles of one (m, P) record of FilterIO::seg_state
+    for (int64_t t0 = span.t_begin; t0 < span.t_end; t0 += 64) {
+        double ychunk = (t0 + lane < span.t_end) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
-        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
+        const bool burn = t0 < span.t_out;                               // burn-in chunks of a segment write nothing
+        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        if (span.state && span.seg > 0 && t0 == span.t_out) {            // the junction: the state the burn-in arrived at
+            if (entry) span.state[D + i * D + j] = P;
+            if (mean_lane) span.state[i] = mrow;
+        }
         ybuf[lane] = ychunk;
         wave_lds_fence();
         double ynext = ybuf[0];
@@ -282,17 +290,21 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             double S, innov;
             coop8_update(Pp, mp, HR, HC, XiC, y, P, mrow, S, innov);
             park[slot] = make_double2(S, innov);
-            wP.store(P, t * (unsigned)(D * D * 8) + offP);
-            wm.store(mrow, t * (unsigned)(D * 8) + offm);
+            wP.store(P, t * (unsigned)(D * D * 8) + offP_c);
+            wm.store(mrow, t * (unsigned)(D * 8) + offm_c);
         }
-        if (want_nll) {
+        if (want_nll && !burn) {
             wave_lds_fence();
             const double2 si = park[lane < nsteps ? lane : 0];
             cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
             wave_lds_fence();
         }
     }
-    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+    if (span.state) {                                                    // the segment's last state and its NLL total, for the fix-up pass
+        if (entry) span.state[kN + D + i * D + j] = P;
+        if (mean_lane) span.state[kN + i] = mrow;
+        if (lane == 0) span.state[2 * kN] = cum;
+    } else if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 
 // ekf8_coop_kernel: ekf (filters_smoothers.py:222-264) for the harmonic chirp LCD model with two or three harmonics, in
@@ -434,8 +446,9 @@ template <int NH>
 inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (io.T * ((2 * NH + 2) * (2 * NH + 2) * 8) > kOobMaxBytes) return CGP_E_UNSUPPORTED;        // output windows (OobWindow)
-    if (ma.sg.flags & CGP_SIGMA_AXIAL) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
-    else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
+    if (ma.sg.flags & CGP_SIGMA_AXIAL) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

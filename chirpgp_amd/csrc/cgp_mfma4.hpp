@@ -260,7 +260,8 @@ template <bool E1>
 CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    const FilterSpan span = filter_span(io, blockIdx.x);                 // (a time-split launch: one SEGMENT of the trial's record)
+    const int64_t trial = span.trial;
 
     HarmonicLCD<1> model;
     model.setup(ma.params + trial * ma.param_stride, ma.dt, ma.model_id);
@@ -323,15 +324,23 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     // 64 measurements with one coalesced 512-B load, requested ONE CHUNK AHEAD: the wait for a load issued at the chunk's own
     // start exposes the whole memory latency (and, vmcnt counting in order, the drain of every store still in flight) once per
     // 64 steps -- 2.7 us of a 16 us chunk
-    double ynext = (lane < T) ? ys[lane] : 0.0;
-    for (int64_t t0 = 0; t0 < T; t0 += 64) {
+    const int64_t Te = span.t_end;
+    double ynext = (span.t_begin + lane < Te) ? ys[span.t_begin + lane] : 0.0;
+    for (int64_t t0 = span.t_begin; t0 < Te; t0 += 64) {
         wave_lds_fence();                                                   // the previous chunk's NLL flush has read its slots
+        // a segment's burn-in chunks write nothing (whole chunks: t_out is a multiple of 64); at the junction the state goes on record
+        const bool burn = t0 < span.t_out;
+        const unsigned p_off_c = burn ? kOobOffset : p_off, m_off_c = burn ? kOobOffset : m_off;
+        if (span.state && span.seg > 0 && t0 == span.t_out) {
+            if (lane < 4) span.state[lane] = x.uq;
+            if (((lane >> 2) & 3) == 0) span.state[4 + 4 * r + q] = x.P;
+        }
         // The empty asm consumes the loaded register here, so the compiler's s_waitcnt for it sits in this outer loop and
         // not in front of every step's v_readlane
         double ychunk = ynext;
         asm volatile("" : "+v"(ychunk));
-        ynext = (t0 + 64 + lane < T) ? ys[t0 + 64 + lane] : 0.0;
-        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        ynext = (t0 + 64 + lane < Te) ? ys[t0 + 64 + lane] : 0.0;
+        const int nsteps = (Te - t0 < 64) ? (int)(Te - t0) : 64;
         const Ekf4State x0 = x;
         unsigned uncommon = 0;                                              // Ekf4Verdict::code of the chunk's last speculative pass
         if (checked_left == 0) {
@@ -355,8 +364,8 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                     ekf4_mfma_step_spec1<E1 ? 2 : 0, HIGH>(K, R, RH, y, x, anchor, S, innov, verdict);
                     park[(slot + k) * kParkStride] = make_double2(S, innov);
                     const unsigned t = (unsigned)(t0 + slot);
-                    Pfs.store_s(x.P, p_off + k * 128u, t * 128u);
-                    mfs.store_s(x.uq, m_off + k * 32u, t * 32u);
+                    Pfs.store_s(x.P, p_off_c + k * 128u, t * 128u);
+                    mfs.store_s(x.uq, m_off_c + k * 32u, t * 32u);
                 };
                 int slot = 0;
                 // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms;
@@ -408,18 +417,22 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store_s(x.P, p_off, t * 128u);
-                mfs.store_s(x.uq, m_off, t * 32u);
+                Pfs.store_s(x.P, p_off_c, t * 128u);
+                mfs.store_s(x.uq, m_off_c, t * 32u);
             }
             checked_left--;
         }
-        if (want_nll) {
+        if (want_nll && !burn) {
             wave_lds_fence();
             const double2 si = park[(lane < nsteps ? lane : 0) * kParkStride];
             cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
         }
     }
-    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+    if (span.state) {                                                       // the segment's last state and its NLL total, for the fix-up pass
+        if (lane < 4) span.state[20 + lane] = x.uq;
+        if (((lane >> 2) & 3) == 0) span.state[24 + 4 * r + q] = x.P;
+        if (lane == 0) span.state[40] = cum;
+    } else if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
     if (io.counters && lane == 0) {
         atomicAdd(io.counters + 0, (unsigned long long)n_high); atomicAdd(io.counters + 1, (unsigned long long)n_common);
         atomicAdd(io.counters + 2, (unsigned long long)n_redo); atomicAdd(io.counters + 3, (unsigned long long)n_checked);
@@ -532,7 +545,7 @@ inline int launch_kf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t 
 }
 
 __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma) {
-    const int64_t trial = blockIdx.x;
+    const int64_t trial = filter_span(io, blockIdx.x).trial;
     if (trial >= io.B) return;
     // the measurement vector of every chirp / La Scala builder is e_1 (models.py:118): the short-chain form of the update;
     // any other H (the API takes one per trial) runs the general form -- a wave-uniform choice
@@ -697,7 +710,9 @@ inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t
     // long for it is refused HERE, next to the kernels that need it (the dispatcher routes such records to the DPP kernel)
     if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
     // beyond one wave per SIMD the four MFMA blocks carry four trials (CGP_ONE_TRIAL_PER_WAVE keeps one, for tests)
-    if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
+    if (io.segs > 1)           // time-split with burn-in: one wavefront per (trial, segment)
+        hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)(io.B * io.segs)), dim3(64), 0, stream, io, ma);
+    else if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
     {
         if (io.B > 4096) hipLaunchKernelGGL(ekf4_mfma_x4_kernel<true>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
         else hipLaunchKernelGGL(ekf4_mfma_x4_kernel<false>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);

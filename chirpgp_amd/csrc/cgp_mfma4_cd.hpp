@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    const FilterSpan span = filter_span(io, blockIdx.x);                 // (a time-split launch: one SEGMENT of the trial's record)
+    const int64_t trial = span.trial;
     if (trial >= io.B) return;
 
     SM model;
@@ -158,10 +159,16 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     const bool want_nll = io.nll != nullptr;
 
     double cum = 0.0;
-    for (int64_t t0 = 0; t0 < T; t0 += 64) {
-        double ychunk = (t0 + lane < T) ? ys[t0 + lane] : 0.0;
+    for (int64_t t0 = span.t_begin; t0 < span.t_end; t0 += 64) {
+        double ychunk = (t0 + lane < span.t_end) ? ys[t0 + lane] : 0.0;
         asm volatile("" : "+v"(ychunk));
-        const int nsteps = (T - t0 < 64) ? (int)(T - t0) : 64;
+        const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
+        const bool burn = t0 < span.t_out;                               // burn-in chunks of a segment write nothing
+        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        if (span.state && span.seg > 0 && t0 == span.t_out) {            // the junction: the state the burn-in arrived at
+            if (lane < 4) span.state[lane] = u;
+            if (b == 0) span.state[4 + 4 * r + q] = P;
+        }
         for (int slot = 0; slot < nsteps; slot++) {
             const unsigned t = (unsigned)(t0 + slot);
             const double y = readlane_f64(ychunk, slot);
@@ -182,17 +189,21 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
             double S, innov;
             mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
-            wP.store(P, t * 128u + offP);
-            wm.store(u, t * 32u + offm);
+            wP.store(P, t * 128u + offP_c);
+            wm.store(u, t * 32u + offm_c);
         }
-        if (want_nll) {
+        if (want_nll && !burn) {
             wave_lds_fence();
             const double2 si = park[lane < nsteps ? lane : 0];
             cum = nll_flush_wave(si.x, si.y, lane, nsteps, cum, nll ? nll + t0 : nullptr);
             wave_lds_fence();
         }
     }
-    if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
+    if (span.state) {                                                    // the segment's last state and its NLL total, for the fix-up pass
+        if (lane < 4) span.state[20 + lane] = u;
+        if (b == 0) span.state[24 + 4 * r + q] = P;
+        if (lane == 0) span.state[40] = cum;
+    } else if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 
 // ------------------------------------------------------------------------------------------------ cd_sgp_smoother, d = 4
@@ -457,8 +468,9 @@ template <class SM>
 inline int launch_cdsgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (!sgp4_mfma_fits(io, ma)) return CGP_E_UNSUPPORTED;
-    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
-    else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
+    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 template <class SM>

@@ -49,10 +49,10 @@ def test_one_segment_is_the_sequential_filter_and_unsupported_methods_say_so():
     assert all(np.array_equal(a, b) for a, b in zip(one, seq)) and float(_engine.last_junction_error.max()) == 0.0
     short = fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys[:, :50], time_split=(4, 640))      # one chunk: nothing to split
     assert np.array_equal(short[0], seq[0][:, :50])
-    h = cs.harmonic_case(T=300, seed=83, nh=2)
     with pytest.raises(RuntimeError, match='time-split'):
         fs.cd_ekf(c.drift, c.disp, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(2, 128))
-    del h
+    with pytest.raises(RuntimeError, match='time-split'):                              # the generic kernels do not know segments
+        fs.sgp_filter(c.disc, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys, time_split=(2, 128), flags=0x10)
 
 
 def test_a_nan_at_a_junction_is_reported_and_the_tolerance_falls_back():
@@ -94,3 +94,34 @@ def test_small_batch_time_split_is_faster():
     worst = max(float((g - s).abs().max() / s.abs().max()) for g, s in zip(got, seq))
     print(f'sgp_filter 125 x 10000: sequential {t_seq:.3f} ms, 8 segments + 3008 burn-in {t_split:.3f} ms, junction mismatch {err:.1e}, worst output difference {worst:.1e}')
     assert err < 1e-6 and worst <= 5 * err and t_split < 0.6 * t_seq
+
+
+@pytest.mark.parametrize('method', ['ekf', 'cd_sgp_filter', 'sgp_filter_d6', 'sgp_filter_d8', 'ekf_general_H'])
+def test_the_other_kernels_that_know_segments(method):
+    """ekf (the bench kernel, also with a measurement vector that is not e_1), cd_sgp_filter (RK4) at d = 4, and the tile-layout
+    sigma-point filter at d = 6 / 8: split into four segments with 3008 steps of burn-in, against their own sequential launch."""
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    T, B = 5500, 4
+    if method.startswith('sgp_filter_d'):
+        nh = 2 if method.endswith('6') else 3
+        c = cs.harmonic_case(T=3000, seed=90 + nh, nh=nh)
+    else:
+        c = cs.chirp_case(T=3000, seed=90)
+    ys = np.tile(c.ys, 2)[None, :T] + 0.05 * np.random.default_rng(7).standard_normal((B, T))
+    H = c.H if method != 'ekf_general_H' else np.array([0.2, 1.0, 0.0, 0.1])
+    if method in ('ekf', 'ekf_general_H'):
+        run = lambda **kw: fs.ekf(c.disc, H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
+    elif method == 'cd_sgp_filter':
+        run = lambda **kw: fs.cd_sgp_filter(c.drift, c.disp(None), c.sgps, H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
+    else:
+        run = lambda **kw: fs.sgp_filter(c.disc, c.sgps, H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
+    seq = run()
+    got = run(time_split=(4, 3008))
+    err = float(_engine.last_junction_error.max())
+    rel = [_rel(g, s_) for g, s_ in zip(got, seq)]
+    print(method, 'junction mismatch', f'{err:.1e}', [f'{v:.1e}' for v in rel])
+    assert 0 < err < 1e-4 and max(rel) <= 5 * err + 1e-14
+    assert np.array_equal(got[0][:, :1408], seq[0][:, :1408])                          # segment 0 is the sequential filter
+    last = run(time_split=(4, 3008), nll_final_only=True, want=(False, False, True))[2]
+    seq_last = run(nll_final_only=True, want=(False, False, True))[2]
+    assert _rel(last, seq_last) <= 5 * err + 1e-12
