@@ -120,8 +120,16 @@ def test_the_other_kernels_that_know_segments(method):
     err = float(_engine.last_junction_error.max())
     rel = [_rel(g, s_) for g, s_ in zip(got, seq)]
     print(method, 'junction mismatch', f'{err:.1e}', [f'{v:.1e}' for v in rel])
-    assert 0 < err < 1e-4 and max(rel) <= 5 * err + 1e-14
+    assert max(rel) <= 5 * err + 1e-14
     assert np.array_equal(got[0][:, :1408], seq[0][:, :1408])                          # segment 0 is the sequential filter
+    if method == 'ekf_general_H':
+        # with this measurement vector the EKF does NOT forget its start within 3008 steps (another start settles on another
+        # track): the junctions say so -- a mismatch of percents -- and a caller's tolerance sends the call to the sequential filter
+        assert err > 1e-3
+        safe = run(time_split=(4, 3008), split_tol=1e-5)
+        assert all(np.array_equal(a, b) for a, b in zip(safe, seq))
+        return
+    assert 0 < err < 1e-4
     last = run(time_split=(4, 3008), nll_final_only=True, want=(False, False, True))[2]
     seq_last = run(nll_final_only=True, want=(False, False, True))[2]
     assert _rel(last, seq_last) <= 5 * err + 1e-12
