@@ -477,6 +477,43 @@ def main():
         return dict(wl=wl, kind=wl['kind'], T=T, steps=steps, B=B, B_total=B_total, elapsed=elapsed, gather_ms=gather_ms,
                     filt_ms=mine[1], smooth_ms=mine[2], filt_ms_max=filt_max, smooth_ms_max=smooth_max, regimes=regimes)
 
+    def measure_time_split(steps):
+        """The time-split filters with burn-in (cgp_filter_time_split) at the shard sizes BASELINE's 8-GPU configurations leave on one
+        GPU -- C2 / C3 / C5: 125 x 10 000, C4: 512 x 50 000 -- next to the sequential launch of the same kernel: kernel time, the
+        launch's own junction mismatch, the worst difference of its outputs from the sequential ones.  Not the default anywhere."""
+        out = {"what": "cgp_filter_time_split: segments = SIMDs // trials wavefronts per trial, each starting `burn_in` steps before its "
+                       "piece from (m0, P0); results are as close to the sequential filter's as junction_mismatch says (include/chirpgp_hip.h)"}
+        for tag, kind, B, T, segs, burn in (("C2_shard", 'ekf', 125, 10000, 8, 4096), ("C3_shard", 'sgp', 125, 10000, 8, 3008),
+                                            ("C5_shard", 'harmonic', 125, 10000, 8, 3008), ("C4_per_gpu", 'cd_sgp', 512, 50000, 2, 3008)):
+            wl = make_workload(B, T, seed=1000003 * rank, kind=kind)
+            ys_dev = torch.from_numpy(wl['ys']).cuda()
+            a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'], ys_dev)
+            if kind == 'ekf':
+                run = lambda **kw: fs.ekf(wl['disc'], *a, **kw)
+            elif kind == 'cd_sgp':
+                run = lambda **kw: fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], *a, **kw)
+            else:
+                run = lambda **kw: fs.sgp_filter(wl['disc'], wl['sgps'], *a, **kw)
+            res = {}
+            for name, kw in (("sequential", {}), ("time_split", dict(time_split=(segs, burn)))):
+                r = run(**kw)
+                sync()
+                events = _engine.kernel_events = []
+                for _ in range(steps):
+                    r = run(**kw)
+                sync()
+                _engine.kernel_events = None
+                res[name] = (r, float(np.mean([x.elapsed_time(y) for n, x, y in events if n == 'filter'])))
+            err = float(_engine.last_junction_error.max())
+            worst = max(float((g - s).abs().max() / s.abs().max()) for g, s in zip(res["time_split"][0], res["sequential"][0]))
+            out[tag] = {"workload": WORKLOADS[kind][0], "batch_per_gpu": B, "T": T, "segments": segs, "burn_in": burn,
+                        "sequential_filter_ms": res["sequential"][1], "time_split_filter_ms": res["time_split"][1],
+                        "speedup": res["sequential"][1] / res["time_split"][1], "junction_mismatch": err, "worst_output_difference": worst,
+                        "accepted_at_1e-5": bool(err <= 1e-5)}
+            del res, r, ys_dev
+            torch.cuda.empty_cache()
+        return out
+
     def measure_crlb(B, T, steps):
         """The reference's only batched use of the path (tetralith/jobs/crlb_ekf.py:59-79): EKF over B simulated chirp-SDE
         records of T steps, dt = 0.01, filter only -- with the means alone (what the job keeps) and with full outputs."""
@@ -522,13 +559,14 @@ def main():
     # The other BASELINE configurations under the same clock: a few passes each after the headline loop, their own default
     # sizes and scaling (C3 / C5: 1000 trials sharded; C4: 512 x 50 000 per GPU; C1: one record per rank).
     others = {}
-    crlb = None
+    crlb = tsplit = None
     default_shape = args.workload == 'ekf' and args.batch is None and args.T is None and not args.flags
     if default_shape and not args.no_other_configs:
         for tag, kind in OTHER_CONFIGS:
             _, Bo, To, mode_o, _ = WORKLOADS[kind if kind != 'ekf_low' else 'ekf']
             others[tag] = measure(kind, mode_o, Bo, To, args.other_steps, 1, {})
         crlb = measure_crlb(262144, 500, args.other_steps)
+        tsplit = measure_time_split(args.other_steps) if world == 1 else None
 
     if use_dist:
         dist.destroy_process_group()       # ranks other than 0 are done: rank 0 times the host CPU with nobody spinning beside it
@@ -594,6 +632,8 @@ def main():
                     oc[tag]["regimes"] = o['regimes']
             if crlb:
                 oc["CRLB_ekf"] = crlb
+            if tsplit:
+                oc["time_split_filters"] = tsplit
             result["other_configs"] = oc
         if not args.no_cpu_baseline:
             try:                                        # the GPU figures above are printed whatever happens to the host-side build / run

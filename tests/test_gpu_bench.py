@@ -61,7 +61,7 @@ def test_default_line_carries_the_other_baseline_configs():
     r = _run('--steps', '3', '--warmup', '1', '--other-steps', '1', '--no-cpu-baseline')
     assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000 and r['roofline']['traffic'] is not None
     oc = r['other_configs']
-    assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf'}
+    assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'time_split_filters'}
     # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
     rg = r['regimes']
     assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['checked'] == rg['chunks']
@@ -73,6 +73,11 @@ def test_default_line_carries_the_other_baseline_configs():
     assert (crlb['batch_per_gpu'], crlb['T']) == (262144, 500)
     for k in ('means_only', 'full_outputs'):
         assert crlb[k]['filter_ms'] > 0 and 0 < crlb[k]['hbm_frac'] < 1
+    ts = oc['time_split_filters']
+    for k in ('C2_shard', 'C3_shard', 'C4_per_gpu'):                      # the chirp filters forget: junctions at 1e-6 or better, >= 1.4 x
+        assert ts[k]['accepted_at_1e-5'] and ts[k]['junction_mismatch'] < 1e-5 and ts[k]['worst_output_difference'] <= 5 * ts[k]['junction_mismatch']
+        assert ts[k]['speedup'] > 1.4, (k, ts[k])
+    assert not ts['C5_shard']['accepted_at_1e-5']                         # the 3-harmonic filter does not, and its junctions say so
     assert (oc['C1']['batch_per_gpu'], oc['C1']['T'], oc['C1']['d']) == (1, 1000, 4)
     assert (oc['C3']['batch_per_gpu'], oc['C3']['T']) == (1000, 10000) and oc['C3']['scaling'] == 'strong'
     assert (oc['C4']['batch_per_gpu'], oc['C4']['T']) == (512, 50000)
@@ -98,6 +103,6 @@ def test_two_rank_rehearsal_of_the_default_line():
     oc = r['other_configs']
     assert oc['C3']['batch_per_gpu'] == 500 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 500
     assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 1024 and oc['C1']['global_batch'] == 2
-    assert all(v['value'] > 0 and v['filter_ms'] > 0 for k, v in oc.items() if k != 'CRLB_ekf')
+    assert all(v['value'] > 0 and v['filter_ms'] > 0 for k, v in oc.items() if k not in ('CRLB_ekf', 'time_split_filters'))
     assert oc['CRLB_ekf']['full_outputs']['filter_ms'] > 0
     assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0
