@@ -292,9 +292,10 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
 
     const int64_t T = io.T;
     const double* __restrict__ ys = io.record(trial);
-    OobWindow mfs, Pfs;
+    OobWindow mfs, Pfs, mnull, Pnull;
     mfs.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     Pfs.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
+    mnull.init(nullptr, 0); Pnull.init(nullptr, 0);                      // the burn-in chunks of a time-split segment store through these
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     double* __restrict__ nll = (io.nll && !nll_final) ? io.nll + trial * T : nullptr;
     const bool want_nll = io.nll != nullptr;
@@ -329,8 +330,10 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     for (int64_t t0 = span.t_begin; t0 < Te; t0 += 64) {
         wave_lds_fence();                                                   // the previous chunk's NLL flush has read its slots
         // a segment's burn-in chunks write nothing (whole chunks: t_out is a multiple of 64); at the junction the state goes on record
+        // (which WINDOW a chunk stores through is a scalar choice of the buffer descriptor: an empty window drops every store, and the
+        // per-lane offsets stay the loop-invariant constants they were -- as per-chunk offsets they cost two vector adds a step)
         const bool burn = t0 < span.t_out;
-        const unsigned p_off_c = burn ? kOobOffset : p_off, m_off_c = burn ? kOobOffset : m_off;
+        const OobWindow Pw = burn ? Pnull : Pfs, mw = burn ? mnull : mfs;
         if (span.state && span.seg > 0 && t0 == span.t_out) {
             if (lane < 4) span.state[lane] = x.uq;
             if (((lane >> 2) & 3) == 0) span.state[4 + 4 * r + q] = x.P;
@@ -364,8 +367,8 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                     ekf4_mfma_step_spec1<E1 ? 2 : 0, HIGH>(K, R, RH, y, x, anchor, S, innov, verdict);
                     park[(slot + k) * kParkStride] = make_double2(S, innov);
                     const unsigned t = (unsigned)(t0 + slot);
-                    Pfs.store_s(x.P, p_off_c + k * 128u, t * 128u);
-                    mfs.store_s(x.uq, m_off_c + k * 32u, t * 32u);
+                    Pw.store_s(x.P, p_off + k * 128u, t * 128u);
+                    mw.store_s(x.uq, m_off + k * 32u, t * 32u);
                 };
                 int slot = 0;
                 // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms;
@@ -417,8 +420,8 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
-                Pfs.store_s(x.P, p_off_c, t * 128u);
-                mfs.store_s(x.uq, m_off_c, t * 32u);
+                Pw.store_s(x.P, p_off, t * 128u);
+                mw.store_s(x.uq, m_off, t * 32u);
             }
             checked_left--;
         }
