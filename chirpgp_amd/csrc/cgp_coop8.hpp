@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     FanRegs R;
     R.init();
     // outputs as raw buffer windows: which lanes store is an offset, not a branch (cgp_coop4.hpp:OobWindow)
-    OobWindow wP, wm;
+    OobWindow wP, wm, wnull;
+    wnull.init(nullptr, 0);                                              // (the burn-in chunks of a time-split segment store through it)
     wP.init(Pfs, T * (D * D * 8));
     wm.init(mfs, T * (D * 8));
     const unsigned offP = entry ? (unsigned)(i * D + j) * 8u : kOobOffset;
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
         const bool burn = t0 < span.t_out;                               // burn-in chunks of a segment write nothing
-        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        const OobWindow wPc = burn ? wnull : wP, wmc = burn ? wnull : wm;   // an empty window drops the stores; the lane offsets stay loop-invariant
         if (span.state && span.seg > 0 && t0 == span.t_out) {            // the junction: the state the burn-in arrived at
             if (entry) span.state[D + i * D + j] = P;
             if (mean_lane) span.state[i] = mrow;
@@ -290,8 +291,8 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
             double S, innov;
             coop8_update(Pp, mp, HR, HC, XiC, y, P, mrow, S, innov);
             park[slot] = make_double2(S, innov);
-            wP.store(P, t * (unsigned)(D * D * 8) + offP_c);
-            wm.store(mrow, t * (unsigned)(D * 8) + offm_c);
+            wPc.store(P, t * (unsigned)(D * D * 8) + offP);
+            wmc.store(mrow, t * (unsigned)(D * 8) + offm);
         }
         if (want_nll && !burn) {
             wave_lds_fence();

@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
     double P = coop4_load_sym_entry(io.P0 + trial * io.P0_stride, r, q);
     const int64_t T = io.T;
     const double* __restrict__ ys = io.record(trial);
-    OobWindow wP, wm;
+    OobWindow wP, wm, wnull;
+    wnull.init(nullptr, 0);                                              // (the burn-in chunks of a time-split segment store through it)
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;      // block 0 stores the 16 entries: one 128-B row
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
         asm volatile("" : "+v"(ychunk));
         const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
         const bool burn = t0 < span.t_out;                               // burn-in chunks of a segment write nothing
-        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        const OobWindow wPc = burn ? wnull : wP, wmc = burn ? wnull : wm;   // an empty window drops the stores; the lane offsets stay loop-invariant
         if (span.state && span.seg > 0 && t0 == span.t_out) {            // the junction: the state the burn-in arrived at
             if (lane < 4) span.state[lane] = u;
             if (b == 0) span.state[4 + 4 * r + q] = P;
@@ -189,8 +190,8 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
             double S, innov;
             mfma4_update_col(Pp, f, Hk, Hq, Xi, y, P, u, S, innov);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
-            wP.store(P, t * 128u + offP_c);
-            wm.store(u, t * 32u + offm_c);
+            wPc.store(P, t * 128u + offP);
+            wmc.store(u, t * 32u + offm);
         }
         if (want_nll && !burn) {
             wave_lds_fence();

@@ -161,7 +161,8 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
 
     const int64_t T = io.T;
     const double* __restrict__ ys = io.record(trial);
-    OobWindow wP, wm;
+    OobWindow wP, wm, wnull;
+    wnull.init(nullptr, 0);                                              // (the burn-in chunks of a time-split segment store through it)
     wP.init(io.Pfs ? io.Pfs + trial * T * 16 : nullptr, T * 128);
     wm.init(io.mfs ? io.mfs + trial * T * 4 : nullptr, T * 32);
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;      // block 0 stores the 16 entries: one 128-B row
@@ -177,7 +178,7 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         const int nsteps = (span.t_end - t0 < 64) ? (int)(span.t_end - t0) : 64;
         // a segment's burn-in chunks (whole chunks: t_out is a multiple of 64) write nothing: their rows belong to the segment before
         const bool burn = t0 < span.t_out;
-        const unsigned offP_c = burn ? kOobOffset : offP, offm_c = burn ? kOobOffset : offm;
+        const OobWindow wPc = burn ? wnull : wP, wmc = burn ? wnull : wm;   // an empty window drops the stores; the lane offsets stay loop-invariant
         if (span.state && span.seg > 0 && t0 == span.t_out) {          // the junction: the state the burn-in arrived at
             if (lane == 0) { span.state[0] = u0; span.state[1] = u1; span.state[2] = u2; span.state[3] = u3; }
             if (b == 0) span.state[4 + 4 * r + q] = P;
@@ -237,9 +238,9 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             u2 = fma(row_bcast_f64<2>(PHc), g, f2);
             u3 = fma(row_bcast_f64<3>(PHc), g, f3);
             park[slot] = make_double2(S, innov);                        // every lane holds them: same address, same value
-            wP.store(P, t * 128u + offP_c);
-            wm.store2(u0, u1, t * 32u + offm_c);
-            wm.store2(u2, u3, t * 32u + 16u + offm_c);
+            wPc.store(P, t * 128u + offP);
+            wmc.store2(u0, u1, t * 32u + offm);
+            wmc.store2(u2, u3, t * 32u + 16u + offm);
         }
         if (want_nll && !burn) {
             wave_lds_fence();
