@@ -118,7 +118,7 @@ CGP_DEV void coop8_update(double Pp, double mp, double HR, double HC, double XiC
 //     xs_c = sgn(xi_c) sqrt(sum_c xi_c^2 dv_c),
 // instead of one per pivot: 20 instead of 49 operations (and one v_rsq_f64 instead of seven) of a step that is bound by
 // instruction issue.
-template <int NH, bool AXIAL>
+template <int NH, bool AXIAL, bool SPLIT>
 __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma) {
     constexpr int D = 2 * NH + 2, NL = 2 * NH, V = NL;
     static_assert(NH == 2 || NH == 3, "d = 6 and d = 8");
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
     const int i = 4 * I + r, j = 4 * J + q;                              // this lane's covariance entry
-    const FilterSpan span = filter_span(io, blockIdx.x);                 // (a time-split launch: one SEGMENT of the trial's record)
+    const FilterSpan span = filter_span<SPLIT>(io, blockIdx.x);          // (a time-split launch: one SEGMENT of the trial's record)
     const int64_t trial = span.trial;
     if (trial >= io.B) return;
 
@@ -447,9 +447,14 @@ template <int NH>
 inline int launch_sgp8_coop(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (io.T * ((2 * NH + 2) * (2 * NH + 2) * 8) > kOobMaxBytes) return CGP_E_UNSUPPORTED;        // output windows (OobWindow)
-    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
-    if (ma.sg.flags & CGP_SIGMA_AXIAL) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
-    else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 2 * NH + 2), stream, io, ma);
+    const bool axial = (ma.sg.flags & CGP_SIGMA_AXIAL) != 0;
+    const size_t lds = sigma_lds_bytes(ma, 2 * NH + 2);
+    if (io.segs > 1) {                                                              // time-split: one wavefront per (trial, segment)
+        const unsigned grid = (unsigned)(io.B * io.segs);
+        if (axial) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true, true>), dim3(grid), dim3(64), lds, stream, io, ma);
+        else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false, true>), dim3(grid), dim3(64), lds, stream, io, ma);
+    } else if (axial) hipLaunchKernelGGL((sgp8_coop_kernel<NH, true, false>), dim3((unsigned)io.B), dim3(64), lds, stream, io, ma);
+    else hipLaunchKernelGGL((sgp8_coop_kernel<NH, false, false>), dim3((unsigned)io.B), dim3(64), lds, stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 

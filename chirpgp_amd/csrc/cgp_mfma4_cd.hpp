@@ -119,13 +119,13 @@ CGP_DEV void mfma4_update_col(double Pp, double fcol, double Hk, double Hq, doub
 }
 
 // ------------------------------------------------------------------------------------------------ cd_sgp_filter, d = 4
-template <class SM, bool TWO>
+template <class SM, bool TWO, bool SPLIT>
 __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const FilterSpan span = filter_span(io, blockIdx.x);                 // (a time-split launch: one SEGMENT of the trial's record)
+    const FilterSpan span = filter_span<SPLIT>(io, blockIdx.x);          // (a time-split launch: one SEGMENT of the trial's record)
     const int64_t trial = span.trial;
     if (trial >= io.B) return;
 
@@ -469,9 +469,13 @@ template <class SM>
 inline int launch_cdsgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (!sgp4_mfma_fits(io, ma)) return CGP_E_UNSUPPORTED;
-    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
-    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
-    else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    const bool two = ma.sg.n_groups > 16;
+    if (io.segs > 1) {                                                              // time-split: one wavefront per (trial, segment)
+        const unsigned grid = (unsigned)(io.B * io.segs);
+        if (two) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+        else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    } else if (two) hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, true, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((cdsgp4_mfma_kernel<SM, false, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 template <class SM>

@@ -110,7 +110,7 @@ CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef
 // E1 (round 4): the measurement vector is e_1, as in every chirp / La Scala builder of the reference (models.py:118) -- H then PICKS
 // entries of Pp (cgp_mfma4.hpp: ekf4_mfma_finish_j): Pp H by row is a row broadcast of Pp, S = Pp_11 + Xi a row broadcast of
 // (H Pp) by column, H . mp = mp_1 -- one matrix instruction where the general update has three, and no dot product.
-template <class DM, bool TWO, bool E1>
+template <class DM, bool TWO, bool E1, bool SPLIT>
 CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     static_assert(DM::D == 4, "d = 4 kernel");
     __shared__ double2 park[64];                                         // (S, innovation) of the chunk's steps, for the NLL
@@ -118,7 +118,7 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     // (time-split launches, cgp_filter_time_split: this wavefront is one SEGMENT of its trial's record -- cgp_kernels.hpp: FilterSpan)
-    const FilterSpan span = filter_span(io, blockIdx.x);
+    const FilterSpan span = filter_span<SPLIT>(io, blockIdx.x);
     const int64_t trial = span.trial;
 
     DM model;
@@ -254,14 +254,14 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         if (b == 0) span.state[24 + 4 * r + q] = P;
     } else if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
-template <class DM, bool TWO>
+template <class DM, bool TWO, bool SPLIT>
 __global__ void __launch_bounds__(64) sgp4_mfma_kernel(FilterIO io, ModelArgs ma) {
-    const int64_t trial = filter_span(io, blockIdx.x).trial;
+    const int64_t trial = filter_span<SPLIT>(io, blockIdx.x).trial;
     if (trial >= io.B) return;
     const double* __restrict__ Hp = io.H + trial * io.H_stride;
     const bool e1 = Hp[0] == 0.0 && Hp[1] == 1.0 && Hp[2] == 0.0 && Hp[3] == 0.0;      // a wave-uniform choice
-    if (e1) sgp4_mfma_trial<DM, TWO, true>(io, ma);
-    else sgp4_mfma_trial<DM, TWO, false>(io, ma);
+    if (e1) sgp4_mfma_trial<DM, TWO, true, SPLIT>(io, ma);
+    else sgp4_mfma_trial<DM, TWO, false, SPLIT>(io, ma);
 }
 
 // The matrix-core kernel takes collapsible sets of at most 32 groups whose output windows fit a raw buffer.
@@ -272,9 +272,13 @@ template <class DM>
 inline int launch_sgp4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (!sgp4_mfma_fits(io, ma)) return CGP_E_UNSUPPORTED;
-    const unsigned grid = (unsigned)(io.B * (io.segs > 1 ? io.segs : 1));           // one wavefront per (trial, segment)
-    if (ma.sg.n_groups > 16) hipLaunchKernelGGL((sgp4_mfma_kernel<DM, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
-    else hipLaunchKernelGGL((sgp4_mfma_kernel<DM, false>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    const bool two = ma.sg.n_groups > 16;
+    if (io.segs > 1) {                                                              // time-split: one wavefront per (trial, segment)
+        const unsigned grid = (unsigned)(io.B * io.segs);
+        if (two) hipLaunchKernelGGL((sgp4_mfma_kernel<DM, true, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+        else hipLaunchKernelGGL((sgp4_mfma_kernel<DM, false, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    } else if (two) hipLaunchKernelGGL((sgp4_mfma_kernel<DM, true, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    else hipLaunchKernelGGL((sgp4_mfma_kernel<DM, false, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     return hip_rc(hipGetLastError());
 }
 
