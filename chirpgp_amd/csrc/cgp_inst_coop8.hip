@@ -1,5 +1,9 @@
 // Lane-cooperative kernels in the 8 x 8 tile layout (cgp_coop8.hpp): harmonic chirp models with two or three harmonics.
+// The sigma-point filter and the smoothers take their polynomial steps as the compiler's own fma (C5's filter 10.68 -> 10.58 ms, its
+// smoother 4.69 -> 4.57 ms; profiles/r04_ab_series.txt); the EKF of the same header measured 1.7 % slower with it and is instantiated
+// in cgp_inst_coop8_ekf.hip with the inline-asm step.
 #define CGP_COOP4_HELPERS_ONLY
+#define CGP_HORNER_PLAIN
 #include "cgp_coop8.hpp"
 namespace cgp {
 // the kernel stores through raw buffer windows: one trial's Pf must fit one (cgp_coop4.hpp:kOobMaxBytes)
@@ -11,13 +15,6 @@ int dispatch_filter_coop8_sgp(int n_harm, const FilterIO& io, const ModelArgs& m
     switch (n_harm) {
     case 2: return launch_sgp8_coop<2>(io, ma, st);
     case 3: return launch_sgp8_coop<3>(io, ma, st);
-    default: return CGP_E_UNSUPPORTED;
-    }
-}
-int dispatch_filter_coop8_ekf(int n_harm, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
-    switch (n_harm) {
-    case 2: return launch_ekf8_coop<2>(io, ma, st);
-    case 3: return launch_ekf8_coop<3>(io, ma, st);
     default: return CGP_E_UNSUPPORTED;
     }
 }
