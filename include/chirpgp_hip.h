@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters), cgp_gaussian_expectation_fn */
+#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters), cgp_gaussian_expectation_fn, cgp_filter_time_split */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
