@@ -566,7 +566,7 @@ def main():
             _, Bo, To, mode_o, _ = WORKLOADS[kind if kind != 'ekf_low' else 'ekf']
             others[tag] = measure(kind, mode_o, Bo, To, args.other_steps, 1, {})
         crlb = measure_crlb(262144, 500, args.other_steps)
-        tsplit = measure_time_split(args.other_steps) if world == 1 else None
+        tsplit = measure_time_split(args.other_steps)          # (every rank runs it -- the shard sizes ARE an 8-GPU run's -- rank 0 reports its own)
 
     if use_dist:
         dist.destroy_process_group()       # ranks other than 0 are done: rank 0 times the host CPU with nobody spinning beside it
