@@ -51,7 +51,7 @@ class CgpInit(C.Structure):
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
-           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split')
+           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums')
 
 _lib = None
 _lock = threading.Lock()
@@ -91,6 +91,8 @@ def load_library():
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_gaussian_expectation_fn.restype = C.c_int
         lib.cgp_gaussian_expectation_fn.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
+        lib.cgp_squared_error_sums.restype = C.c_int
+        lib.cgp_squared_error_sums.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _vp, _vp]
         lib.cgp_debug_math.restype = C.c_int
         lib.cgp_debug_math.argtypes = [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp]
         lib.cgp_simulate.restype = C.c_int
@@ -544,3 +546,27 @@ def debug_counters(reset=True, device_index=None):
     out = (C.c_uint64 * 8)()
     _check(ctx, load_library().cgp_debug_counters(ctx, out, 1 if reset else 0, _stream()), 'cgp_debug_counters')
     return {k: int(out[i]) for i, k in enumerate(REGIME_COUNTERS)}
+
+
+def squared_error_sums(a, r, comps, sums=None):
+    """sums[c][0][t] += sum_b (a - r)[b, t, comps[c]]^2, sums[c][1][t] += sum_b of its square (include/chirpgp_hip.h:
+    cgp_squared_error_sums) -- the per-step error statistics of the reference's CRLB jobs, reduced on the device.  a, r: (B, T, d)
+    device tensors; returns the (n, 2, T) tensor of sums (a fresh zeroed one unless `sums` is passed to accumulate into)."""
+    torch = _torch()
+    a, r = dev(a), dev(r)
+    if a.shape != r.shape or a.ndim != 3:
+        raise ValueError(f'a and r must both be (B, T, d); got {tuple(a.shape)}, {tuple(r.shape)}')
+    B, T, d = (int(v) for v in a.shape)
+    comps = [int(c) for c in comps]
+    with torch.cuda.device(a.device):
+        ctx = context(a.device.index)
+        if sums is None:
+            sums = torch.zeros((len(comps), 2, T), dtype=torch.float64, device=a.device)
+        elif tuple(sums.shape) != (len(comps), 2, T) or not sums.is_contiguous():
+            raise ValueError(f'sums must be a contiguous ({len(comps)}, 2, {T}) tensor')
+        arr = (C.c_int32 * len(comps))(*comps)
+        for lo in range(0, max(B, 1), 65535 * 512):                    # the kernel's grid limit: slabs of 512 trials
+            hi = min(B, lo + 65535 * 512)
+            rc = load_library().cgp_squared_error_sums(ctx, _ptr(a[lo:hi]), _ptr(r[lo:hi]), hi - lo, T, d, arr, len(comps), _ptr(sums), _stream())
+            _check(ctx, rc, 'cgp_squared_error_sums')
+    return sums

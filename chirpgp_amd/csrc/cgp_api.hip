@@ -95,6 +95,43 @@ __global__ void __launch_bounds__(256) gaussian_expectation_kernel(const double*
     }
 }
 
+// cgp_squared_error_sums: lane = time step (64 consecutive steps of a trial are one contiguous 64 d doubles), the four wavefronts of a
+// workgroup take every fourth trial of its slab of 512; per-thread sums, then LDS across the wavefronts and one float64 atomic per
+// (component, moment, step) and slab.  Reads every byte of a and r once: HBM-bound.
+struct ErrComps { int c[8]; int n; };
+__global__ void __launch_bounds__(256) squared_error_sums_kernel(const double* __restrict__ a, const double* __restrict__ r, int64_t B, int64_t T, int d,
+                                                                 ErrComps comps, double* __restrict__ sums) {
+    __shared__ double part[4][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t b0 = (int64_t)blockIdx.y * 512, b1 = (b0 + 512 < B) ? b0 + 512 : B;
+    double acc[16];
+    CGP_UNROLL for (int k = 0; k < 16; k++) acc[k] = 0.0;
+    if (t < T) {
+        for (int64_t b = b0 + w; b < b1; b += 4) {
+            const double* __restrict__ pa = a + (b * T + t) * d;
+            const double* __restrict__ pr = r + (b * T + t) * d;
+            CGP_UNROLL for (int c = 0; c < 8; c++) {
+                if (c < comps.n) {
+                    const double e = pa[comps.c[c]] - pr[comps.c[c]], e2 = e * e;
+                    acc[2 * c] += e2;
+                    acc[2 * c + 1] = fma(e2, e2, acc[2 * c + 1]);
+                }
+            }
+        }
+    }
+    CGP_UNROLL for (int k = 0; k < 16; k++) part[w][k][lane] = acc[k];
+    __syncthreads();
+    if (w == 0 && t < T) {
+        CGP_UNROLL for (int k = 0; k < 16; k++) {
+            if (k < 2 * comps.n) {
+                const double v = (part[0][k][lane] + part[1][k][lane]) + (part[2][k][lane] + part[3][k][lane]);
+                atomicAdd(sums + (int64_t)k * T + t, v);          // sums[c][m][t], k = 2 c + m
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* __restrict__ x, int64_t n,
                                                          double* __restrict__ o0, double* __restrict__ o1) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -477,6 +514,26 @@ int cgp_gaussian_expectation_fn(cgp_ctx* ctx, int func, const double* ms, const 
     case CGP_FN_SQUARE:   hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_SQUARE>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
     default:              hipLaunchKernelGGL(gaussian_expectation_kernel<CGP_FN_SOFTPLUS>, dim3(grid), dim3(256), 0, st, ms, sd, n, in_stride, xi, w, order, out); break;
     }
+    return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
+}
+
+int cgp_squared_error_sums(cgp_ctx* ctx, const double* a, const double* r, int64_t B, int64_t T, int32_t d,
+                           const int32_t* comps, int32_t n, double* sums, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (B < 0 || T < 0 || d < 1 || n < 1 || n > 8) return fail(ctx, CGP_E_ARG, "bad B, T, d or n (1 <= n <= 8)");
+    if (B == 0 || T == 0) return CGP_OK;
+    if (!a || !r || !comps || !sums) return fail(ctx, CGP_E_ARG, "NULL pointer");
+    ErrComps ec;
+    ec.n = n;
+    for (int i = 0; i < 8; i++) {
+        ec.c[i] = i < n ? comps[i] : 0;
+        if (ec.c[i] < 0 || ec.c[i] >= d) return fail(ctx, CGP_E_ARG, "component outside 0..d-1");
+    }
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    const int64_t slabs = (B + 511) / 512;
+    if (slabs > 65535) return fail(ctx, CGP_E_ARG, "more than 65535 x 512 trials in one call: reduce chunk by chunk");
+    hipLaunchKernelGGL(squared_error_sums_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, a, r, B, T, (int)d, ec, sums);
     return hipGetLastError() == hipSuccess ? CGP_OK : fail(ctx, CGP_E_HIP, "kernel launch failed");
 }
 

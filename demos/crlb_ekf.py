@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from chirpgp_amd import filters_smoothers as fs, tools                       # noqa: E402
+from chirpgp_amd import filters_smoothers as fs, tools, _engine              # noqa: E402
 from chirpgp_amd.models import model_chirp, disc_chirp_lcd                    # noqa: E402
 from chirpgp_amd.parallel import shard_bounds                                 # noqa: E402
 
@@ -55,7 +55,7 @@ def main(argv=None):
         def filtering(yss):
             return fs.ekf(m_and_cov, H, args.Xi, m0, P0, dt, yss, want=(True, False, False))
     lo, hi = shard_bounds(args.num_mcs, rank, world)
-    sums = torch.zeros((4, T), dtype=torch.float64, device='cuda')        # sum e_chirp, e_chirp^2, e_v, e_v^2 per step
+    sums = torch.zeros((2, 2, T), dtype=torch.float64, device='cuda')     # [chirp | v][sum e, sum e^2][step], e = squared error
     # warm-up: library load, code-object load and the first allocations are one-off costs of the process
     _, yw = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, 8, args.seed, batch=64)
     filtering(yw)
@@ -65,19 +65,17 @@ def main(argv=None):
         n = min(args.chunk, hi - first)
         xss, yss = tools.simulate_measurements(m_and_cov, H, args.Xi, m0, P0, dt, T, args.seed, batch=n, trial0=first)
         mfs, _, _ = filtering(yss)
-        e_chirp = (mfs[:, :, 1] - xss[:, :, 1]) ** 2
-        e_v = (mfs[:, :, 2] - xss[:, :, 2]) ** 2
-        sums += torch.stack([e_chirp.sum(0), (e_chirp ** 2).sum(0), e_v.sum(0), (e_v ** 2).sum(0)])
-        del xss, yss, mfs, e_chirp, e_v
+        _engine.squared_error_sums(mfs, xss, (1, 2), sums)               # reduced over the trials on the device: no torch arithmetic
+        del xss, yss, mfs
     if world > 1:
         dist.all_reduce(sums)
     torch.cuda.synchronize()
     t1 = time.time()
     if rank == 0:
         n = args.num_mcs
-        mean_c, mean_v = sums[0] / n, sums[2] / n
-        std_c = (sums[1] / n - mean_c ** 2).clamp_min(0).sqrt()
-        std_v = (sums[3] / n - mean_v ** 2).clamp_min(0).sqrt()
+        mean_c, mean_v = sums[0, 0] / n, sums[1, 0] / n
+        std_c = (sums[0, 1] / n - mean_c ** 2).clamp_min(0).sqrt()
+        std_v = (sums[1, 1] / n - mean_v ** 2).clamp_min(0).sqrt()
         print(f'{n} trials x {T} steps on {world} GPU(s): simulate + {args.filter.upper()} + error statistics {t1 - t0:.3f} s')
         if args.save:
             import numpy as np

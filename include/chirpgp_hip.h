@@ -222,6 +222,14 @@ int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, i
 int cgp_gaussian_expectation_fn(cgp_ctx* ctx, int func, const double* ms, const double* sd, int64_t n, int64_t in_stride,
                                 const double* xi, const double* w, int32_t order, double* out, void* stream);
 
+/* Per-step squared-error statistics over the trial axis -- what the reference's Monte-Carlo jobs reduce their runs to
+ * (tetralith/jobs/crlb_ekf.py:82-89: mean and standard deviation over 10^6 trials of (mfs - xs)^2 per time step):
+ *     e = (a[b][t][comps[c]] - r[b][t][comps[c]])^2,     sums[c][0][t] += sum_b e,     sums[c][1][t] += sum_b e^2
+ * a, r: [B][T][d] (device); comps: n <= 8 component numbers (HOST array); sums: [n][2][T] (device), ACCUMULATED into -- zero it
+ * before the first chunk, call once per chunk of trials (and all-reduce it over ranks: 2 n T doubles). */
+int cgp_squared_error_sums(cgp_ctx* ctx, const double* a, const double* r, int64_t B, int64_t T, int32_t d,
+                           const int32_t* comps, int32_t n, double* sums, void* stream);
+
 /* ---- input side: Monte-Carlo data generated in HBM ------------------------------------
  * Random numbers are counter-based (Philox4x32-10 keyed by `seed`, counter = (global trial number, index, stream),
  * Box-Muller), so a trial's draws do not depend on B, on the launch shape or on how the batch is sharded over ranks:

@@ -178,3 +178,25 @@ def test_reference_crlb_monte_carlo_statement():
         P = Pp - np.outer(K, K) * (H @ Pp @ H + Xi)
         want.append(P)
     npt.assert_allclose(Pf, np.array(want), rtol=1e-12, atol=1e-14)
+
+
+def test_squared_error_sums_on_the_device():
+    """cgp_squared_error_sums -- the per-step error statistics the CRLB jobs reduce 10^6 trials to (tetralith/jobs/crlb_ekf.py:82-89) --
+    against NumPy: ragged B (not a multiple of the 512-trial slab) and T (not a multiple of 64), accumulation over two chunks."""
+    import numpy as np
+    import torch
+    from chirpgp_amd import _engine
+    rng = np.random.default_rng(9)
+    B, T, d = 1300, 150, 4
+    a, r = rng.standard_normal((B, T, d)), rng.standard_normal((B, T, d))
+    e = (a - r) ** 2
+    want = np.stack([np.stack([e[:, :, c].sum(0), (e[:, :, c] ** 2).sum(0)]) for c in (1, 2)])
+    at, rt = torch.from_numpy(a).cuda(), torch.from_numpy(r).cuda()
+    got = _engine.squared_error_sums(at, rt, (1, 2))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12)
+    two = _engine.squared_error_sums(at[:700], rt[:700], (1, 2))
+    _engine.squared_error_sums(at[700:], rt[700:], (1, 2), two)
+    np.testing.assert_allclose(two.cpu().numpy(), want, rtol=1e-12)
+    import pytest
+    with pytest.raises(RuntimeError):
+        _engine.squared_error_sums(at, rt, (1, 4))
