@@ -96,7 +96,7 @@ def test_small_batch_time_split_is_faster():
     assert err < 1e-6 and worst <= 5 * err and t_split < 0.6 * t_seq
 
 
-@pytest.mark.parametrize('method', ['ekf', 'cd_sgp_filter', 'sgp_filter_d6', 'sgp_filter_d8', 'ekf_general_H'])
+@pytest.mark.parametrize('method', ['ekf', 'cd_sgp_filter', 'sgp_filter_d6', 'sgp_filter_d8', 'ekf_general_H', 'lascala_ekf', 'lascala_sgp'])
 def test_the_other_kernels_that_know_segments(method):
     """ekf (the bench kernel, also with a measurement vector that is not e_1), cd_sgp_filter (RK4) at d = 4, and the tile-layout
     sigma-point filter at d = 6 / 8: split into four segments with 3008 steps of burn-in, against their own sequential launch."""
@@ -105,11 +105,13 @@ def test_the_other_kernels_that_know_segments(method):
     if method.startswith('sgp_filter_d'):
         nh = 2 if method.endswith('6') else 3
         c = cs.harmonic_case(T=3000, seed=90 + nh, nh=nh)
+    elif method.startswith('lascala'):
+        c = cs.lascala_case(T=3000, seed=95)
     else:
         c = cs.chirp_case(T=3000, seed=90)
     ys = np.tile(c.ys, 2)[None, :T] + 0.05 * np.random.default_rng(7).standard_normal((B, T))
     H = c.H if method != 'ekf_general_H' else np.array([0.2, 1.0, 0.0, 0.1])
-    if method in ('ekf', 'ekf_general_H'):
+    if method in ('ekf', 'ekf_general_H', 'lascala_ekf'):
         run = lambda **kw: fs.ekf(c.disc, H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
     elif method == 'cd_sgp_filter':
         run = lambda **kw: fs.cd_sgp_filter(c.drift, c.disp(None), c.sgps, H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
