@@ -131,7 +131,8 @@ def test_the_other_kernels_that_know_segments(method):
         safe = run(time_split=(4, 3008), split_tol=1e-5)
         assert all(np.array_equal(a, b) for a, b in zip(safe, seq))
         return
-    assert 0 < err < 1e-4
+    # (the La Scala model forgets more slowly: 1e-4 after 3008 steps where the chirp model is at 4e-8 -- the junctions say so)
+    assert 0 < err < (1e-3 if method.startswith('lascala') else 1e-4)
     last = run(time_split=(4, 3008), nll_final_only=True, want=(False, False, True))[2]
     seq_last = run(nll_final_only=True, want=(False, False, True))[2]
     assert _rel(last, seq_last) <= 5 * err + 1e-12
