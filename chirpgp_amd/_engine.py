@@ -51,7 +51,8 @@ class CgpInit(C.Structure):
 
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
-           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums')
+           'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
+           'cgp_reserve_workspace')
 
 _lib = None
 _lock = threading.Lock()
@@ -106,6 +107,8 @@ def load_library():
         lib.cgp_debug_counters.restype = C.c_int
         lib.cgp_debug_counters.argtypes = [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]
         lib.cgp_debug_philox.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, _vp]
+        lib.cgp_reserve_workspace.restype = C.c_int
+        lib.cgp_reserve_workspace.argtypes = [_vp, C.c_size_t, _vp]
         _lib = lib
         return lib
 
@@ -314,11 +317,24 @@ def _out(t, like_numpy, squeeze):
     return t.cpu().numpy() if like_numpy else t
 
 
-last_junction_error = None      # device tensor [B] of the most recent time-split filter call (cgp_filter_time_split)
+class _PerThread(threading.local):
+    junction_error = None
+
+
+_per_thread = _PerThread()
+
+
+def __getattr__(name):
+    # `_engine.last_junction_error`: device tensor [B] of the CALLING THREAD's most recent time-split filter call
+    # (cgp_filter_time_split), None when that call fell back to the sequential filter (split_tol) -- the rows returned are then
+    # not the split run's.  Prefer `return_junction_error=True`, which hands the tensor back with the results.
+    if name == 'last_junction_error':
+        return _per_thread.junction_error
+    raise AttributeError(name)
 
 
 def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, flags=0, want=(True, True, True),
-               trials_per_record=None, record_index=None, time_split=None, split_tol=None):
+               trials_per_record=None, record_index=None, time_split=None, split_tol=None, return_junction_error=False):
     """cgp_filter with NumPy / torch marshalling.  ys (T,) or (B, T) -> (mfs, Pfs, nll) with matching leading axes.
 
     Shared records (include/chirpgp_hip.h, cgp_filter): with ``trials_per_record = k`` every record of ys -- (T,) or (R, T) --
@@ -327,10 +343,11 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
     record is read from ONE copy in HBM: nothing is replicated.
 
     ``time_split = (segments, burn_in)``: the time-split filter with burn-in (include/chirpgp_hip.h, cgp_filter_time_split) -- several
-    wavefronts per trial for batches that leave most SIMDs idle; the per-trial junction mismatch is left in
-    ``_engine.last_junction_error`` (device tensor), and with ``split_tol`` the call checks it (one device synchronisation) and
-    falls back to the sequential filter if any junction is further off."""
-    global last_junction_error
+    wavefronts per trial for batches that leave most SIMDs idle.  With ``return_junction_error=True`` the per-trial junction mismatch
+    of THIS call comes back as a fourth output (device tensor [B]; None if the results are the sequential filter's); it is also
+    left, per calling thread, in ``_engine.last_junction_error``.  With ``split_tol`` the call checks it (one device
+    synchronisation) and falls back to the sequential filter if any junction is further off."""
+    junction = None
     torch = _torch()
     like_numpy = not _is_torch(ys)
     ys_d = dev(ys)
@@ -375,15 +392,17 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
                                                                     C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
                                                                     _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, segments, burn_in, _ptr(err), st))
             _check(ctx, rc, 'cgp_filter_time_split')
-            last_junction_error = err
+            junction = err
             if split_tol is not None and not bool((err <= float(split_tol)).all()):      # NaN / inf / too far: the sequential filter
-                time_split = None
+                time_split, junction = None, None
         if time_split is None:
             rc = _timed('filter', lambda: lib.cgp_filter(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
                                                          C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d), B, T,
                                                          _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, st))
             _check(ctx, rc, 'cgp_filter')
-        return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
+        _per_thread.junction_error = junction
+        res = tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
+        return res + (junction,) if return_junction_error else res
 
 
 def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
@@ -533,6 +552,13 @@ DBG_WALK_SEGMENTS, DBG_COUNT_REGIMES = 1, 2
 REGIME_COUNTERS = ('high', 'common', 'redone', 'checked', 'high_left')
 
 
+def reserve_workspace(nbytes, device_index=None):
+    """Size the current stream's scratch buffer of the time-split launches ahead of time (include/chirpgp_hip.h:
+    cgp_reserve_workspace) -- needed only before capturing such launches into a graph."""
+    ctx = context(device_index)
+    _check(ctx, load_library().cgp_reserve_workspace(ctx, int(nbytes), _stream()), 'cgp_reserve_workspace')
+
+
 def debug_set(key, value, device_index=None):
     """Per-context tuning / measurement knob (include/chirpgp_hip.h: cgp_debug_set)."""
     ctx = context(device_index)
@@ -553,7 +579,10 @@ def squared_error_sums(a, r, comps, sums=None):
     cgp_squared_error_sums) -- the per-step error statistics of the reference's CRLB jobs, reduced on the device.  a, r: (B, T, d)
     device tensors; returns the (n, 2, T) tensor of sums (a fresh zeroed one unless `sums` is passed to accumulate into)."""
     torch = _torch()
-    a, r = dev(a), dev(r)
+    a = dev(a)
+    r = dev(r, a.device.index)
+    if r.device != a.device:
+        r = r.to(a.device)
     if a.shape != r.shape or a.ndim != 3:
         raise ValueError(f'a and r must both be (B, T, d); got {tuple(a.shape)}, {tuple(r.shape)}')
     B, T, d = (int(v) for v in a.shape)
@@ -562,8 +591,10 @@ def squared_error_sums(a, r, comps, sums=None):
         ctx = context(a.device.index)
         if sums is None:
             sums = torch.zeros((len(comps), 2, T), dtype=torch.float64, device=a.device)
-        elif tuple(sums.shape) != (len(comps), 2, T) or not sums.is_contiguous():
-            raise ValueError(f'sums must be a contiguous ({len(comps)}, 2, {T}) tensor')
+        elif (not _is_torch(sums) or tuple(sums.shape) != (len(comps), 2, T) or not sums.is_contiguous() or sums.dtype != torch.float64
+              or not sums.is_cuda or sums.device != a.device):
+            # the kernel adds float64 atomically through the raw pointer: anything else is a wrong result or a fault
+            raise ValueError(f'sums must be a contiguous float64 ({len(comps)}, 2, {T}) tensor on {a.device}')
         arr = (C.c_int32 * len(comps))(*comps)
         for lo in range(0, max(B, 1), 65535 * 512):                    # the kernel's grid limit: slabs of 512 trials
             hi = min(B, lo + 65535 * 512)

@@ -234,11 +234,21 @@ int cgp_create(cgp_ctx** out, int device) {
 
 void cgp_destroy(cgp_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->counters_mem) {
+    {
         DeviceScope on_device(ctx->device);
-        (void)hipFree(ctx->counters_mem);
+        if (ctx->counters_mem) (void)hipFree(ctx->counters_mem);
+        for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);      // hipFree waits for the device: no launch still uses them
     }
     delete ctx;
+}
+
+int cgp_reserve_workspace(cgp_ctx* ctx, size_t bytes, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    if (bytes == 0) return CGP_OK;
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    if (!ctx_workspace(ctx, (hipStream_t)stream, bytes)) return fail(ctx, CGP_E_HIP, "workspace allocation failed");
+    return CGP_OK;
 }
 
 int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value) {
@@ -334,8 +344,15 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
         io.segs = (int)segs; io.seg_len = seg_len; io.burn_in = (burn_in + 63) / 64 * 64;
         io.seg_stride = 2 * (model->d + model->d * model->d) + 1;
         if (segs > 1) {
-            if (hipMallocAsync((void**)&seg_ws, sizeof(double) * (size_t)io.seg_stride * (size_t)B * (size_t)segs, (hipStream_t)stream) != hipSuccess)
-                return fail(ctx, CGP_E_HIP, "hipMallocAsync of the segment records failed");
+            // (a set too large for the LDS stage runs one lane per trial whatever the flags say -- choose_wave -- and those kernels
+            // know no segments: refuse instead of reading records nobody wrote)
+            if (sig && SigmaSet::stage_bytes(sigma->s, sigma->d, sigma->n_groups, sigma->group_start != nullptr) > (size_t)kSigLdsMaxBytes)
+                return fail(ctx, CGP_E_UNSUPPORTED, "time-split filters need a sigma-point set that fits the LDS stage of the one-wavefront-per-trial kernels");
+            const size_t seg_doubles = (size_t)io.seg_stride * (size_t)B * (size_t)segs;
+            seg_ws = (double*)ctx_workspace(ctx, (hipStream_t)stream, sizeof(double) * seg_doubles);
+            if (!seg_ws) return fail(ctx, CGP_E_HIP, "no workspace for the segment records (allocation failed, or the buffer would grow inside a graph capture: cgp_reserve_workspace first)");
+            // NaN-filled: a kernel that ignored the segments would show as junction_err = inf, not as garbage
+            if (hipMemsetAsync(seg_ws, 0xFF, sizeof(double) * seg_doubles, (hipStream_t)stream) != hipSuccess) return fail(ctx, CGP_E_HIP, "hipMemsetAsync of the segment records failed");
             io.seg_state = seg_ws;
             flags |= CGP_WAVE_PER_TRIAL;
             io.flags = flags;
@@ -355,6 +372,7 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     else if (method == CGP_F_CD_EKF && sde4 && mfma) limit = {4, 1};
     else if (method == CGP_F_CD_SGP && sde4 && mfma) limit = {48, 1};
     const bool wave = choose_wave(ctx, B, flags, limit, sig ? sigma : nullptr);
+    if (split && io.segs > 1 && !wave) return fail(ctx, CGP_E_UNSUPPORTED, "time-split filters run one wavefront per trial only");
     hipStream_t st = (hipStream_t)stream;
     switch (model->model_id) {
     case CGP_M_LINEAR:
@@ -372,6 +390,8 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
             rc = dispatch_filter_coop8_ekf(model->n_harm, io, ma, st);
         else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, io.T, ma))
             rc = dispatch_filter_coop8_sgp(model->n_harm, io, ma, st);
+        else if (method == CGP_F_EKF && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_filter_fits(io))
+            rc = dispatch_filter_lane4(method, io, ma, st);                                      // large batches: cgp_lane4.hpp
         else rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st);
         break;
     case CGP_M_LINEAR_SDE:   rc = dispatch_filter_sde_linear(method, model->d, wave, io, ma, st); break;
@@ -388,7 +408,6 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
             if (io.segs > 1) hipLaunchKernelGGL(filter_split_fixup_kernel, dim3((unsigned)B), dim3(64), 0, st, io, model->d, junction_err);
             else if (hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, st) != hipSuccess) rc = CGP_E_HIP;
         }
-        if (seg_ws && hipFreeAsync(seg_ws, st) != hipSuccess && rc == CGP_OK) rc = CGP_E_HIP;
     }
     if (rc == CGP_E_UNSUPPORTED) return fail(ctx, rc, "this (method, model, dimension) combination is not compiled in");
     if (rc == CGP_E_HIP) return fail(ctx, rc, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
@@ -431,6 +450,7 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
 
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
+    io.host_ctx = ctx;
     // Time-split form of the discrete wave-per-trial smoothers: when the batch leaves two thirds of the SIMDs idle (or on
     // request).  cgp_debug_set(CGP_DBG_WALK_SEGMENTS) caps the number of segments of this context (tuning aid).
     io.num_cus = ctx->num_cus;

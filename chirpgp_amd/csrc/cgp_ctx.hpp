@@ -1,6 +1,8 @@
 // cgp_ctx.hpp -- the opaque context of include/chirpgp_hip.h, shared by the translation units that implement the C-ABI.
 #pragma once
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <hip/hip_runtime.h>
 
 struct cgp_ctx {
@@ -9,6 +11,12 @@ struct cgp_ctx {
     int walk_segments = 0;                       // cgp_debug_set(CGP_DBG_WALK_SEGMENTS): 0 = choose, 1 = off, n = cap
     unsigned long long* counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): eight device counters, NULL = off
     unsigned long long* counters_mem = nullptr;  // the allocation (kept while counting is switched off)
+    // Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers):
+    // ONE buffer per stream, kept by the context and grown on demand (cgp::ctx_workspace).  Work on one stream is ordered, so two
+    // launches never hold the same buffer at once; threads that share a context use different streams or serialise themselves.
+    struct Workspace { void* p = nullptr; size_t bytes = 0; };
+    std::mutex ws_mutex;
+    std::unordered_map<hipStream_t, Workspace> ws;
 };
 
 namespace cgp {
@@ -25,6 +33,25 @@ inline int fail(cgp_ctx* ctx, int code, const std::string& msg) {
     e.ctx = ctx;
     e.msg = msg;
     return code;
+}
+
+// The stream's scratch buffer of at least `bytes` bytes, or NULL (allocation failed, or the buffer would have to grow while the
+// stream is being captured into a graph: size it first with cgp_reserve_workspace).  Growing waits for the stream's queued work --
+// which may still use the old buffer -- and frees it; a buffer that is large enough is returned without any HIP call.
+inline void* ctx_workspace(cgp_ctx* ctx, hipStream_t st, size_t bytes) {
+    if (!ctx) return nullptr;
+    std::lock_guard<std::mutex> lock(ctx->ws_mutex);
+    cgp_ctx::Workspace& w = ctx->ws[st];
+    if (w.bytes >= bytes && w.p) return w.p;
+    if (w.p) {
+        if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        (void)hipFree(w.p);
+        w.p = nullptr; w.bytes = 0;
+    }
+    const size_t want = (bytes + (size_t)0xFFFFF) & ~(size_t)0xFFFFF;      // whole MiB: small changes of (B, segments) do not reallocate
+    if (hipMalloc(&w.p, want) != hipSuccess) { (void)hipGetLastError(); w.p = nullptr; return nullptr; }
+    w.bytes = want;
+    return w.p;
 }
 
 // Every entry point runs on the context's device and leaves the calling thread's current device as it found it

@@ -1,0 +1,14 @@
+// Large batches at d = 4, one lane per trial (cgp_lane4.hpp): the chirp / La Scala LCD models.
+#define CGP_COOP4_HELPERS_ONLY      // OobWindow, not a second copy of ekf4_coop_kernel
+#include "cgp_dispatch.hpp"
+#include "cgp_lane4.hpp"
+namespace cgp {
+int dispatch_filter_lane4(int method, const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
+    using DM = HarmonicLCD<1>;
+    using Meas = LinearMeasurement<4>;
+    switch (method) {
+    case CGP_F_EKF: return hip_rc(launch_lane4_filter<EkfPredict<DM, false>, Meas>(io, ma, st));
+    default: return CGP_E_UNSUPPORTED;
+    }
+}
+}  // namespace cgp

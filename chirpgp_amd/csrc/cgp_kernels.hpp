@@ -9,6 +9,7 @@
 //   WAVE  = false : grid = ceil(B / 64).  One lane per trial (large batches).
 #pragma once
 #include "cgp_steps.hpp"
+#include "cgp_ctx.hpp"
 #include "../../include/chirpgp_hip.h"
 
 namespace cgp {
@@ -81,6 +82,7 @@ struct SmootherIO {
     int num_cus = 256;
     int tiles_per_seg = 0;
     double* __restrict__ ws = nullptr;
+    cgp_ctx* host_ctx = nullptr;  // host side only: the context whose per-stream workspace (cgp::ctx_workspace) serves `ws`
 };
 
 // Dynamic LDS (sized by the launch): the staged sigma-point set.  The static LDS in front of it (the 17 152-byte
@@ -574,6 +576,13 @@ int dispatch_smoother_mfma4_cdeks(const SmootherIO&, const ModelArgs&, hipStream
 // the matrix-core EKF addresses a trial's outputs through 2 GiB buffer windows (cgp_mfma4.hpp)
 inline bool ekf4_mfma_fits(const FilterIO& io) { return io.T * 128 <= 0x7FFFFF00ll; }
 int dispatch_filter_coop4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
+// d = 4, one lane per trial, large batches (cgp_lane4.hpp).  The launches it takes: dense or shared records whose rows start on
+// 16-byte boundaries (its LDS-DMA moves 16-byte pieces), an even number of steps, output windows of 64 trials within the 2 GiB a
+// raw buffer addresses, no time-split segments.
+inline bool lane4_filter_fits(const FilterIO& io) {
+    return io.segs <= 1 && io.T >= 2 && io.T % 2 == 0 && io.ys_stride % 2 == 0 && ((uintptr_t)io.ys & 15) == 0 && io.T * 128 * 64 <= 0x7FFFFF00ll;
+}
+int dispatch_filter_lane4(int method, const FilterIO&, const ModelArgs&, hipStream_t);
 // d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
 bool coop8_filter_sgp_ok(int n_harm, int64_t T, const ModelArgs&);
 bool walk4_smoother_fits(int64_t T, const ModelArgs&);

@@ -1,0 +1,242 @@
+// cgp_lane4.hpp -- d = 4 filters for LARGE batches: one lane per trial, 64 trials per wavefront, built around the memory system.
+//
+// The reference's only batched use of the filters is its CRLB job (tetralith/jobs/crlb_ekf.py:59-79, crlb_ghf.py:71-75): 10^4 ...
+// 10^6 trials x 500 steps.  There every SIMD holds many trials, a trial-step costs ~ 5 vector instructions per lane and the launch
+// is bound by its 176 bytes per trial-step -- IF the wavefront never waits for its own stores.  On gfx950 loads,
+// stores and LDS-DMA retire through ONE in-order counter (vmcnt): the data of a load is usable only when every OLDER store has
+// been acknowledged by memory, i.e. a load whose result is needed soon after the step's output stores costs a full drain of the
+// store queue (several microseconds when HBM is saturated).  Round 4's lane kernel (cgp_kernels.hpp: filter_kernel, STAGED) did that
+// twice: the measurements of a 16-step block were loaded and consumed at once, and -- capped at 256 registers -- it reloaded 34
+// spilled values per step from scratch (profiles/r04_ekf_large_*: 4.0 TB/s with 1.12 x the algorithmic traffic).  This kernel:
+//   * measurements: LDS-DMA (global_load_lds_dwordx4: no registers) of the NEXT block's 64 x 16 doubles while the current block
+//     runs; the wait at the block boundary is a counted vmcnt(N), N = the stores issued since, so no store is waited for;
+//   * no spill: the means of four steps (one 128-byte line) wait in registers with compile-time slots, the covariance leaves
+//     packed (10 doubles per lane) through a 6 KB LDS transpose, and nothing else is held across steps;
+//   * every global store instruction writes whole 128-byte lines (8 trials x 128 B): covariance rows per step, means per four
+//     steps, cumulative NLL per 16 steps (written into the consumed measurements' LDS slots);
+//   * outputs are addressed as raw-buffer windows over the wavefront's 64 trials: lanes past the batch are dropped by the range
+//     check, so the step has no exec-masked store.
+// tools/ubench/store_pattern.hip issues exactly this access pattern without arithmetic: 5.0 - 5.6 TB/s on MI355X, the roof here.
+#pragma once
+#include "cgp_kernels.hpp"
+#include "cgp_coop4.hpp"
+
+namespace cgp {
+
+using LdsDouble2Ptr = __attribute__((address_space(3))) double2_t*;
+using LdsDoublePtr = __attribute__((address_space(3))) double*;
+
+struct Lane4 {
+    static constexpr int KB = 16;                  // steps per block: 16 x 8 B = one line of measurements / NLL per trial
+    static constexpr int YDOUBLES = 64 * KB;       // one block, laid out [piece 0..7][trial 0..63][2] (what the LDS-DMA writes)
+    static constexpr int PITCH_P = 12;             // packed covariance row (10 doubles) + 2: conflict-free 16-byte row writes
+    static constexpr int PITCH_M = 18;             // a line of means (4 steps x 4) + 2
+    static constexpr int TILE = 64 * PITCH_M;      // doubles; the covariance rows (64 x 12) use the front of it
+};
+
+// 64 trials x 16 steps of measurements into LDS: instruction pc moves, for every lane's trial, the 16 bytes of steps t0 + 2 pc,
+// t0 + 2 pc + 1 to lds_base + 1024 pc + 16 lane.  Pieces past the end of the record re-read its last piece (never consumed).
+// M0 is the compiler's: saved, set and restored inside the statement (cdna_hip_programming.md 5.7).
+CGP_DEV void lane4_dma_y(unsigned lds_base, const double* __restrict__ rec, int64_t t0, int64_t T) {
+    CGP_UNROLL for (int pc = 0; pc < 8; pc++) {
+        int64_t e = t0 + 2 * pc;
+        if (e + 2 > T) e = T - 2;
+        const double* src = rec + e;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + pc * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+// Wait until all but the N youngest vector-memory operations of this wavefront are done (N a compile-time constant).
+template <int N> CGP_DEV void lane4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+// WHOLE LINES ONLY.  tools/ubench/store_pattern.hip, same bytes: 4.7 ms when every store instruction fills 128-byte lines, 6.1 - 6.3 ms
+// when the 8-byte NLL stream alone leaves in aligned 64-byte halves or in 128-byte chunks that straddle two lines (a record of T = 500
+// steps starts 32, 64 or 96 bytes into a line for three trials out of four), 7.7 ms with the means in 32-byte pieces.  So the blocks of
+// a trial are cut where ITS rows cross line boundaries: trial b's rows start (b T mod 16) steps into a line, and a wavefront takes 64
+// trials of the SAME phase -- every `period`-th trial, period = 16 / gcd(T, 16) -- runs (16 - phase) mod 16 head steps row by row and
+// from there on blocks of 16 steps whose measurement, NLL and mean chunks are whole lines (base pointers on line boundaries assumed:
+// torch allocations are; any other base only costs the partial lines back).  Workgroup (g, r) = (blockIdx / period, blockIdx mod
+// period) takes the trials 64 period g + r + period l, lane l.
+template <class Pred, class Meas>
+__global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs ma, int period) {
+    static_assert(Pred::D == 4 && !Pred::WAVE, "one lane per trial, d = 4");
+    constexpr int D = 4;
+    __shared__ __attribute__((aligned(16))) double ybuf[2 * Lane4::YDOUBLES];
+    __shared__ __attribute__((aligned(16))) double tile[Lane4::TILE];
+    __shared__ double lds[Pred::USES_LDS ? kFanLdsDoubles : 1];
+    const int lane = threadIdx.x;
+    const int64_t group = (int64_t)(blockIdx.x / (unsigned)period);
+    const int64_t block_first = group * 64 * period + (int64_t)(blockIdx.x % (unsigned)period);
+    if (block_first >= io.B) return;
+    const int64_t nv = (io.B - block_first + period - 1) / period;
+    const int nvalid = nv < 64 ? (int)nv : 64;
+    int64_t trial = block_first + (int64_t)period * (lane < nvalid ? lane : nvalid - 1);      // lanes past the batch redo the last trial; the windows drop their stores
+
+    Pred pred;
+    pred.setup(ma, trial);
+    Vec<D> H, mf;
+    Sym<D> Pf;
+    if (io.H) load_vec<D>(io.H + trial * io.H_stride, H);
+    else { CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0; }
+    const double Xi = io.Xi[trial * io.Xi_stride];
+    load_vec<D>(io.m0 + trial * io.m0_stride, mf);
+    load_sym<D>(io.P0 + trial * io.P0_stride, Pf);
+
+    const int64_t T = io.T;
+    const double* __restrict__ rec = io.record(trial);
+    const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
+    const bool want_nll = io.nll != nullptr, nll_rows = want_nll && !nll_final;
+    const bool want_m = io.mfs != nullptr, want_P = io.Pfs != nullptr;
+
+    // output windows over this wavefront's trials; per-lane byte offsets of (trial 8 i + sub, 16-byte piece pc) in them
+    OobWindow wP, wM, wN;
+    const int64_t span = (int64_t)(nvalid - 1) * period + 1;         // trials from this wavefront's first to its last valid one
+    wP.init(want_P ? io.Pfs + block_first * T * 16 : nullptr, span * T * 128);
+    wM.init(want_m ? io.mfs + block_first * T * 4 : nullptr, span * T * 32);
+    wN.init(nll_rows ? io.nll + block_first * T : nullptr, span * T * 8);
+    // (eight CONSECUTIVE lanes cover one trial's 128-byte line: the memory pipeline merges neighbouring lanes' pieces into line
+    // requests -- with the trial in the low lane bits instead, every lane's 16 bytes travel alone: 6.4 against ... ms, measured)
+    const int sub = lane >> 3, pc = lane & 7;
+    const unsigned rowP = (unsigned)(T * period) * 128u, rowM = (unsigned)(T * period) * 32u, rowN = (unsigned)(T * period) * 8u;      // lane to lane
+    unsigned voffP = (unsigned)sub * rowP + (unsigned)pc * 16u;      // + 128 per step
+    unsigned voffM = (unsigned)sub * rowM + (unsigned)pc * 16u;      // + 128 per four steps
+    unsigned voffN = (unsigned)sub * rowN + (unsigned)pc * 16u;      // + 128 per block
+    // the two packed entries of piece pc of a full 4 x 4 row-major covariance row: (i, j), (i, j + 1) with i = pc / 2, j = 2 (pc % 2)
+    const int ia = (pc == 0) ? 0 : (pc == 1) ? 3 : (pc == 2) ? 1 : (pc == 3) ? 4 : (pc == 4) ? 3 : (pc == 5) ? 5 : (pc == 6) ? 6 : 8;
+    const int ib = (pc == 0) ? 1 : (pc == 1) ? 6 : (pc == 2) ? 2 : (pc == 3) ? 7 : (pc == 4) ? 4 : (pc == 5) ? 8 : (pc == 6) ? 7 : 9;
+    const double* tPa = tile + sub * Lane4::PITCH_P + ia;
+    const double* tPb = tile + sub * Lane4::PITCH_P + ib;
+    const double* tM = tile + sub * Lane4::PITCH_M + 2 * pc;
+
+    double cum = 0.0;
+    // one filtering step of this lane's trial; leaves its cumulative NLL in the consumed measurement's slot and its covariance row in HBM
+    auto step = [&](double y, double* nll_slot) __attribute__((always_inline)) {      // (not inlined, its captures live in scratch)
+        Vec<D> mp; Sym<D> Pp;
+        double S, innov;
+        pred.predict(lane, lds, mf, Pf, mp, Pp);
+        Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+        if (want_nll) {
+            cum += nll_increment(S, innov);
+            if (nll_rows) *nll_slot = cum;
+        }
+        if (want_P) {
+            double* row = tile + lane * Lane4::PITCH_P;
+            CGP_UNROLL for (int c = 0; c < 5; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(Pf.a[2 * c], Pf.a[2 * c + 1]);
+            wave_lds_fence();
+            CGP_UNROLL for (int i = 0; i < 8; i++)
+                wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)i * 8u * rowP);
+            wave_lds_fence();
+        }
+        voffP += 128u;
+    };
+
+    // up to 16 steps [ta, ta + n) with a run-time count -- the head in front of the first line boundary and the tail behind the last:
+    // same step, rows of means and NLL values one by one (partial lines: a record's first and last line are shared with its neighbours)
+    auto partial = [&](double* yb, int64_t ta, int n) __attribute__((always_inline)) {
+        for (int k = 0; k < n; k++) {
+            double* slot = yb + (k >> 1) * 128 + lane * 2 + (k & 1);
+            step(*slot, slot);
+            if (want_m) block_store_rows<D>(tile, lane, mf.v, io.mfs + (block_first * T + ta + k) * D, T * period * D, nvalid);
+        }
+        if (nll_rows) {
+            wave_lds_fence();
+            for (int i = 0; i < 16; i++) {
+                const int g = i * 64 + lane, tr = g >> 4, e = g & 15;
+                if (tr < nvalid && e < n) io.nll[(block_first + (int64_t)tr * period) * T + ta + e] = yb[(e >> 1) * 128 + tr * 2 + (e & 1)];
+            }
+            wave_lds_fence();
+        }
+        voffM += 32u * (unsigned)n;
+        voffN += 8u * (unsigned)n;
+    };
+
+    const unsigned ybase = (unsigned)(uintptr_t)(LdsDoublePtr)ybuf;
+    // vector-memory operations a full block issues after the DMA of the block that follows it (capped at the counter's 63)
+    const int block_stores = (want_P ? 128 : 0) + (want_m ? 32 : 0) + (nll_rows ? 8 : 0);
+    int64_t t = 0;
+    int cur = 0;
+    bool drained = true;                                             // the next wait is a full one (no count of the stores since the DMA)
+    lane4_dma_y(ybase, rec, 0, T);
+    {
+        const int phase = (int)((block_first * T) & 15);             // wave-uniform: period * T is a multiple of 16
+        const int64_t head = (16 - phase) & 15;
+        if (head > 0) {
+            const int n = head < T ? (int)head : (int)T;
+            lane4_wait_vm<0>();
+            if (n < T) lane4_dma_y(ybase + Lane4::YDOUBLES * 8u, rec, n, T);
+            partial(ybuf, 0, n);
+            t = n; cur = 1;
+        }
+    }
+    for (; t + Lane4::KB <= T; t += Lane4::KB) {
+        double* yb = ybuf + cur * Lane4::YDOUBLES;
+        // this block's measurements were requested a whole block ago: wait for them, not for the stores issued since
+        if (drained || block_stores < 8) lane4_wait_vm<0>();
+        else if (block_stores >= 63) lane4_wait_vm<63>();
+        else if (block_stores == 40) lane4_wait_vm<40>();
+        else if (block_stores == 32) lane4_wait_vm<32>();
+        else lane4_wait_vm<8>();
+        drained = false;
+        if (t + Lane4::KB < T) lane4_dma_y(ybase + (unsigned)(cur ^ 1) * (Lane4::YDOUBLES * 8u), rec, t + Lane4::KB, T);
+        _Pragma("unroll 1") for (int q = 0; q < 4; q++) {
+            double* yq = yb + q * 256 + lane * 2;                    // steps 4 q, 4 q + 1 | + 128: steps 4 q + 2, 4 q + 3
+            const double2 y01 = *reinterpret_cast<const double2*>(yq);
+            const double2 y23 = *reinterpret_cast<const double2*>(yq + 128);
+            double mh[16];
+            step(y01.x, yq);
+            CGP_UNROLL for (int i = 0; i < D; i++) mh[i] = mf.v[i];
+            step(y01.y, yq + 1);
+            CGP_UNROLL for (int i = 0; i < D; i++) mh[4 + i] = mf.v[i];
+            step(y23.x, yq + 128);
+            CGP_UNROLL for (int i = 0; i < D; i++) mh[8 + i] = mf.v[i];
+            step(y23.y, yq + 129);
+            CGP_UNROLL for (int i = 0; i < D; i++) mh[12 + i] = mf.v[i];
+            if (want_m) {
+                double* row = tile + lane * Lane4::PITCH_M;
+                CGP_UNROLL for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(mh[2 * c], mh[2 * c + 1]);
+                wave_lds_fence();
+                CGP_UNROLL for (int i = 0; i < 8; i++) {
+                    const double2 v = *reinterpret_cast<const double2*>(tM + i * 8 * Lane4::PITCH_M);
+                    wM.store2(v.x, v.y, voffM + (unsigned)i * 8u * rowM);
+                }
+                wave_lds_fence();
+            }
+            voffM += 128u;
+        }
+        if (nll_rows) {
+            wave_lds_fence();
+            CGP_UNROLL for (int i = 0; i < 8; i++) {
+                const double2 v = *reinterpret_cast<const double2*>(yb + pc * 128 + (8 * i + sub) * 2);
+                wN.store2(v.x, v.y, voffN + (unsigned)i * 8u * rowN);
+            }
+            wave_lds_fence();
+        }
+        voffN += 128u;
+        cur ^= 1;
+    }
+    if (t < T) {
+        lane4_wait_vm<0>();
+        partial(ybuf + cur * Lane4::YDOUBLES, t, (int)(T - t));
+    }
+    if (want_nll && nll_final && lane < nvalid) io.nll[trial] = cum;
+}
+
+// Trials of equal line phase are `period` apart: the smallest power of two with period * T a multiple of 16 (T is even: <= 8), or 1
+// (no alignment, partial lines) where 64 such trials would not fit the 2 GiB a raw-buffer window addresses.
+inline int lane4_period(int64_t T) {
+    int p = 1;
+    while ((p * T) % 16 != 0) p *= 2;
+    return (T * p * 128 * 64 <= kOobMaxBytes) ? p : 1;
+}
+template <class Pred, class Meas>
+inline hipError_t launch_lane4_filter(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    const int period = lane4_period(io.T);
+    const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+    hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
+    return hipGetLastError();
+}
+
+}  // namespace cgp

@@ -248,16 +248,15 @@ inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs
         hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
         return hipGetLastError();
     }
-    // time-split: two passes with the segments' maps in a stream-ordered scratch allocation (nothing the caller sees)
+    // time-split: two passes with the segments' maps in the context's per-stream workspace (nothing the caller sees)
     SmootherIO io = io_in;
     io.segs = segs;
     const int64_t tiles = (io.T - 1 + 63) / 64;
     io.tiles_per_seg = (int)((tiles + io.segs - 1) / io.segs);
     io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
-    void* ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, sizeof(double) * kWalkMapDoubles * (size_t)io.B * io.segs, stream);
-    if (e != hipSuccess) {               // no stream-ordered allocator here: the one-wave-per-trial form needs no scratch
-        (void)hipGetLastError();
+    void* ws = ctx_workspace(io.host_ctx, stream, sizeof(double) * kWalkMapDoubles * (size_t)io.B * io.segs);
+    hipError_t e;
+    if (!ws) {                           // no workspace (allocation failed, or growth inside a graph capture): the one-wave-per-trial form needs none
         hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
         return hipGetLastError();
     }
@@ -266,8 +265,7 @@ inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs
     hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
     hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
     e = hipGetLastError();
-    const hipError_t e2 = hipFreeAsync(ws, stream);
-    return e != hipSuccess ? e : e2;
+    return e;
 }
 
 }  // namespace cgp

@@ -38,13 +38,14 @@
 #ifndef CHIRPGP_HIP_H
 #define CHIRPGP_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define CGP_VERSION 120          /* 0.1.2: cgp_debug_set / cgp_debug_counters (per-context tuning knob, regime counters), cgp_gaussian_expectation_fn, cgp_filter_time_split */
+#define CGP_VERSION 130          /* 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -192,8 +193,12 @@ int cgp_filter(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma
  * pieces of whole 64-step chunks, and wavefront s > 0 starts `burn_in` steps BEFORE its piece from (m0, P0), writes nothing
  * until its piece begins, and carries on like the sequential filter from there.  junction_err[b] (DEVICE array, [B], required)
  * receives, per trial, the largest relative mismatch at a junction between the state a burn-in arrived at and the state the
- * previous segment ended with: every row a segment wrote is at most about that far from the sequential filter's (inf if a NaN
- * sits at a junction).  The caller picks burn_in for its model (the chirp models of the reference lose a decade per ~ 450 steps
+ * previous segment ended with (inf if a NaN sits at a junction).  It is a HEURISTIC, not a bound: the mismatch is
+ * max |difference| / max |reference| over the whole mean vector and, separately, over the covariance -- components of different
+ * scale (chirp amplitude ~ 1, frequency state ~ 7) share one denominator, so a small component can be off by more, relative to
+ * itself, than the figure says -- and segment s is compared with the end of segment s - 1, which is itself approximate, not with
+ * the sequential filter.  On the chirp models the rows a segment wrote were within 5 x the reported mismatch of the sequential
+ * filter's in every test (tests/test_gpu_filter_split.py compares them with the CPU oracle directly).  The caller picks burn_in for its model (the chirp models of the reference lose a decade per ~ 450 steps
  * after the first ~ 1000: 3000 steps for 1e-7) and checks junction_err against its own tolerance -- cgp_filter remains the
  * reference's sequential recursion.  Cumulative NLL rows are made continuous across segments by a fix-up pass.  Built for
  * sgp_filter / cd_sgp_filter / ekf on the d = 4 chirp / La Scala models and sgp_filter at d = 6 / 8 (matrix-core / tile-layout
@@ -202,6 +207,14 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
                           double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
                           int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags,
                           int64_t segments, int64_t burn_in, double* junction_err, void* stream);
+
+/* Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers) lives in
+ * ONE buffer per (context, stream), grown on demand and freed by cgp_destroy; the library allocates nothing else per call.  Growing
+ * waits for the stream -- illegal while the stream is being captured into a graph -- so a caller that captures its launches sizes the
+ * buffer first: `bytes` >= 8 * (2 (d + d^2) + 1) * B * segments for a time-split filter, 8 * 40 * B * segments (d = 4) or
+ * 8 * 112 * B * segments (d <= 8) for a time-split smoother (a smoother that finds no workspace falls back to its one-wavefront-
+ * per-trial form, which needs none).  Threads that share a context must use different streams. */
+int cgp_reserve_workspace(cgp_ctx* ctx, size_t bytes, void* stream);
 
 /* Smoothers: reads mfs / Pfs, writes mss / Pss (row T-1 is the filtering row T-1). */
 int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,

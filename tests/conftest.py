@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "perf: asserts on a measured time; skipped unless CGP_RUN_PERF=1 (shared or throttled boxes make "
+                                       "such assertions flake, so they stay out of the correctness suite)")
 
 
 def _have_gpu():
@@ -20,6 +22,11 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get("CGP_RUN_PERF") != "1":
+        skip_perf = pytest.mark.skip(reason="timing assertion: set CGP_RUN_PERF=1")
+        for item in items:
+            if "perf" in item.keywords:
+                item.add_marker(skip_perf)
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
