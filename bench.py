@@ -36,8 +36,37 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
-PMC_PROFILE = 'profiles/r04_ekf_pmc.json'
-ISSUE_TABLE = 'profiles/r04_issue_table.json'
+PMC_PROFILE = 'profiles/r05_ekf_pmc.json'
+ISSUE_TABLE = 'profiles/r05_issue_table.json'
+CRLB_PROFILES = {'ekf_full': 'profiles/r05_ekf_large_full_pmc.json', 'ekf_means': 'profiles/r05_ekf_large_means_pmc.json',
+                 'ghf_means': 'profiles/r05_ghf_large_means_pmc.json'}
+_SHA = {}
+
+
+def library_sha256():
+    """sha256 of the library this process loads (chirpgp_amd/libchirpgp_hip.so)."""
+    if 'lib' not in _SHA:
+        import hashlib
+        try:
+            _SHA['lib'] = hashlib.sha256(open(os.path.join(ROOT, 'chirpgp_amd', 'libchirpgp_hip.so'), 'rb').read()).hexdigest()
+        except OSError:
+            _SHA['lib'] = None
+    return _SHA['lib']
+
+
+def load_profile(rel):
+    """A committed counter profile (tools/parse_pmc.py, tools/issue_table.py) -> (dict or None, reason): the static figures of a profile
+    are quoted only for the very library that produced them ("_library_sha256" recorded when the counters were collected); a kernel
+    change without a re-profile leaves them null on the bench line instead of stale."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, rel)))
+    except OSError:
+        return None, f"{rel}: not committed"
+    sha = prof.get('_library_sha256')
+    if sha is None or sha != library_sha256():
+        return None, (f"{rel}: collected from library {str(sha)[:12]}, this run loads {str(library_sha256())[:12]} -- counters withheld "
+                      f"(re-profile with tools/profile_all.sh)")
+    return prof, None
 
 
 def chirp_batch(B, T, seed, dt=1e-3, Xi=0.1, num_harmonics=0, offset=8.0, meow=500.0):
@@ -101,33 +130,29 @@ def bytes_per_trial_step(d):
     return filt, smooth
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
-    (PMC_PROFILE: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  None if no profile is committed for that kernel."""
-    path = os.path.join(ROOT, PMC_PROFILE)
-    try:
-        prof = json.load(open(path))
-    except OSError:
-        return None
+def pmc_traffic(kernel_key, profile=None):
+    """(HBM bytes per launch of the named kernel, why not) from a committed PMC profile of the same command (rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE in separate passes; KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM")."""
+    prof, why = load_profile(profile or PMC_PROFILE)
+    if prof is None:
+        return None, why
     for name, counters in prof.items():
-        if kernel_key in name and 'hbm_bytes_per_launch' in counters:
-            return counters['hbm_bytes_per_launch']
-    return None
+        if not name.startswith('_') and kernel_key in name and 'hbm_bytes_per_launch' in counters:
+            return counters['hbm_bytes_per_launch'], None
+    return None, f"{profile or PMC_PROFILE}: no kernel named *{kernel_key}*"
 
 
 def pmc_issue(kernel_key, units):
     """Instructions and cycles per trial-step of the dominant kernel from the same committed profile (SQ_INSTS_VALU,
     SQ_INSTS_SALU, SQ_WAVE_CYCLES x 4): why a T-serial kernel sits far below the HBM roof at B = 1000."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-    except OSError:
-        return None
+    prof, why = load_profile(PMC_PROFILE)
+    if prof is None:
+        return {"withheld": why}
     for name, c in prof.items():
-        if kernel_key in name and all(k in c for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES')):
+        if not name.startswith('_') and kernel_key in name and all(k in c for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES')):
             return {"valu_per_step": c['SQ_INSTS_VALU']['mean'] / units, "salu_per_step": c['SQ_INSTS_SALU']['mean'] / units,
                     "cycles_per_step": 4 * c['SQ_WAVE_CYCLES']['mean'] / units, "waves": c['SQ_WAVES']['mean'],
-                    "source": PMC_PROFILE}
+                    "source": PMC_PROFILE, "library_sha256": prof['_library_sha256']}
     return None
 
 
@@ -253,6 +278,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the passes of the other BASELINE configurations that follow the timed loop of the default workload')
     ap.add_argument('--other-steps', type=int, default=3, help='timed passes of each other configuration')
+    ap.add_argument('--no-spread', action='store_true', help='skip other_configs.C2_spread (45 record sets of the headline shape)')
     ap.add_argument('--force-dist', action='store_true',
                     help='take the RCCL path even with one rank: init_process_group("nccl"), barrier, all_reduce and the final '
                          'all_gather on device tensors at world size 1')
@@ -284,9 +310,10 @@ def valu_issue(workload, kernel, units, ms):
     """Executed float64 vector work of one launch from the committed PMC profile of this workload
     (ISSUE_TABLE, written by tools/issue_table.py from rocprofv3 --pmc passes): wave-instructions by
     class per trial-step, hence executed FLOP (all 64 lanes counted, FMA = 2) and the share of VALU issue slots used."""
+    prof, _ = load_profile(ISSUE_TABLE)
     try:
-        tab = json.load(open(os.path.join(ROOT, ISSUE_TABLE)))[workload][kernel]
-    except (OSError, KeyError):
+        tab = prof[workload][kernel]
+    except (TypeError, KeyError):
         return None
     flop_per_step = 64 * (2 * tab['fma_f64'] + tab['mul_f64'] + tab['add_f64']) + 2 * 256 * tab.get('mfma_f64', 0)
     return {"executed_tflops": flop_per_step * units / (ms * 1e-3) / 1e12, "valu_per_step": tab['valu'],
@@ -301,11 +328,11 @@ def roofline_of(kind, B, T, d, filt_ms, smooth_ms, bench_shape=False):
     units = B * T
     dom = ('filter', filt_ms, bf) if filt_ms >= smooth_ms else ('smoother', smooth_ms, bs)
     achieved = dom[2] * units / (dom[1] * 1e-3) / 1e9 if dom[1] else None
-    traffic = pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'walk4_smoother') if bench_shape else None
+    traffic, why = pmc_traffic('ekf4_mfma' if dom[0] == 'filter' else 'walk4_smoother') if bench_shape else (None, None)
     hbm = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-           "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                              "committed; not re-measured by this run)") if traffic is not None else None,
+           "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured by "
+                              "this run; collected from the library this run loads: sha256 " + str(library_sha256())[:16] + ")") if traffic is not None else why,
            "algorithmic_bytes_per_launch": dom[2] * units, "avg_launch_ms": dom[1],
            # one wavefront per trial below ~2.5 trials per SIMD (cgp_api.hip:choose_wave): occupancy of the 1024 SIMDs
            "waves_per_simd": round(B / N_SIMDS, 3) if B < 2560 else None}
@@ -515,22 +542,31 @@ def main():
         return out
 
     def measure_crlb(B, T, steps):
-        """The reference's only batched use of the path (tetralith/jobs/crlb_ekf.py:59-79): EKF over B simulated chirp-SDE
-        records of T steps, dt = 0.01, filter only -- with the means alone (what the job keeps) and with full outputs."""
+        """The reference's only batched use of the path (tetralith/jobs/crlb_ekf.py:59-79, crlb_ghf.py:64-75): filters over B simulated
+        chirp-SDE records of T steps, dt = 0.01, filter only -- the EKF with the means alone (what the job keeps) and with full outputs,
+        and the Gauss-Hermite order-3 sigma-point filter with the means alone.  One lane per trial (cgp_lane4.hpp); counter traffic from
+        the committed rocprofv3 --pmc passes of tools/profile_crlb.sh, quoted only for the library this run loads."""
         from chirpgp_amd import tools
         from chirpgp_amd.models import model_chirp, disc_chirp_lcd
+        from chirpgp_amd.quadratures import SigmaPoints
         _, _, m0, P0, H = model_chirp(0.1, 0.1, 1.0, 1.0, 0.1)
         mc = disc_chirp_lcd(0.1, 0.1, 1.0, 1.0)
+        gh3 = SigmaPoints.gauss_hermite(4, 3)
         _, yss = tools.simulate_measurements(mc, H, 0.1, m0, P0, 0.01, T, 666 + rank, batch=B, states=False)
-        out = {"workload": "CRLB job shape: ekf filter only, chirp LCD model, dt = 0.01 (tetralith/jobs/crlb_ekf.py:59-79)", "d": 4, "T": T,
-               "batch_per_gpu": B, "steps": steps, "data": "simulated on the device (cgp_simulate)"}
-        for tag, want, nbytes in (("means_only", (True, False, False), 8 + 32), ("full_outputs", (True, True, True), 176)):
+        base = {"d": 4, "T": T, "batch_per_gpu": B, "steps": steps, "data": "simulated on the device (cgp_simulate)"}
+        ekf = dict(base, workload="CRLB job shape: ekf filter only, chirp LCD model, dt = 0.01 (tetralith/jobs/crlb_ekf.py:59-79)")
+        ghf = dict(base, workload="CRLB job shape: sgp_filter (Gauss-Hermite order 3, 81 points) filter only, chirp LCD model, dt = 0.01 "
+                                  "(tetralith/jobs/crlb_ghf.py:64-75)", sigma_points=int(gh3.n_points))
+        runs = (("means_only", ekf, 'ekf_means', (True, False, False), 8 + 32, lambda w: fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=w)),
+                ("full_outputs", ekf, 'ekf_full', (True, True, True), 176, lambda w: fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=w)),
+                ("means_only", ghf, 'ghf_means', (True, False, False), 8 + 32, lambda w: fs.sgp_filter(mc, gh3, H, 0.1, m0, P0, 0.01, yss, want=w)))
+        for tag, out, prof, want, nbytes, run in runs:
             for _ in range(2):
-                r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want)
+                r = run(want)
             sync()
             events = _engine.kernel_events = []
             for _ in range(steps):
-                r = fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, want=want)
+                r = run(want)
             sync()
             _engine.kernel_events = None
             ms = float(np.mean([a.elapsed_time(b) for n, a, b in events if n == 'filter']))
@@ -538,14 +574,67 @@ def main():
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t[0])
+            algo = nbytes * B * T
+            traffic, why = pmc_traffic('lane4_filter_kernel', CRLB_PROFILES[prof]) if (B, T) == (262144, 500) else (None, "profiled at 262144 x 500")
             out[tag] = {"filter_ms": ms, "value": B * world * T / (ms * 1e-3), "unit": "trial-steps/s",
-                        "algorithmic_bytes_per_trial_step": nbytes, "achieved_GBs": nbytes * B * T / (ms * 1e-3) / 1e9,
-                        "hbm_frac": nbytes * B * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "algorithmic_bytes_per_trial_step": nbytes, "achieved_GBs": algo / (ms * 1e-3) / 1e9,
+                        "hbm_frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_over_algorithmic": traffic / algo if traffic else None,
+                        "traffic_source": CRLB_PROFILES[prof] if traffic else why}
             del r
             torch.cuda.empty_cache()
         del yss
         torch.cuda.empty_cache()
-        return out
+        return ekf, ghf
+
+    def measure_spread(steps):
+        """How much the headline depends on its data: the C2 pass (ekf + eks, 1000 x 10^4) over 5 base seeds x measurement
+        noise Xi in {0.01, 0.1, 1} x frequency offset in {5.5, 8, 20} Hz of the reference's toy chirp (demos/ekfs_mle.py:16-39 with
+        toymodels.py:226-268's law; (seed 0, 0.1, 8) is the headline's record set) -- value = trial-steps/s of each combination from the
+        wall time of `steps` passes, and the regime counters of its filter launch (chunks repeated / run on the checked step)."""
+        from chirpgp_amd import models as pm
+        params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
+        drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+        B, T, dt = 1000, 10000, 1e-3
+        chunks = B * ((T + 63) // 64)
+        rows = []
+        for seed in (0, 1000, 2000, 3000, 4000):
+            for Xi in (0.01, 0.1, 1.0):
+                for offset in (5.5, 8.0, 20.0):
+                    ys = torch.from_numpy(chirp_batch(B, T, seed, dt=dt, Xi=Xi, offset=offset)).cuda()
+
+                    def step():
+                        f = fs.ekf(disc, H, Xi, m0, P0, dt, ys)
+                        return f, fs.eks(disc, f[0], f[1], dt)
+                    keep = [step(), step()]
+                    torch.cuda.synchronize()
+                    del keep
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        r = step()
+                    torch.cuda.synchronize()
+                    dt_pass = (time.perf_counter() - t0) / steps
+                    _engine.debug_set(_engine.DBG_COUNT_REGIMES, 1)
+                    _engine.debug_counters(reset=True)
+                    step()
+                    rg = _engine.debug_counters(reset=True)
+                    _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
+                    rows.append({"seed": seed, "Xi": Xi, "offset_hz": offset, "value": B * T / dt_pass, "ms_per_pass": dt_pass * 1e3,
+                                 "high": rg['high'], "common": rg['common'], "redone": rg['redone'], "checked": rg['checked'], "high_left": rg['high_left']})
+                    del r, ys
+        torch.cuda.empty_cache()
+        vals = np.array([r['value'] for r in rows])
+        med = float(np.median(vals))
+        slow = min(rows, key=lambda r: r['value'])
+        return {"what": "C2 pass over 5 seeds x Xi {0.01, 0.1, 1} x frequency offset {5.5, 8, 20} Hz; value = trial-steps/s (wall of the passes)",
+                "combinations": len(rows), "steps": steps, "chunks_per_launch": chunks,
+                "value_min": float(vals.min()), "value_median": med, "value_max": float(vals.max()),
+                "slowest_over_median_time": med / float(vals.min()), "slowest": slow,
+                "redone_plus_checked_share_max": max((r['redone'] + r['checked']) / chunks for r in rows),
+                "redone_plus_checked_share_at_reference_inputs": max((r['redone'] + r['checked']) / chunks for r in rows if (r['Xi'], r['offset_hz']) == (0.1, 8.0)),
+                "by_offset_median": {str(o): float(np.median([r['value'] for r in rows if r['offset_hz'] == o])) for o in (5.5, 8.0, 20.0)},
+                "by_Xi_median": {str(x): float(np.median([r['value'] for r in rows if r['Xi'] == x])) for x in (0.01, 0.1, 1.0)},
+                "rows": rows}
 
     label, B_default, T_default, scaling_default, bound = WORKLOADS[args.workload]
     scaling = 'strong' if args.strong else (args.scaling or scaling_default)
@@ -559,14 +648,17 @@ def main():
     # The other BASELINE configurations under the same clock: a few passes each after the headline loop, their own default
     # sizes and scaling (C3 / C5: 1000 trials sharded; C4: 512 x 50 000 per GPU; C1: one record per rank).
     others = {}
-    crlb = tsplit = None
+    crlb = tsplit = spread = None
     default_shape = args.workload == 'ekf' and args.batch is None and args.T is None and not args.flags
     if default_shape and not args.no_other_configs:
         for tag, kind in OTHER_CONFIGS:
             _, Bo, To, mode_o, _ = WORKLOADS[kind if kind != 'ekf_low' else 'ekf']
             others[tag] = measure(kind, mode_o, Bo, To, args.other_steps, 1, {})
-        crlb = measure_crlb(262144, 500, args.other_steps)
+        # (a rehearsal's ranks share ONE device's HBM: the CRLB batch is divided among them there)
+        crlb = measure_crlb(262144 // world if args.rehearse else 262144, 500, args.other_steps)
         tsplit = measure_time_split(args.other_steps)          # (every rank runs it -- the shard sizes ARE an 8-GPU run's -- rank 0 reports its own)
+        if world == 1 and not args.no_spread:
+            spread = measure_spread(args.other_steps)
 
     if use_dist:
         dist.destroy_process_group()       # ranks other than 0 are done: rank 0 times the host CPU with nobody spinning beside it
@@ -631,7 +723,9 @@ def main():
                 if o.get('regimes'):
                     oc[tag]["regimes"] = o['regimes']
             if crlb:
-                oc["CRLB_ekf"] = crlb
+                oc["CRLB_ekf"], oc["CRLB_ghf"] = crlb
+            if spread:
+                oc["C2_spread"] = spread
             if tsplit:
                 oc["time_split_filters"] = tsplit
             result["other_configs"] = oc

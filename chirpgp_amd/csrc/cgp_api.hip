@@ -390,7 +390,8 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
             rc = dispatch_filter_coop8_ekf(model->n_harm, io, ma, st);
         else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, io.T, ma))
             rc = dispatch_filter_coop8_sgp(model->n_harm, io, ma, st);
-        else if (method == CGP_F_EKF && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_filter_fits(io))
+        else if ((method == CGP_F_EKF || (method == CGP_F_SGP && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes)) && model->n_harm == 1 && !wave &&
+                 !(flags & CGP_GENERIC_KERNEL) && lane4_filter_fits(io))
             rc = dispatch_filter_lane4(method, io, ma, st);                                      // large batches: cgp_lane4.hpp
         else rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st);
         break;

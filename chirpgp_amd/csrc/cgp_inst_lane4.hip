@@ -8,6 +8,11 @@ int dispatch_filter_lane4(int method, const FilterIO& io, const ModelArgs& ma, h
     using Meas = LinearMeasurement<4>;
     switch (method) {
     case CGP_F_EKF: return hip_rc(launch_lane4_filter<EkfPredict<DM, false>, Meas>(io, ma, st));
+    case CGP_F_SGP:
+        if (sigma_lds_bytes(ma, 4) > (size_t)kSigLdsMaxBytes) return CGP_E_UNSUPPORTED;
+        // the collapsed quadrature alone where the host has checked the set for it (fewer registers, less code)
+        if (sgp_collapsible_host<DM>(ma)) return hip_rc(launch_lane4_filter<SgpPredictLane<DM, true>, Meas>(io, ma, st));
+        return hip_rc(launch_lane4_filter<SgpPredictLane<DM>, Meas>(io, ma, st));
     default: return CGP_E_UNSUPPORTED;
     }
 }

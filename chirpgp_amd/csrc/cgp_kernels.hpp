@@ -97,6 +97,7 @@ inline size_t sigma_lds_bytes(const ModelArgs& ma, int d) {
 
 // Linear scalar measurement y = H x + noise (every filter but ekf_for_kpt).
 template <int D> struct LinearMeasurement {
+    static constexpr bool LINEAR = true;
     CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& H, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
                                double& S, double& innov) {
         scalar_update<D>(mp, Pp, H, Xi, y, false, 0.0, mf, Pf, S, innov);
@@ -105,6 +106,7 @@ template <int D> struct LinearMeasurement {
 // ekf_for_kpt (filters_smoothers.py:298-311): H = grad h(mp), pred = h(mp).
 template <int NH, bool UNIFORM = false> struct KptUpdate {
     static constexpr int D = NH + 2;
+    static constexpr bool LINEAR = false;
     CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>&, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
                                double& S, double& innov) {
         Vec<D> H;

@@ -31,7 +31,10 @@ struct Lane4 {
     static constexpr int YDOUBLES = 64 * KB;       // one block, laid out [piece 0..7][trial 0..63][2] (what the LDS-DMA writes)
     static constexpr int PITCH_P = 12;             // packed covariance row (10 doubles) + 2: conflict-free 16-byte row writes
     static constexpr int PITCH_M = 18;             // a line of means (4 steps x 4) + 2
-    static constexpr int TILE = 64 * PITCH_M;      // doubles; the covariance rows (64 x 12) use the front of it
+    // The LDS transposes run in passes so that a wavefront needs 19 KB in all and EIGHT fit a CU: covariance rows 32 lanes at a
+    // time, lines of means 16 lanes at a time (a pass = masked row writes, then whole-wave reads + stores; DS instructions of one
+    // wavefront execute in order, so passes only need the compiler kept from reordering them).
+    static constexpr int TILE = 32 * PITCH_P;      // doubles (= 16 * PITCH_M + 96 = 64 rows of 4 + 2 for the head / tail rows)
 };
 
 // 64 trials x 16 steps of measurements into LDS: instruction pc moves, for every lane's trial, the 16 bytes of steps t0 + 2 pc,
@@ -59,12 +62,20 @@ template <int N> CGP_DEV void lane4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0
 // from there on blocks of 16 steps whose measurement, NLL and mean chunks are whole lines (base pointers on line boundaries assumed:
 // torch allocations are; any other base only costs the partial lines back).  Workgroup (g, r) = (blockIdx / period, blockIdx mod
 // period) takes the trials 64 period g + r + period l, lane l.
-template <class Pred, class Meas>
+// WANT_P: the covariances are an output (compile time: the launch that keeps the means alone -- the CRLB job -- carries none of the
+// covariance path's registers, addresses and branches).
+template <class Pred, class Meas, bool WANT_P>
 __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs ma, int period) {
     static_assert(Pred::D == 4 && !Pred::WAVE, "one lane per trial, d = 4");
     constexpr int D = 4;
     __shared__ __attribute__((aligned(16))) double ybuf[2 * Lane4::YDOUBLES];
     __shared__ __attribute__((aligned(16))) double tile[Lane4::TILE];
+    // LIGHT steps (the EKF: ~ 260 vector instructions) are unrolled four times and keep a line of means in registers with compile-time
+    // slots; HEAVY steps (a sigma-point fan per step: thousands) are not -- four copies of the fan cost the kernel its registers (256 +
+    // spills, measured) -- and park each step's mean in a second LDS tile instead (such a kernel is bound by its arithmetic, not by LDS
+    // capacity)
+    constexpr bool LIGHT = Pred::LANE_TWO_WAVES;
+    __shared__ __attribute__((aligned(16))) double mtile[LIGHT ? 2 : 64 * Lane4::PITCH_M];
     __shared__ double lds[Pred::USES_LDS ? kFanLdsDoubles : 1];
     const int lane = threadIdx.x;
     const int64_t group = (int64_t)(blockIdx.x / (unsigned)period);
@@ -76,10 +87,16 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
 
     Pred pred;
     pred.setup(ma, trial);
+    if constexpr (Pred::USES_SIGMA) pred.sg.stage(dyn_lds(), lane, 64, D);       // (SgpPredictLane: the fan reads the set from LDS)
+    // (the per-lane softplus stays the naive form here: the wide common-regime form -- cgp_models.hpp: softplus_pair_wide -- pays only
+    // while every lane's frequency state is >= 1.5, and the CRLB job's is a zero-mean GP: its fallback ran in every wavefront, +23 %
+    // vector instructions, measured)
     Vec<D> H, mf;
     Sym<D> Pf;
     if (io.H) load_vec<D>(io.H + trial * io.H_stride, H);
     else { CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = 0.0; }
+    // wave-uniform: every lane's measurement vector is e_1 and the measurement is linear in the state (not ekf_for_kpt)
+    const bool he1 = Meas::LINEAR && __builtin_amdgcn_ballot_w64(!(H.v[0] == 1.0 && H.v[1] == 0.0 && H.v[2] == 0.0 && H.v[3] == 0.0)) == 0;
     const double Xi = io.Xi[trial * io.Xi_stride];
     load_vec<D>(io.m0 + trial * io.m0_stride, mf);
     load_sym<D>(io.P0 + trial * io.P0_stride, Pf);
@@ -88,7 +105,8 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
     const double* __restrict__ rec = io.record(trial);
     const bool nll_final = (io.flags & CGP_NLL_FINAL_ONLY) != 0;
     const bool want_nll = io.nll != nullptr, nll_rows = want_nll && !nll_final;
-    const bool want_m = io.mfs != nullptr, want_P = io.Pfs != nullptr;
+    const bool want_m = io.mfs != nullptr;
+    constexpr bool want_P = WANT_P;
 
     // output windows over this wavefront's trials; per-lane byte offsets of (trial 8 i + sub, 16-byte piece pc) in them
     OobWindow wP, wM, wN;
@@ -116,20 +134,36 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
         Vec<D> mp; Sym<D> Pp;
         double S, innov;
         pred.predict(lane, lds, mf, Pf, mp, Pp);
-        Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+        if (he1) {
+            // H = e_1 (every chirp model of the reference: models.py:118): H Pp is column 0 as it stands, S = Pp_00 + Xi
+            S = Pp(0, 0) + Xi;
+            innov = y - mp.v[0];
+            const double rS = rcp_nr(S);
+            Vec<D> K;
+            CGP_UNROLL for (int i = 0; i < D; i++) K.v[i] = Pp(i, 0) * rS;
+            CGP_UNROLL for (int i = 0; i < D; i++) mf.v[i] = fma(K.v[i], innov, mp.v[i]);
+            CGP_UNROLL for (int i = 0; i < D; i++)
+                CGP_UNROLL for (int j = 0; j <= i; j++) Pf(i, j) = fma(-K.v[i], Pp(j, 0), Pp(i, j));
+        } else {
+            Meas::update(mp, Pp, H, Xi, y, mf, Pf, S, innov);
+        }
         if (want_nll) {
             cum += nll_increment(S, innov);
             if (nll_rows) *nll_slot = cum;
         }
-        if (want_P) {
-            double* row = tile + lane * Lane4::PITCH_P;
-            CGP_UNROLL for (int c = 0; c < 5; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(Pf.a[2 * c], Pf.a[2 * c + 1]);
-            wave_lds_fence();
-            CGP_UNROLL for (int i = 0; i < 8; i++)
-                wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)i * 8u * rowP);
-            wave_lds_fence();
+        if constexpr (want_P) {
+            double* row = tile + (lane & 31) * Lane4::PITCH_P;
+            CGP_UNROLL for (int h = 0; h < 2; h++) {
+                if ((lane >> 5) == h) {
+                    CGP_UNROLL for (int c = 0; c < 5; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(Pf.a[2 * c], Pf.a[2 * c + 1]);
+                }
+                wave_lds_fence();
+                CGP_UNROLL for (int i = 0; i < 4; i++)
+                    wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)(4 * h + i) * 8u * rowP);
+                wave_lds_fence();
+            }
         }
-        voffP += 128u;
+        if constexpr (want_P) voffP += 128u;
     };
 
     // up to 16 steps [ta, ta + n) with a run-time count -- the head in front of the first line boundary and the tail behind the last:
@@ -180,6 +214,29 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
         else lane4_wait_vm<8>();
         drained = false;
         if (t + Lane4::KB < T) lane4_dma_y(ybase + (unsigned)(cur ^ 1) * (Lane4::YDOUBLES * 8u), rec, t + Lane4::KB, T);
+        if constexpr (!LIGHT) {
+            _Pragma("unroll 1") for (int q = 0; q < 4; q++) {
+                _Pragma("unroll 1") for (int sidx = 0; sidx < 4; sidx++) {
+                    const int k = 4 * q + sidx;
+                    double* slot = yb + (k >> 1) * 128 + lane * 2 + (k & 1);
+                    step(*slot, slot);
+                    if (want_m) {
+                        double* row = mtile + lane * Lane4::PITCH_M + 4 * sidx;
+                        *reinterpret_cast<double2*>(row) = make_double2(mf.v[0], mf.v[1]);
+                        *reinterpret_cast<double2*>(row + 2) = make_double2(mf.v[2], mf.v[3]);
+                    }
+                }
+                if (want_m) {
+                    wave_lds_fence();
+                    CGP_UNROLL for (int i = 0; i < 8; i++) {
+                        const double2 v = *reinterpret_cast<const double2*>(mtile + (8 * i + sub) * Lane4::PITCH_M + 2 * pc);
+                        wM.store2(v.x, v.y, voffM + (unsigned)i * 8u * rowM);
+                    }
+                    wave_lds_fence();
+                }
+                voffM += 128u;
+            }
+        } else
         _Pragma("unroll 1") for (int q = 0; q < 4; q++) {
             double* yq = yb + q * 256 + lane * 2;                    // steps 4 q, 4 q + 1 | + 128: steps 4 q + 2, 4 q + 3
             const double2 y01 = *reinterpret_cast<const double2*>(yq);
@@ -194,14 +251,18 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
             step(y23.y, yq + 129);
             CGP_UNROLL for (int i = 0; i < D; i++) mh[12 + i] = mf.v[i];
             if (want_m) {
-                double* row = tile + lane * Lane4::PITCH_M;
-                CGP_UNROLL for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(mh[2 * c], mh[2 * c + 1]);
-                wave_lds_fence();
-                CGP_UNROLL for (int i = 0; i < 8; i++) {
-                    const double2 v = *reinterpret_cast<const double2*>(tM + i * 8 * Lane4::PITCH_M);
-                    wM.store2(v.x, v.y, voffM + (unsigned)i * 8u * rowM);
+                double* row = tile + (lane & 15) * Lane4::PITCH_M;
+                CGP_UNROLL for (int h = 0; h < 4; h++) {
+                    if ((lane >> 4) == h) {
+                        CGP_UNROLL for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(mh[2 * c], mh[2 * c + 1]);
+                    }
+                    wave_lds_fence();
+                    CGP_UNROLL for (int i = 0; i < 2; i++) {
+                        const double2 v = *reinterpret_cast<const double2*>(tM + i * 8 * Lane4::PITCH_M);
+                        wM.store2(v.x, v.y, voffM + (unsigned)(2 * h + i) * 8u * rowM);
+                    }
+                    wave_lds_fence();
                 }
-                wave_lds_fence();
             }
             voffM += 128u;
         }
@@ -235,7 +296,9 @@ inline hipError_t launch_lane4_filter(const FilterIO& io, const ModelArgs& ma, h
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
     const int period = lane4_period(io.T);
     const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
-    hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
+    const size_t dyn = Pred::USES_SIGMA ? sigma_lds_bytes(ma, Pred::D) : 0;
+    if (io.Pfs) hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas, true>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
+    else hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas, false>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
     return hipGetLastError();
 }
 

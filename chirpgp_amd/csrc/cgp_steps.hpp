@@ -525,6 +525,20 @@ template <class DM, bool WAVE_, bool COLL = false> struct SgpPredict {
     }
 };
 
+// the same with one lane per trial and the sigma-point set STAGED in LDS (cgp_lane4.hpp): a lane walks the whole fan, and its group
+// table must not come from global memory -- a load behind the step's output stores waits for all of them (one in-order counter)
+template <class DM, bool COLL = false> struct SgpPredictLane {
+    static constexpr bool USES_SIGMA = true;
+    static constexpr bool LANE_TWO_WAVES = false;
+    static constexpr int D = DM::D; static constexpr bool WAVE = false; static constexpr bool USES_LDS = false;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = false; }
+    CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> unused;
+        sgp_prediction<DM, false, false, true, COLL>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
+    }
+};
+
 // cd_ekf (filters_smoothers.py:384-394): dm = a(m), dP = P J^T + J P + gamma
 template <class SM, bool WAVE_> struct CdEkfPredict {
     static constexpr bool USES_SIGMA = false;

@@ -1,6 +1,7 @@
 """Time-split filters with burn-in (cgp_filter_time_split): several wavefronts per trial for batches that leave most SIMDs idle.
 Not the sequential recursion -- a filter cannot be cut in time exactly -- but as close to it as the reported junction mismatch says:
-checked here against the sequential launch of the same kernels, with the mismatch the launch itself reports as the yardstick."""
+checked here against the sequential launch of the same kernels, with the mismatch the launch itself reports as the yardstick, and
+(test_time_split_filters_against_the_oracle_at_the_bench_shards) against the CPU oracle itself at the shard sizes bench.py reports."""
 import numpy as np
 import pytest
 
@@ -72,8 +73,49 @@ def test_a_nan_at_a_junction_is_reported_and_the_tolerance_falls_back():
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
 
 
+@pytest.mark.parametrize('kind,B,T,segments,burn_in', [('ekf', 125, 10000, 8, 4096), ('sgp', 125, 10000, 8, 3008), ('cd_sgp', 512, 50000, 2, 3008)])
+def test_time_split_filters_against_the_oracle_at_the_bench_shards(kind, B, T, segments, burn_in):
+    """The shards `bench.py` reports under other_configs.time_split_filters (BASELINE C2 / C3 on one of 8 GPUs: 125 x 10^4; C4: 512 x
+    5 10^4), EVERY trial against the C port of the reference's sequential recursion (filters_smoothers.py:263, 489, 581) -- not against
+    the engine's own sequential launch: within max(1e-5, 5 x the junction mismatch the launch reports) of the port, relative to each
+    output's largest entry (1e-5 is the north star's tolerance; the mismatch is the launch's own accuracy figure)."""
+    import copy
+    import torch
+    import bench
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    wl = bench.make_workload(B, T, kind=kind)
+    ys = torch.from_numpy(wl['ys']).cuda()
+    a = (wl['H'], wl['Xi'], wl['m0'], wl['P0'], wl['dt'])
+    kw = dict(time_split=(segments, burn_in), return_junction_error=True)
+    if kind == 'ekf':
+        got = fs.ekf(wl['disc'], *a, ys, **kw)
+        want = port.filter(port.F_EKF, wl['disc'], None, *a, wl['ys'])
+    elif kind == 'sgp':
+        got = fs.sgp_filter(wl['disc'], wl['sgps'], *a, ys, **kw)
+        want = port.filter(port.F_SGP, wl['disc'], wl['sgps'], *a, wl['ys'])
+    else:
+        dg = copy.copy(wl['drift'])
+        dg.gamma = wl['disp'].outer()
+        got = fs.cd_sgp_filter(wl['drift'], wl['disp'](None), wl['sgps'], *a, ys, **kw)
+        want = port.filter(port.F_CD_SGP, dg, wl['sgps'], *a, wl['ys'])
+    err = got[3].cpu().numpy()
+    assert err.shape == (B,) and np.isfinite(err).all() and err.max() > 0
+    rel = []
+    for g, w, n in zip(got[:3], want, ('mfs', 'Pfs', 'nll')):
+        g = g.cpu().numpy()
+        per_trial = np.abs(g - w).reshape(B, -1).max(axis=1) / np.abs(w).max()
+        gate = np.maximum(1e-5, 5 * err)
+        assert (per_trial <= gate).all(), (kind, n, float(per_trial.max()), float(err.max()))
+        rel.append(float(per_trial.max()))
+    print(f'{kind} {B} x {T} ({segments}, {burn_in}): junction mismatch {err.max():.1e}; worst difference from the port mfs / Pfs / nll ' +
+          ' / '.join(f'{v:.1e}' for v in rel))
+
+
+@pytest.mark.perf
 def test_small_batch_time_split_is_faster():
-    """BASELINE C3's shard on one of 8 GPUs (125 x 10 000): eight segments with 3008 steps of burn-in against the sequential launch."""
+    """BASELINE C3's shard on one of 8 GPUs (125 x 10 000): eight segments with 3008 steps of burn-in against the sequential launch.
+    (A timing assertion: CGP_RUN_PERF=1 only.)"""
     import torch
     import bench
     from chirpgp_amd import filters_smoothers as fs, _engine

@@ -12,13 +12,17 @@ import sys
 
 def main(dirs):
     out = {}
+    shas = set()
     for d in dirs:
         bench = json.loads(open(os.path.join(d, 'bench.json')).read().strip().splitlines()[-1])
         pmc = json.load(open(os.path.join(d, 'pmc.json')))
         wl = {v[0]: k for k, v in __import__('bench').WORKLOADS.items()}[bench['config']['workload']]
         units = bench['config']['batch_per_gpu'] * bench['config']['T']
         roles = {}
+        shas.add(pmc.get('_library_sha256'))
         for name, c in pmc.items():
+            if name.startswith('_'):
+                continue
             role = 'smoother' if 'smooth' in name or 'eks' in name or 'sgps' in name.lower() or 'split_kernel' in name else 'filter'
             g = lambda k: c.get(k, {}).get('mean', 0.0) / units
             roles[role] = {'kernel': name, 'valu': g('SQ_INSTS_VALU'), 'salu': g('SQ_INSTS_SALU'), 'lds': g('SQ_INSTS_LDS'),
@@ -27,6 +31,8 @@ def main(dirs):
                            'cycles': 4 * g('SQ_WAVE_CYCLES'), 'waves': c.get('SQ_WAVES', {}).get('mean'),
                            'source': 'profiles/' + os.path.basename(d.rstrip('/')).replace('prof_', '') + '_pmc.json'}
         out[wl] = roles
+    # one library for the whole table, or none: bench.py quotes the table only for the library that produced it
+    out['_library_sha256'] = shas.pop() if len(shas) == 1 else None
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -2,7 +2,7 @@
 # tools/pmc_run.sh <outdir> <program> [args...]: rocprofv3 evidence for ONE command (run on the GPU box from the repo root):
 # kernel-trace stats, then one --pmc pass per counter group with nothing else enabled -> <outdir>/{kernel_stats.csv,pmc.json}.
 # PMC_GROUPS (";"-separated) overrides the counter groups.  The program goes after "--" itself (no env / bash -c hop: the
-# profiler's preloaded library has initialised the GPU by then).  pmc.json records the sha256 of the library that ran.
+# profiler's preloaded library has initialised the GPU by then).  pmc.json records the sha256 of the library that ran (tools/parse_pmc.py).
 set -e
 OUT=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -18,12 +18,5 @@ for group in "${GROUPS_ARR[@]}"; do
     rocprofv3 --pmc $group -d "$OUT/pmc_$i" -o pmc --output-format csv -- "$@" > /dev/null 2> "$OUT/pmc_$i.log" || echo "pmc group $i ($group) failed"
 done
 python "$ROOT/tools/parse_pmc.py" "$OUT" > "$OUT/pmc.json"
-python - "$OUT/pmc.json" "$ROOT/chirpgp_amd/libchirpgp_hip.so" <<'PY'
-import hashlib, json, sys
-p, so = sys.argv[1], sys.argv[2]
-d = json.load(open(p))
-d['_library_sha256'] = hashlib.sha256(open(so, 'rb').read()).hexdigest()
-json.dump(d, open(p, 'w'), indent=1)
-PY
 rm -rf "$OUT"/trace "$OUT"/pmc_[0-9]*/
 echo "pmc_run: $OUT done"

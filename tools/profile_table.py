@@ -11,7 +11,7 @@ print('| workload (B x T) | kernel | rocprofv3 avg (calls; min) | bench.py HIP e
 print('|---|---|---|---|---|---|---|')
 for w, label, units, d in rows:
     st = {r['Name']: (float(r['AverageNs']) / 1e6, float(r['MinNs']) / 1e6, r['Calls']) for r in csv.DictReader(open(P(f'{w}_kernel_stats.csv')))}
-    tr = {k: v.get('hbm_bytes_per_launch') for k, v in json.load(open(P(f'{w}_pmc.json'))).items()}
+    tr = {k: v.get('hbm_bytes_per_launch') for k, v in json.load(open(P(f'{w}_pmc.json'))).items() if not k.startswith('_')}
     b = json.load(open(P(f'{w}_bench.json')))
     for kind, by in (('filter', 8 + 8 * d + 8 * d * d + 8), ('smoother', 2 * (8 * d + 8 * d * d))):
         v = t[w][kind]
