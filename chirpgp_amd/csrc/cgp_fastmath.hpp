@@ -243,6 +243,10 @@ CGP_DEV void fast_sincos_uniform(double x, double& sn, double& cs) {
 // naive form of models.py:50 is evaluated as is, overflow behaviour included.
 CGP_DEV void softplus_pair_uniform(double x, double& sp, double& dsp) {
     const int hx = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    // 40 <= x < 700: t = exp(-x) < 4.3e-18 is below half an ulp of x and of 1, so the form below returns exactly (x, 1) -- without
+    // evaluating it.  (The KPT measurement's argument is frequency + accumulated PHASE, models.py:575-578: beyond 40 after a few hundred
+    // steps of every record; the exp / reciprocal chain was a third of that filter's step.)
+    if (hx >= 0x40440000 && hx < 0x4085E000) { sp = x; dsp = 1.0; return; }
     if (__builtin_expect(hx >= 0x40180000 && hx < 0x4085E000, 1)) {   // 6.0 <= x < 700.0 (positive doubles order like their bits)
         const double t = fast_exp_core(-x);
         double p = -1.0 / 6.0;

@@ -61,7 +61,7 @@ def test_default_line_carries_the_other_baseline_configs():
     r = _run('--steps', '3', '--warmup', '1', '--other-steps', '1', '--no-cpu-baseline')
     assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000 and r['roofline']['traffic'] is not None
     oc = r['other_configs']
-    assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'time_split_filters'}
+    assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'CRLB_ghf', 'C2_spread', 'time_split_filters'}
     # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
     rg = r['regimes']
     assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['checked'] == rg['chunks']
@@ -73,6 +73,17 @@ def test_default_line_carries_the_other_baseline_configs():
     assert (crlb['batch_per_gpu'], crlb['T']) == (262144, 500)
     for k in ('means_only', 'full_outputs'):
         assert crlb[k]['filter_ms'] > 0 and 0 < crlb[k]['hbm_frac'] < 1
+        # counter traffic only from a profile of the very library that ran (else withheld, with the reason)
+        assert (crlb[k]['traffic'] is None) == (crlb[k]['traffic_over_algorithmic'] is None) and crlb[k]['traffic_source']
+        if crlb[k]['traffic'] is not None:
+            assert 0.99 < crlb[k]['traffic_over_algorithmic'] < 1.16
+    ghf = oc['CRLB_ghf']
+    assert (ghf['batch_per_gpu'], ghf['T'], ghf['sigma_points']) == (262144, 500, 81) and ghf['means_only']['filter_ms'] > 0
+    # the headline's dependence on its data, measured: 45 record sets of the headline shape
+    sp = oc['C2_spread']
+    assert sp['combinations'] == 45 and len(sp['rows']) == 45 and sp['value_min'] <= sp['value_median'] <= sp['value_max']
+    assert sp['slowest_over_median_time'] < 1.15, sp['slowest']                       # no record set more than 15 % slower than the median
+    assert sp['redone_plus_checked_share_at_reference_inputs'] <= 0.01                # the reference's inputs, any seed: <= 1 % of the chunks repeated
     ts = oc['time_split_filters']
     for k in ('C2_shard', 'C3_shard', 'C4_per_gpu'):                      # the chirp filters forget: junctions at 1e-6 or better, >= 1.4 x
         assert ts[k]['accepted_at_1e-5'] and ts[k]['junction_mismatch'] < 1e-5 and ts[k]['worst_output_difference'] <= 5 * ts[k]['junction_mismatch']
@@ -91,6 +102,28 @@ def test_default_line_carries_the_other_baseline_configs():
         # round 4 the algorithmic figure of C3 exceeds the executed one: the two are reported side by side, not ordered)
         if rf['frac'] is not None:
             assert 0 < rf['frac'] < 1
+
+
+def test_six_rank_rehearsal_of_the_scaling_command():
+    """First contact with a multi-GPU node should be uneventful: the driver's N > 1 command with the default shapes on SIX ranks sharing
+    the one GPU (the box allows six processes on its card -- an 8-rank rehearsal is not permitted here; world = 8 itself is covered on CPU
+    by tests/test_dist_gloo.py) -- the parent spawns a fresh child (never re-execs), every rank goes through the headline, the strong C2
+    figure, other_configs and the gathers, rank 0 alone times the host CPU once, and the whole run stays far inside the driver's 600 s."""
+    import time
+    t0 = time.time()
+    r = _run('--gpus', '6', '--rehearse', '--steps', '2', '--warmup', '1', '--other-steps', '1')
+    took = time.time() - t0
+    assert r['n_gpus'] == 6 and r['ranks_seen'] == 6 and r['collectives'].startswith('gloo')
+    assert r['scaling'] == 'weak' and r['config']['batch_per_gpu'] == 1000 and r['config']['global_batch'] == 6000
+    assert r['strong']['global_batch'] == 1000 and r['strong']['batch_per_gpu'] == 167 and r['strong']['gather_ms'] is not None
+    assert r['gather_ms'] is not None and r['gather_ms'] >= 0
+    oc = r['other_configs']
+    assert oc['C3']['batch_per_gpu'] == 167 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 167
+    assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 6 * 512 and oc['C1']['global_batch'] == 6
+    assert 'C2_spread' not in oc                                       # a single-GPU diagnostic: not repeated on every rank
+    assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0
+    print(f'six-rank rehearsal of the default line: {took:.0f} s')
+    assert took < 400, took
 
 
 def test_two_rank_rehearsal_of_the_default_line():
