@@ -485,7 +485,12 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     }
     ShapeLimit limit = affine ? ShapeLimit{16, 1} : (sig ? ShapeLimit{8, 1} : ShapeLimit{5, 2});
     if (coop_walk) limit = {-1, 1};
-    else if (method == CGP_S_CD_EKS && sde4) limit = {5, 1};
+    else if (method == CGP_S_CD_EKS && sde4) limit = lane4_smoother_fits(io) ? ShapeLimit{3, 1} : ShapeLimit{5, 1};
+    // (round 5: eks on the d = 4 chirp models beyond 24 trials per SIMD runs one lane per trial in the kernel of cgp_lane4.hpp -- 1.21 against
+    // 1.48 ms at 32 768 x 500, 8.0 against 10.6 ms at 262 144 x 500, the walk ahead below: 0.70 against 0.93 ms at 16 384;
+    // profiles/r05_lane_smoothers.txt.  cd_eks: 1.74 against 2.48 ms at 4096 x 500)
+    if (coop_walk && method == CGP_S_EKS && spec && model->n_harm == 1 && (model->model_id == CGP_M_HARMONIC_LCD || model->model_id == CGP_M_LASCALA_LCD) &&
+        lane4_smoother_fits(io) && !(flags & CGP_SEQUENTIAL_SCAN)) limit = {24, 1};
     else if (method == CGP_S_CD_SGP && sde4) limit = {48, 1};
     const bool wave = choose_wave(ctx, B, flags, limit, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
@@ -501,12 +506,16 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     case CGP_M_LASCALA_LCD:
         if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm >= 2 && coop8_smoother_ok(model->d, T, ma) && coop8_smoother_harm_ok(method, ma)) rc = dispatch_smoother_coop8_harm(method, model->n_harm, io, ma, st);
         else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm == 1 && walk4_smoother_fits(T, ma)) rc = dispatch_smoother_walk4_harm(method, io, ma, st);
+        else if (method == CGP_S_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io))
+            rc = dispatch_smoother_lane4(method, model->model_id, io, ma, st);                 // one lane per trial: cgp_lane4.hpp
         else rc = dispatch_smoother_disc_harm(method, model->n_harm, wave, io, ma, st);
         break;
     case CGP_M_LINEAR_SDE:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;
     case CGP_M_HARMONIC_SDE:
         if (method == CGP_S_CD_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdsgp(io, ma, st);
         else if (method == CGP_S_CD_EKS && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdeks(io, ma, st);
+        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io))
+            rc = dispatch_smoother_lane4(method, model->model_id, io, ma, st);                 // one lane per trial: cgp_lane4.hpp
         else rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st);
         break;
     default: rc = CGP_E_ARG;

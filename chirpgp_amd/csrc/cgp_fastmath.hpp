@@ -172,6 +172,14 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
     }
 }
 
+// fast_sincos for kernels whose angles are small throughout (one lane per trial at dt = 0.01: the rotation angle is dt 2 pi g(u) ~ 0.06 g):
+// if every active lane's |x| <= pi / 4 the Cody-Waite reduction is the identity (n = 0, r = x, no swap, no sign flip) and is skipped -- the
+// same bits, ~ 18 instructions less; one wave-uniform branch, otherwise fast_sincos as is (NaN and inf take that way).
+CGP_DEV void fast_sincos_small(double x, double& sn, double& cs) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabs(x) <= kPiOver4)) == 0, 1)) { sincos_reduced(x, sn, cs); return; }
+    fast_sincos(x, sn, cs);
+}
+
 // fast_sincos without its fallback branch: ok = false for |x| >= 1e5, inf and NaN (the caller repeats with fast_sincos).
 CGP_DEV void fast_sincos_spec(double x, double& sn, double& cs, bool& ok) {
     ok = fabs(x) < 1.0e5;

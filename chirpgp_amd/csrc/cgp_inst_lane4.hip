@@ -16,4 +16,11 @@ int dispatch_filter_lane4(int method, const FilterIO& io, const ModelArgs& ma, h
     default: return CGP_E_UNSUPPORTED;
     }
 }
+int dispatch_smoother_lane4(int method, int model_id, const SmootherIO& io, const ModelArgs& ma, hipStream_t st) {
+    if (method == CGP_S_EKS && (model_id == CGP_M_HARMONIC_LCD || model_id == CGP_M_LASCALA_LCD))
+        return hip_rc(launch_lane4_smoother<EksStep<HarmonicLCD<1>, false>>(io, ma, st));
+    if (method == CGP_S_CD_EKS && model_id == CGP_M_HARMONIC_SDE)
+        return hip_rc(launch_lane4_smoother<CdEksStep<HarmonicSDE<1>, false>>(io, ma, st));
+    return CGP_E_UNSUPPORTED;
+}
 }  // namespace cgp

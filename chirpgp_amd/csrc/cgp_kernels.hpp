@@ -585,6 +585,12 @@ inline bool lane4_filter_fits(const FilterIO& io) {
     return io.segs <= 1 && io.T >= 2 && io.T % 2 == 0 && io.ys_stride % 2 == 0 && ((uintptr_t)io.ys & 15) == 0 && io.T * 128 * 64 <= 0x7FFFFF00ll;
 }
 int dispatch_filter_lane4(int method, const FilterIO&, const ModelArgs&, hipStream_t);
+// ... and its smoothers (eks on the chirp / La Scala LCD models, cd_eks on the chirp SDE): 16-byte aligned inputs (LDS-DMA), output windows
+// of 64 trials within 2 GiB
+inline bool lane4_smoother_fits(const SmootherIO& io) {
+    return io.T >= 2 && io.T * 128 * 64 <= 0x7FFFFF00ll && ((uintptr_t)io.mfs & 15) == 0 && ((uintptr_t)io.Pfs & 15) == 0;
+}
+int dispatch_smoother_lane4(int method, int model_id, const SmootherIO&, const ModelArgs&, hipStream_t);
 // d = 6 / 8 harmonic models in the 8 x 8 tile layout (cgp_coop8.hpp)
 bool coop8_filter_sgp_ok(int n_harm, int64_t T, const ModelArgs&);
 bool walk4_smoother_fits(int64_t T, const ModelArgs&);

@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
     Pred pred;
     pred.setup(ma, trial);
     if constexpr (Pred::USES_SIGMA) pred.sg.stage(dyn_lds(), lane, 64, D);       // (SgpPredictLane: the fan reads the set from LDS)
+    pred.large_batch();                                  // small-angle sin / cos where every lane's angle allows (cgp_fastmath.hpp)
     // (the per-lane softplus stays the naive form here: the wide common-regime form -- cgp_models.hpp: softplus_pair_wide -- pays only
     // while every lane's frequency state is >= 1.5, and the CRLB job's is a zero-mean GP: its fallback ran in every wavefront, +23 %
     // vector instructions, measured)
@@ -299,6 +300,201 @@ inline hipError_t launch_lane4_filter(const FilterIO& io, const ModelArgs& ma, h
     const size_t dyn = Pred::USES_SIGMA ? sigma_lds_bytes(ma, Pred::D) : 0;
     if (io.Pfs) hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas, true>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
     else hipLaunchKernelGGL((lane4_filter_kernel<Pred, Meas, false>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
+    return hipGetLastError();
+}
+
+// ====================================================================================================================== smoothers
+// The same rules for the backward pass (eks, cd_eks at d = 4; per trial and step 160 bytes in -- mf, Pf -- and 160 out -- ms, Ps): the
+// generic lane kernel (cgp_kernels.hpp: smoother_kernel) loads a step's filtering rows right behind the previous step's stores (a full
+// drain of the store queue per step) and moves the means in 32-byte pieces -- 3.7 TB/s at 65 536 x 500, with or without the RK4 of cd_eks
+// in between (profiles/r05_lane_smoothers.txt).  Here:
+//   * the covariance rows of the NEXT step (128 B per trial) and the mean lines of the NEXT four steps (one 128-byte line per trial) come
+//     in by LDS-DMA while the current step computes; the waits are counted (vmcnt(8) / (16): the stores issued since stay in flight);
+//   * a DMA instruction lays its 64 lanes' 16-byte pieces down contiguously, so it fetches 8 trials x 128 B (whole lines) with the pieces
+//     of trial s rotated by s slots (and the instructions' 1 KB pieces 1040 bytes apart, the odd ones shifted by one slot more): a lane then reads ITS trial's row back without bank
+//     conflicts -- what a pitch of 18 doubles does for the register-staged tiles;
+//   * smoothed means leave as whole lines per four steps, covariances packed through the 3 KB tile, as in the filter; trials are grouped
+//     by the phase of their rows against the lines (period = 4 / gcd(T, 4)), the few rows outside whole quads go row by row.
+struct Lane4S { static constexpr int PITCH = 1040, ROWS = (8 * 1040 + 16) / 8 + 2; };      // bytes between the instructions' 1 KB pieces (the odd ones shifted by 16 more); doubles of a set
+
+// 64 rows of 128 bytes, one per trial of the wavefront, into LDS.  g0: this lane's source for instruction 0 -- row of trial (lane >> 3),
+// piece ((lane & 7) + (lane >> 3)) & 7; instruction i serves the trials 8 i .. 8 i + 7: `step` doubles further (trials past the batch
+// clamped by the caller through `last`: the row of the last valid trial).
+CGP_DEV void lane4_dma_rows(unsigned lds_base, const double* __restrict__ g0, int64_t step, int sub, int nvalid, const double* __restrict__ last) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (LDS reads of the buffer being refilled have returned)
+    CGP_UNROLL for (int i = 0; i < 8; i++) {
+        const double* src = (8 * i + sub < nvalid) ? g0 + i * step : last;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + i * Lane4S::PITCH + (i & 1) * 16);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+// byte offset (from the set's base) of piece p of the row of trial `lane`
+CGP_DEV unsigned lane4_row_piece(int lane, int p) {
+    const int i = lane >> 3, s = lane & 7;
+    return (unsigned)(i * Lane4S::PITCH + (i & 1) * 16 + s * 128 + ((p - s) & 7) * 16);
+}
+
+template <class Step>
+__global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, ModelArgs ma, int period) {
+    static_assert(Step::D == 4 && !Step::WAVE && !Step::USES_SIGMA, "one lane per trial, d = 4, no sigma-point set");
+    constexpr int D = 4;
+    __shared__ __attribute__((aligned(16))) double pin[2 * Lane4S::ROWS];
+    __shared__ __attribute__((aligned(16))) double min_[Lane4S::ROWS];
+    __shared__ __attribute__((aligned(16))) double tile[Lane4::TILE];
+    __shared__ double lds[Step::USES_LDS ? kFanLdsDoubles : 1];
+    const int lane = threadIdx.x;
+    const int64_t group = (int64_t)(blockIdx.x / (unsigned)period);
+    const int64_t block_first = group * 64 * period + (int64_t)(blockIdx.x % (unsigned)period);
+    if (block_first >= io.B) return;
+    const int64_t nv = (io.B - block_first + period - 1) / period;
+    const int nvalid = nv < 64 ? (int)nv : 64;
+    const bool valid = lane < nvalid;
+    const int64_t trial = block_first + (int64_t)period * (valid ? lane : nvalid - 1);
+
+    Step step;
+    step.setup(ma, trial);
+    const int64_t T = io.T;
+    const double* __restrict__ mfs = io.mfs + trial * T * D;
+    const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
+    double* __restrict__ mss = io.mss + trial * T * D;
+    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+
+    // filters_smoothers.py:140-142: the last smoothing row is the last filtering row (copied verbatim, all 16 covariance entries)
+    Vec<D> ms; Sym<D> Ps;
+    load_vec<D>(mfs + (T - 1) * D, ms);
+    load_sym<D>(Pfs + (T - 1) * D * D, Ps);
+    if (valid) {
+        CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+        CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i];
+    }
+    // one row outside the whole quads: inputs and outputs straight from / to this lane's rows (a handful per record)
+    auto edge = [&](int64_t t) __attribute__((always_inline)) {
+        Vec<D> mf; Sym<D> Pf;
+        load_vec<D>(mfs + t * D, mf);
+        load_sym<D>(Pfs + t * D * D, Pf);
+        step.step(lane, lds, mf, Pf, ms, Ps);
+        if (valid) {
+            store_vec<D>(mss + t * D, ms);
+            store_sym_full<D>(Pss + t * D * D, Ps);
+        }
+    };
+    // rows [a_lo, a_lo + 4 nq) are whole lines of four means for every trial of this wavefront (wave-uniform: period * T is a multiple of 4)
+    const int a_lo = (int)((4 - ((block_first * T) & 3)) & 3);
+    const int64_t nq = (T - 1 > a_lo) ? (T - 1 - a_lo) / 4 : 0;
+    for (int64_t t = T - 2; t >= (nq > 0 ? a_lo + 4 * nq : 0); t--) edge(t);     // (no whole quad: every row goes this way)
+    if (nq > 0) {
+        // output windows over this wavefront's trials, per-lane offsets of (trial 8 i + sub, piece pc), as in the filter
+        OobWindow wP, wM;
+        const int64_t span = (int64_t)(nvalid - 1) * period + 1;
+        wP.init(io.Pss + block_first * T * 16, span * T * 128);
+        wM.init(io.mss + block_first * T * 4, span * T * 32);
+        const int sub = lane >> 3, pc = lane & 7;
+        const unsigned rowP = (unsigned)(T * period) * 128u, rowM = (unsigned)(T * period) * 32u;
+        const int64_t t_hi = a_lo + 4 * nq - 1;                          // the first row of the quads (processed downwards)
+        unsigned voffP = (unsigned)sub * rowP + (unsigned)pc * 16u + (unsigned)t_hi * 128u;
+        unsigned voffM = (unsigned)sub * rowM + (unsigned)pc * 16u + (unsigned)(t_hi - 3) * 32u;
+        const int ia = (pc == 0) ? 0 : (pc == 1) ? 3 : (pc == 2) ? 1 : (pc == 3) ? 4 : (pc == 4) ? 3 : (pc == 5) ? 5 : (pc == 6) ? 6 : 8;
+        const int ib = (pc == 0) ? 1 : (pc == 1) ? 6 : (pc == 2) ? 2 : (pc == 3) ? 7 : (pc == 4) ? 4 : (pc == 5) ? 8 : (pc == 6) ? 7 : 9;
+        const double* tPa = tile + sub * Lane4::PITCH_P + ia;
+        const double* tPb = tile + sub * Lane4::PITCH_P + ib;
+        const double* tM = tile + sub * Lane4::PITCH_M + 2 * pc;
+        // DMA sources of this lane: trial (block_first + period * sub) for instruction 0, piece rotated by the trial's slot
+        const int64_t tr_step = 8 * period * T;                          // trials from one instruction to the next, in rows
+        const int rot = ((lane & 7) + sub) & 7;
+        const double* gP = io.Pfs + (block_first + (int64_t)period * sub) * T * 16 + 2 * rot;
+        const double* gM = io.mfs + (block_first + (int64_t)period * sub) * T * 4 + 2 * rot;
+        const double* lastP = io.Pfs + (block_first + (int64_t)period * (nvalid - 1)) * T * 16 + 2 * rot;
+        const double* lastM = io.mfs + (block_first + (int64_t)period * (nvalid - 1)) * T * 4 + 2 * rot;
+        const unsigned pbase = (unsigned)(uintptr_t)(LdsDoublePtr)pin, mbase = (unsigned)(uintptr_t)(LdsDoublePtr)min_;
+        const char* pin_b = reinterpret_cast<const char*>(pin);
+        const char* min_b = reinterpret_cast<const char*>(min_);
+        unsigned rd[8];                                                  // this lane's row pieces in a DMA-ed set
+        CGP_UNROLL for (int p = 0; p < 8; p++) rd[p] = lane4_row_piece(lane, p);
+
+        lane4_dma_rows(mbase, gM + (t_hi - 3) * 4, tr_step * 4, sub, nvalid, lastM + (t_hi - 3) * 4);
+        lane4_dma_rows(pbase, gP + t_hi * 16, tr_step * 16, sub, nvalid, lastP + t_hi * 16);
+        int cur = 0;
+        bool first = true;
+        for (int64_t k = nq - 1; k >= 0; k--) {
+            const int64_t a = a_lo + 4 * k;
+            double mq[16], mh[16];
+            CGP_UNROLL for (int s4 = 3; s4 >= 0; s4--) {
+                const int64_t t = a + s4;
+                // this row's covariances were requested a step ago: wait for them, not for the stores issued since (8 covariance stores;
+                // behind the last row of a quad also 8 stores of means)
+                if (first) lane4_wait_vm<0>();
+                else if (s4 == 3) lane4_wait_vm<16>();
+                else lane4_wait_vm<8>();
+                first = false;
+                if (t > a_lo) lane4_dma_rows(pbase + (unsigned)(cur ^ 1) * (Lane4S::ROWS * 8u), gP + (t - 1) * 16, tr_step * 16, sub, nvalid, lastP + (t - 1) * 16);
+                if (s4 == 3) {
+                    CGP_UNROLL for (int p = 0; p < 8; p++) {
+                        const double2 v = *reinterpret_cast<const double2*>(min_b + rd[p]);
+                        mq[2 * p] = v.x; mq[2 * p + 1] = v.y;
+                    }
+                    if (k > 0) lane4_dma_rows(mbase, gM + (a - 4) * 4, tr_step * 4, sub, nvalid, lastM + (a - 4) * 4);
+                }
+                Vec<D> mf; Sym<D> Pf;
+                CGP_UNROLL for (int i = 0; i < D; i++) mf.v[i] = mq[4 * s4 + i];
+                {
+                    const char* row = pin_b + cur * (Lane4S::ROWS * 8);
+                    const double2 p0 = *reinterpret_cast<const double2*>(row + rd[0]), p2 = *reinterpret_cast<const double2*>(row + rd[2]);
+                    const double2 p4 = *reinterpret_cast<const double2*>(row + rd[4]), p5 = *reinterpret_cast<const double2*>(row + rd[5]);
+                    const double2 p6 = *reinterpret_cast<const double2*>(row + rd[6]), p7 = *reinterpret_cast<const double2*>(row + rd[7]);
+                    Pf.a[0] = p0.x; Pf.a[1] = p2.x; Pf.a[2] = p2.y; Pf.a[3] = p4.x; Pf.a[4] = p4.y; Pf.a[5] = p5.x;
+                    Pf.a[6] = p6.x; Pf.a[7] = p6.y; Pf.a[8] = p7.x; Pf.a[9] = p7.y;                 // the lower triangle, like load_sym
+                }
+                step.step(lane, lds, mf, Pf, ms, Ps);
+                {
+                    double* row = tile + (lane & 31) * Lane4::PITCH_P;
+                    CGP_UNROLL for (int h = 0; h < 2; h++) {
+                        if ((lane >> 5) == h) {
+                            CGP_UNROLL for (int c = 0; c < 5; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(Ps.a[2 * c], Ps.a[2 * c + 1]);
+                        }
+                        wave_lds_fence();
+                        CGP_UNROLL for (int i = 0; i < 4; i++)
+                            wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)(4 * h + i) * 8u * rowP);
+                        wave_lds_fence();
+                    }
+                }
+                voffP -= 128u;
+                CGP_UNROLL for (int i = 0; i < D; i++) mh[4 * s4 + i] = ms.v[i];
+                cur ^= 1;
+            }
+            {
+                double* row = tile + (lane & 15) * Lane4::PITCH_M;
+                CGP_UNROLL for (int h = 0; h < 4; h++) {
+                    if ((lane >> 4) == h) {
+                        CGP_UNROLL for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(mh[2 * c], mh[2 * c + 1]);
+                    }
+                    wave_lds_fence();
+                    CGP_UNROLL for (int i = 0; i < 2; i++) {
+                        const double2 v = *reinterpret_cast<const double2*>(tM + i * 8 * Lane4::PITCH_M);
+                        wM.store2(v.x, v.y, voffM + (unsigned)(2 * h + i) * 8u * rowM);
+                    }
+                    wave_lds_fence();
+                }
+            }
+            voffM -= 128u;
+        }
+        for (int64_t t = a_lo - 1; t >= 0; t--) edge(t);
+    }
+}
+
+// period of the smoothers' trial groups: whole lines of four MEANS (p * T a multiple of 4); record lengths from two steps on
+inline int lane4_smoother_period(int64_t T) {
+    int p = 1;
+    while ((p * T) % 4 != 0) p *= 2;
+    return (T * p * 128 * 64 <= kOobMaxBytes) ? p : 1;
+}
+template <class Step>
+inline hipError_t launch_lane4_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    const int period = lane4_smoother_period(io.T);
+    const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+    hipLaunchKernelGGL((lane4_smoother_kernel<Step>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
     return hipGetLastError();
 }
 

@@ -163,6 +163,7 @@ template <int NH> struct HarmonicLCD {
     double M[4], MS[3];
     bool uniform = false;      // set by wave-per-trial EKF-type callers: propagate() then sees a wave-uniform state
     bool wide = false;         // set by latency-bound callers (wave per trial, time-parallel smoother): softplus_pair_sel
+    bool small_angles = false; // set by the large-batch lane kernel (cgp_lane4.hpp): fast_sincos_small in rotations()
     CGP_DEV void setup(const double* __restrict__ p, double dt_, int model_id) {
         dt = dt_;
         if (model_id == 2 /* CGP_M_LASCALA_LCD */) {
@@ -180,7 +181,8 @@ template <int NH> struct HarmonicLCD {
     // recurrence for the overtones (same values as cos(dt k w), sin(dt k w) up to rounding).
     CGP_DEV void rotations(double w, double (&c)[NH], double (&s)[NH]) const {
         double s1, c1;
-        fast_sincos(dt * w, s1, c1);
+        if (small_angles) fast_sincos_small(dt * w, s1, c1);
+        else fast_sincos(dt * w, s1, c1);
         double ck = c1, sk = s1;
         c[0] = c1 * rho; s[0] = s1 * rho;
         CGP_UNROLL for (int k = 1; k < NH; k++) {

@@ -506,6 +506,7 @@ template <class DM, bool WAVE_> struct EkfPredict {
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
+    CGP_DEV void large_batch() { model.small_angles = true; }      // cgp_lane4.hpp
     CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> T;
         model.propagate(mf, Pf, mp, T, Pp);
@@ -533,6 +534,7 @@ template <class DM, bool COLL = false> struct SgpPredictLane {
     static constexpr int D = DM::D; static constexpr bool WAVE = false; static constexpr bool USES_LDS = false;
     DM model; SigmaSet sg;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = false; }
+    CGP_DEV void large_batch() {}
     CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> unused;
         sgp_prediction<DM, false, false, true, COLL>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);

@@ -2,7 +2,8 @@
 the phase of their rows against the 128-byte lines) against the C port of the reference's recursion (filters_smoothers.py:222-264, 446-490)
 on the same inputs: the CRLB jobs' shape (tetralith/jobs/crlb_ekf.py:59-79, crlb_ghf.py:64-75) on a 4096-trial subset at 1e-9, ragged
 batches, record lengths of every line phase and tail, every combination of outputs, shared / indexed records, per-trial models and
-measurement vectors, NaN measurements -- and, at the full 262 144 x 500, size-independent properties."""
+measurement vectors, NaN measurements -- and, at the full 262 144 x 500, size-independent properties.  The backward pass likewise: eks and
+cd_eks one lane per trial (filters_smoothers.py:317-349, 400-443) on the port's own filtering results."""
 import numpy as np
 import pytest
 
@@ -211,3 +212,71 @@ def test_full_size_properties():
         _close(g[idx], w, f'262144 x 500, every 512th trial: {n}')
     P = full[1]
     assert torch.equal(P, P.transpose(-1, -2))
+
+
+@pytest.mark.parametrize('B,T', [(1037, 500), (130, 506), (64, 16), (70, 14), (129, 49), (65, 2), (200, 7), (3, 1001), (257, 511), (100, 5), (64, 3)])
+def test_smoothers_one_lane_per_trial_against_the_port(B, T):
+    """eks and cd_eks through lane4_smoother_kernel (rows by LDS-DMA a step ahead, mean lines a quad ahead, whole-line stores) on the port's
+    filtering results: record lengths of every period (T mod 4 = 0: 1; 2: 2; odd: 4), records with no whole quad of rows, ragged batches;
+    the last smoothing row is the last filtering row bit for bit (filters_smoothers.py:140-142)."""
+    import copy
+    from chirpgp_amd import filters_smoothers as fs, tools
+    from chirpgp_amd.models import model_chirp, disc_chirp_lcd
+    from oracle import port
+    drift, disp, m0, P0, H = model_chirp(0.1, 0.1, 1.0, 1.0, 0.1)
+    mc = disc_chirp_lcd(0.1, 0.1, 1.0, 1.0)
+    dg = copy.copy(drift)
+    dg.gamma = disp.outer()
+    _, yss = tools.simulate_measurements(mc, H, 0.1, m0, P0, 0.01, T, 11 + B, batch=B, states=False)
+    f = port.filter(port.F_EKF, mc, None, H, 0.1, m0, P0, 0.01, yss.cpu().numpy())
+    for name, got, want in (('eks', fs.eks(mc, f[0], f[1], 0.01, **LANE), port.smoother(port.S_EKS, mc, None, 0.01, f[0], f[1])),
+                            ('cd_eks', fs.cd_eks(drift, disp, f[0], f[1], 0.01, **LANE), port.smoother(port.S_CD_EKS, dg, None, 0.01, f[0], f[1]))):
+        for g, w, n in zip(got, want, ('mss', 'Pss')):
+            _close(g, w, f'{name} B={B} T={T} {n}')
+        assert np.array_equal(got[0][:, -1], f[0][:, -1]) and np.array_equal(got[1][:, -1], f[1][:, -1])
+
+
+def test_smoothers_per_trial_models_nan_rows_and_the_lascala_model():
+    """Per-trial parameters; a NaN in a trial's filtering results poisons that trial's smoothing rows from there DOWN (the backward pass)
+    and no other trial; the La Scala model shares the kernel."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from oracle import port
+    B, T = 150, 203
+    rng = np.random.default_rng(8)
+    params = np.array([0.1, 0.1, 0.1, 1., 1., 7.]) * (1 + 0.2 * rng.random((B, 6)))
+    drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+    ys = np.stack([cs.chirp_case(T=T, seed=300 + (b % 5)).ys for b in range(B)]) + 0.05 * rng.standard_normal((B, T))
+    ys[77, 120] = np.nan
+    f = port.filter(port.F_EKF, disc, None, H, 0.1, m0, P0, 1e-3, ys)
+    got = fs.eks(disc, f[0], f[1], 1e-3, **LANE)
+    want = port.smoother(port.S_EKS, disc, None, 1e-3, f[0], f[1])
+    for g, w, n in zip(got, want, ('mss', 'Pss')):
+        cs.assert_close(g, w, RTOL, f'per-trial models {n}')
+    assert np.isnan(got[0][77]).all() and np.isfinite(got[0][76]).all() and np.isfinite(got[0][78]).all()
+    l = cs.lascala_case(T=T, seed=62)
+    ysl = l.ys[None, :] + 0.05 * rng.standard_normal((70, T))
+    fl = port.filter(port.F_EKF, l.disc, None, l.H, l.Xi, l.m0, l.P0, l.dt, ysl)
+    for g, w, n in zip(fs.eks(l.disc, fl[0], fl[1], l.dt, **LANE), port.smoother(port.S_EKS, l.disc, None, l.dt, fl[0], fl[1]), ('mss', 'Pss')):
+        cs.assert_close(g, w, RTOL, f'lascala eks {n}')
+
+
+def test_smoother_full_size_properties():
+    """262 144 x 500 through the DEFAULT eks launch (one lane per trial from 24 trials per SIMD on): every 512th trial against the port at
+    1e-9; the first and last 1024 trials equal a launch of just those, bit for bit; smoothed covariances symmetric to the last bit."""
+    import torch
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    hip, _ = _filters('ekf')
+    mc, H, Xi, m0, P0, dt, yss = _crlb(500, 262144)
+    f = hip(mc, H, Xi, m0, P0, dt, yss)
+    s = fs.eks(mc, f[0], f[1], dt)
+    for sl in (slice(0, 1024), slice(262144 - 1024, 262144)):
+        part = fs.eks(mc, f[0][sl].contiguous(), f[1][sl].contiguous(), dt, **LANE)
+        assert all(torch.equal(p, x[sl]) for p, x in zip(part, s))
+    assert torch.equal(s[1], s[1].transpose(-1, -2)) and bool(torch.isfinite(s[0]).all())
+    sel = np.arange(0, 262144, 512)
+    idx = torch.from_numpy(sel).cuda()
+    fm, fP = f[0][idx].cpu().numpy(), f[1][idx].cpu().numpy()
+    want = port.smoother(port.S_EKS, mc, None, dt, fm, fP)
+    for g, w, n in zip(s, want, ('mss', 'Pss')):
+        _close(g[idx], w, f'262144 x 500, every 512th trial: {n}')
