@@ -479,7 +479,7 @@ def main():
             chunks = B * ((T + 63) // 64)
             regimes['chunks'] = chunks
             regimes['high_share'] = regimes['high'] / chunks if chunks else None
-            regimes['kernel'] = 'ekf4_mfma_kernel (one trial per wavefront)' if (regimes['high'] + regimes['common'] + regimes['redone'] + regimes['checked']) else 'not counted by this launch shape'
+            regimes['kernel'] = 'ekf4_mfma_kernel (one trial per wavefront)' if (regimes['high'] + regimes['common'] + regimes['redone'] + regimes['checked'] + regimes['wide']) else 'not counted by this launch shape'
         filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
         smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
         mine = [elapsed, float(np.mean(filt)) if filt else 0.0, float(np.mean(smooth)) if smooth else 0.0]
@@ -591,7 +591,9 @@ def main():
         """How much the headline depends on its data: the C2 pass (ekf + eks, 1000 x 10^4) over 5 base seeds x measurement
         noise Xi in {0.01, 0.1, 1} x frequency offset in {5.5, 8, 20} Hz of the reference's toy chirp (demos/ekfs_mle.py:16-39 with
         toymodels.py:226-268's law; (seed 0, 0.1, 8) is the headline's record set) -- value = trial-steps/s of each combination from the
-        wall time of `steps` passes, and the regime counters of its filter launch (chunks repeated / run on the checked step)."""
+        wall time of `steps` passes, and the regime counters of its filter launch: chunks kept from the HIGH / common regime of the
+        speculative step, repeated, run on the WIDE step (branch-free full-accuracy softplus: records whose frequency state wanders
+        below 1.5) and on the checked step."""
         from chirpgp_amd import models as pm
         params = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
         drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
@@ -620,7 +622,7 @@ def main():
                     rg = _engine.debug_counters(reset=True)
                     _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
                     rows.append({"seed": seed, "Xi": Xi, "offset_hz": offset, "value": B * T / dt_pass, "ms_per_pass": dt_pass * 1e3,
-                                 "high": rg['high'], "common": rg['common'], "redone": rg['redone'], "checked": rg['checked'], "high_left": rg['high_left']})
+                                 "high": rg['high'], "common": rg['common'], "redone": rg['redone'], "wide": rg['wide'], "checked": rg['checked'], "high_left": rg['high_left']})
                     del r, ys
         torch.cuda.empty_cache()
         vals = np.array([r['value'] for r in rows])
@@ -632,6 +634,7 @@ def main():
                 "slowest_over_median_time": med / float(vals.min()), "slowest": slow,
                 "redone_plus_checked_share_max": max((r['redone'] + r['checked']) / chunks for r in rows),
                 "redone_plus_checked_share_at_reference_inputs": max((r['redone'] + r['checked']) / chunks for r in rows if (r['Xi'], r['offset_hz']) == (0.1, 8.0)),
+                "wide_share_max": max(r['wide'] / chunks for r in rows),
                 "by_offset_median": {str(o): float(np.median([r['value'] for r in rows if r['offset_hz'] == o])) for o in (5.5, 8.0, 20.0)},
                 "by_Xi_median": {str(x): float(np.median([r['value'] for r in rows if r['Xi'] == x])) for x in (0.01, 0.1, 1.0)},
                 "rows": rows}

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* _
         case 3: a = rcp_nr(v); break;
         case 7: softplus_pair_wide(v, a, b); break;
         case 9: a = rcp_nr1(v); break;
+        case 10: { bool ok; softplus_pair_any(v, a, b, ok); if (!ok) { a = __builtin_nan(""); b = a; } break; }      // (not ok -> NaN: the caller's fallback)
         default: softplus_pair(v, a, b); break;
         }
         o0[i] = a;
@@ -365,11 +366,12 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     const bool sde4 = spec && model->model_id == CGP_M_HARMONIC_SDE && model->n_harm == 1;
     const bool mfma = !(flags & CGP_DPP_KERNEL);
     ShapeLimit limit = sig ? ShapeLimit{8, 1} : ShapeLimit{5, 2};
-    // (round 5: where the large-batch lane kernel of cgp_lane4.hpp takes the launch, one lane per trial wins from 5.5 / 14 trials per
-    // SIMD on -- tools/lane_crossover.sh, profiles/r05_lane_crossover.txt: EKF 0.62 against 0.58 ms at 6144 x 500, GH-3 8.6 against 7.7 ms
-    // at 16384 x 500; the generic lane kernel it replaces there kept the round-3 limits of 20 / 24)
+    // (round 5: where the large-batch lane kernel of cgp_lane4.hpp takes the launch, one lane per trial wins from 9 / 14 trials per
+    // SIMD on -- tools/lane_crossover.sh, profiles/r05_lane_crossover.txt: EKF 0.49 against 0.59 ms at 8192 x 500 and 0.71 against 0.59 at
+    // 10 240 (CRLB records, i.e. with the four-trials-per-wavefront kernel on its branch-free wide step), GH-3 8.6 against 7.7 ms at
+    // 16 384 x 500; the generic lane kernel it replaces there kept the round-3 limits of 20 / 24)
     const bool lane4 = spec && lane4_filter_fits(io);
-    if (method == CGP_F_EKF && chirp4 && mfma && !(flags & CGP_ONE_TRIAL_PER_WAVE)) limit = lane4 ? ShapeLimit{11, 2} : ShapeLimit{20, 1};
+    if (method == CGP_F_EKF && chirp4 && mfma && !(flags & CGP_ONE_TRIAL_PER_WAVE)) limit = lane4 ? ShapeLimit{9, 1} : ShapeLimit{20, 1};
     else if (method == CGP_F_EKF && harm8) limit = {8, 1};
     else if (method == CGP_F_SGP && chirp4 && mfma) limit = (lane4 && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes) ? ShapeLimit{14, 1} : ShapeLimit{24, 1};
     else if (method == CGP_F_SGP && harm8) limit = {11, 1};
@@ -573,7 +575,7 @@ int cgp_squared_error_sums(cgp_ctx* ctx, const double* a, const double* r, int64
 
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream) {
     if (!ctx) return CGP_E_ARG;
-    if (n < 0 || op < 0 || op > 9) return fail(ctx, CGP_E_ARG, "bad op or n");
+    if (n < 0 || op < 0 || op > 10) return fail(ctx, CGP_E_ARG, "bad op or n");
     if (n == 0) return CGP_OK;
     if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
     DeviceScope on_device(ctx->device);

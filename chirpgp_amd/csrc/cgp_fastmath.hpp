@@ -180,6 +180,51 @@ CGP_DEV void fast_sincos_small(double x, double& sn, double& cs) {
     fast_sincos(x, sn, cs);
 }
 
+// Softplus log(exp(x) + 1) and its derivative for ANY finite |x| < 700 without a branch, in Estrin form (round 5: the middle tier of the
+// matrix-core EKF, cgp_mfma4.hpp -- records whose frequency state leaves the lean regime x >= 1.5 used to fall all the way to the naive
+// exp + log with their regime branches, three times the step): with t = exp(-|x|) in (0, 1], z = 1 + t in (1, 2],
+//     log(exp(x) + 1) = max(x, 0) + log1p(t),      exp(x) / (exp(x) + 1) = (x > 0 ? 1 : t) / z,
+// log z by the atanh series of fast_log_ge1 (no exponent extraction: z or z / 2 lies in (1 / sqrt 2, sqrt 2]), log1p(t) = log z + (t - (z - 1)) / z
+// (the rounding of 1 + t put back: exact to the last bits also where t vanishes against 1).  ~1e-16 like the naive form; ok = false
+// for |x| >= 700, inf and NaN, where the reference's form overflows (the caller repeats those with the checked step).
+CGP_DEV void softplus_pair_any(double x, double& sp, double& dsp, bool& ok) {
+    const double a = fabs(x);
+    ok = a < 700.0;
+    const double na = -a;
+    const double k = __builtin_rint(na * kLog2e);
+    double r = fma(-k, kLn2Hi, na);
+    r = fma(-k, kLn2Lo, r);
+    // exp(r), |r| <= ln2 / 2: sum r^i / i!, i <= 13, Estrin
+    const double r2 = r * r;
+    const double e0 = fma(r, 1.0, 1.0), e1 = fma(r, 1.0 / 6.0, 0.5), e2 = fma(r, 1.0 / 120.0, 1.0 / 24.0), e3 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+    const double e4 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0), e5 = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0), e6 = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+    const double r4 = r2 * r2;
+    const double f0 = fma(e1, r2, e0), f1 = fma(e3, r2, e2), f2 = fma(e5, r2, e4);
+    const double r8 = r4 * r4;
+    const double g0 = fma(f1, r4, f0), g1 = fma(e6, r4, f2);
+    const double t = __builtin_amdgcn_ldexp(fma(g1, r8, g0), (int)k);
+    const double z = 1.0 + t;
+    const double rz = rcp_nr(z);
+    const bool big = z > 1.4142135623730951;
+    const double m = big ? 0.5 * z : z;
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double sc = fma(fma(-(m + 1.0), s, m - 1.0), rcp_nr1(m + 1.0), s);          // one residual correction of the quotient (<= 1 ulp)
+    const double s2 = sc * sc;
+    // 1/3 + s2/5 + ... + s2^9/21, Estrin
+    const double p0 = fma(s2, 1.0 / 5.0, 1.0 / 3.0), p1 = fma(s2, 1.0 / 9.0, 1.0 / 7.0), p2 = fma(s2, 1.0 / 13.0, 1.0 / 11.0);
+    const double p3 = fma(s2, 1.0 / 17.0, 1.0 / 15.0), p4 = fma(s2, 1.0 / 21.0, 1.0 / 19.0);
+    const double s4 = s2 * s2;
+    const double q0 = fma(p1, s4, p0), q1 = fma(p3, s4, p2);
+    const double s8 = s4 * s4;
+    const double pl = fma(fma(p4, s8, q1), s8, q0);
+    const double two_s = sc + sc;
+    double lz = fma(two_s, pl * s2, two_s);
+    lz = big ? fma(1.0, kLn2Lo, lz) + kLn2Hi : lz;
+    const double l1p = fma(t - (z - 1.0), rz, lz);
+    sp = (x > 0.0 ? x : 0.0) + l1p;
+    dsp = (x > 0.0 ? 1.0 : t) * rz;
+}
+
 // fast_sincos without its fallback branch: ok = false for |x| >= 1e5, inf and NaN (the caller repeats with fast_sincos).
 CGP_DEV void fast_sincos_spec(double x, double& sn, double& cs, bool& ok) {
     ok = fabs(x) < 1.0e5;

@@ -131,6 +131,20 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
     ekf4_mfma_finish_j<E1>(K, y, J0T, K.kja * dsp, x, S, innov);
 }
 
+// The WIDE step (round 5): full-accuracy softplus and sincos WITHOUT regime branches, valid for any |u2| < 700 and |theta| < 1e5
+// (cgp_fastmath.hpp: softplus_pair_any, fast_sincos_spec) -- what a chunk outside the lean regime runs on; `bad` collects the steps outside
+// even that (the chunk is then repeated with the checked step).  Records whose frequency state wanders below 1.5 -- low signal-to-noise,
+// low or high chirp rates: two thirds of bench.py's C2_spread combinations -- ran 3 x slower on the checked step before.
+template <int E1 = 0>
+CGP_DEV void ekf4_mfma_step_wide(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov, bool& bad) {
+    double sp, dsp, s1, c1;
+    bool ok1, ok2;
+    softplus_pair_any(x.u2(), sp, dsp, ok1);
+    fast_sincos_spec(K.ang * sp, s1, c1, ok2);
+    bad = bad || !(ok1 && ok2);
+    ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
+}
+
 // The checked step: full softplus and sincos, regime branches and all (the reference's naive arithmetic anywhere).
 template <int E1 = 0>
 CGP_DEV void ekf4_mfma_step_checked(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
@@ -316,7 +330,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
     int checked_left = 0;
-    unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0;      // chunks by regime (scalars; cgp_debug_counters)
+    unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0, n_wide = 0;      // chunks by regime (scalars; cgp_debug_counters)
     // The rotation pair is re-anchored with the full softplus and sincos (a dependent chain of ~ 70 operations) every FOURTH
     // accepted chunk only (round 4): an accepted chunk hands its last (theta, A, B) to the next one -- one rounding per step in the
     // rotation, 256 steps at most: 3e-14.
@@ -414,15 +428,29 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         if (checked_left > 0 || redo) {
             // a record whose frequency state left the regime probably stays outside: the next chunks go straight to the checked
             // step; a single jump of the angle (code 2 alone) says nothing about the next chunk
-            if (redo) { x = x0; checked_left = (uncommon & 1u) ? kCheckedChunks : 1; n_redo++; } else n_checked++;
+            if (redo) { x = x0; checked_left = (uncommon & 1u) ? kCheckedChunks : 1; n_redo++; }
+            // first on the wide step (branch-free, any |u2| < 700); a chunk that leaves even that is repeated with the checked step
+            bool bad = false;
             for (int slot = 0; slot < nsteps; slot++) {
                 double S, innov;
-                ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
+                ekf4_mfma_step_wide<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov, bad);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pw.store_s(x.P, p_off, t * 128u);
                 mw.store_s(x.uq, m_off, t * 32u);
             }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+                x = x0;
+                for (int slot = 0; slot < nsteps; slot++) {
+                    double S, innov;
+                    ekf4_mfma_step_checked<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov);
+                    park[slot * kParkStride] = make_double2(S, innov);
+                    const unsigned t = (unsigned)(t0 + slot);
+                    Pw.store_s(x.P, p_off, t * 128u);
+                    mw.store_s(x.uq, m_off, t * 32u);
+                }
+                if (!redo) n_checked++;
+            } else if (!redo) n_wide++;
             checked_left--;
         }
         if (want_nll && !burn) {
@@ -439,7 +467,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     if (io.counters && lane == 0) {
         atomicAdd(io.counters + 0, (unsigned long long)n_high); atomicAdd(io.counters + 1, (unsigned long long)n_common);
         atomicAdd(io.counters + 2, (unsigned long long)n_redo); atomicAdd(io.counters + 3, (unsigned long long)n_checked);
-        atomicAdd(io.counters + 4, (unsigned long long)n_high_left);
+        atomicAdd(io.counters + 4, (unsigned long long)n_high_left); atomicAdd(io.counters + 5, (unsigned long long)n_wide);
     }
 }
 
@@ -571,7 +599,16 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 template <int E1 = 0>
 CGP_DEV void ekf4_mfma_step_checked_lane(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov) {
     double sp, dsp, s1, c1;
-    softplus_pair_wide(x.u2(), sp, dsp);
+    // (round 5: the branch-free softplus for any |u2| < 700 first -- softplus_pair_wide's fast form holds for u2 >= 1.5 only, and a record
+    // that is here has usually left that regime; beyond 700, inf and NaN take the reference's naive form)
+    bool ok;
+    softplus_pair_any(x.u2(), sp, dsp, ok);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        double sp_n, dsp_n;
+        softplus_pair(x.u2(), sp_n, dsp_n);
+        sp = ok ? sp : sp_n;
+        dsp = ok ? dsp : dsp_n;
+    }
     fast_sincos(K.ang * sp, s1, c1);
     ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }

@@ -64,7 +64,7 @@ def test_default_line_carries_the_other_baseline_configs():
     assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'CRLB_ghf', 'C2_spread', 'time_split_filters'}
     # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
     rg = r['regimes']
-    assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['checked'] == rg['chunks']
+    assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['wide'] + rg['checked'] == rg['chunks']
     assert 0.7 < rg['high_share'] < 0.85 and rg['high_left'] < 0.05 * rg['chunks'] and rg['redone'] < 0.01 * rg['chunks']
     low = oc['C2_low_freq']
     assert (low['batch_per_gpu'], low['T'], low['d']) == (1000, 10000, 4) and low['filter_ms'] > 0 and low['smoother_ms'] > 0

@@ -148,3 +148,20 @@ def test_rcp():
     x = np.concatenate([10 ** rng.uniform(-200, 200, 3000) * rng.choice([-1, 1], 3000), [1., 0.1, 3.]])
     got, _ = E.debug_math(3, x)
     assert np.max(np.abs(got * x - 1.0)) < 4e-16
+
+
+def test_branch_free_softplus_pair_for_any_argument():
+    """softplus_pair_any (cgp_fastmath.hpp; the WIDE step of the matrix-core EKF): log(exp(x) + 1) and its derivative for every finite
+    |x| < 700 -- negative arguments, the crossover at 0, the region where exp(-|x|) vanishes against 1 -- to a few ulp of a 200-bit
+    reference; |x| >= 700, inf and NaN are reported invalid (the kernel then takes the reference's naive form)."""
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-50, 50, 4000), rng.uniform(-699, 699, 1000), rng.uniform(-2, 2, 1000),
+                        [0., 1e-300, -1e-300, 1.5, -1.5, 36.7, -36.7, 40., -40., 699.9, -699.9, np.log(np.sqrt(2.) - 1.), np.log(np.sqrt(2.) - 1.) + 1e-12]])
+    sp, dsp = E.debug_math(10, x)
+    assert _ulp_err(sp, [mp.log1p(mp.exp(mp.mpf(float(v)))) for v in x]) < 2e-15          # (log1p: at 200 bits 1 + exp(-300) is 1)
+    assert _ulp_err(dsp, [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x]) < 2e-15
+    bad, _ = E.debug_math(10, np.array([700., -700., 1e4, np.inf, -np.inf, np.nan]))
+    assert np.isnan(bad).all()

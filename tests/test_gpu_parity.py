@@ -998,6 +998,35 @@ def test_rotation_increments_at_the_admitted_bound():
     assert (over > 1.0).sum() >= 5 and 3 <= c30['redone'] <= 16 and c30['checked'] == 0      # beyond it: that chunk repeated, nothing sticky
 
 
+def test_wide_step_for_records_outside_the_lean_regime():
+    """Records whose frequency state lives below 1.5 or wanders through it (a chirp the filter never locks on: 20 Hz against an initial
+    7; a start at 0.5 on a 1 - 2 Hz chirp; a negative start): the matrix-core EKF runs their chunks on the WIDE step (branch-free
+    softplus for any |state| < 700, cgp_fastmath.hpp: softplus_pair_any) -- counted by the kernel -- within 1e-9 of the C port, and only
+    a state beyond 700 (exp overflows in the reference's naive softplus: NaN from there on, in the same places) falls through to the checked step."""
+    import bench
+    from chirpgp_amd import filters_smoothers as fs, models as pm, _engine
+    from oracle import port
+    T, B = 3000, 6
+    for m0_v, off, label in ((7.0, 20.0, 'no lock'), (0.5, 1.0, 'low'), (-3.0, 2.0, 'negative start'), (705.0, 8.0, 'overflow')):
+        _, _, disc, m0, P0, H = pm.build_chirp_model(np.array([0.1, 0.1, 0.1, 1., 1., m0_v]))
+        ys = bench.chirp_batch(B, T, 5, Xi=0.1, offset=off)
+        want = port.filter(port.F_EKF, disc, None, H, 0.1, m0, P0, 1e-3, ys)
+        _engine.debug_set(_engine.DBG_COUNT_REGIMES, 1)
+        _engine.debug_counters(reset=True)
+        got = fs.ekf(disc, H, 0.1, m0, P0, 1e-3, ys, **WAVE)
+        rg = _engine.debug_counters(reset=True)
+        _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
+        print(label, rg, [f'{cs.max_rel_err(g, w):.1e}' for g, w in zip(got, want)])
+        for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+            assert cs.max_rel_err(g, w) <= 1e-9, (label, n, cs.max_rel_err(g, w))
+        chunks = B * ((T + 63) // 64)
+        assert rg['high'] + rg['common'] + rg['redone'] + rg['wide'] + rg['checked'] == chunks
+        if label == 'overflow':
+            assert rg['checked'] > 0
+        else:
+            assert rg['wide'] > 0.2 * chunks and rg['checked'] == 0, (label, rg)
+
+
 @pytest.mark.parametrize('nh', [2, 3])
 def test_tile_layout_sigma_filter_axial_and_rotated_cubature(nh):
     """The d = 6 / 8 tile-layout sigma-point filter takes ONE square root per lane and step when every sigma point sits on one axis
