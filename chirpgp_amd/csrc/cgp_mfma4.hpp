@@ -431,14 +431,22 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             if (redo) { x = x0; checked_left = (uncommon & 1u) ? kCheckedChunks : 1; n_redo++; }
             // first on the wide step (branch-free, any |u2| < 700); a chunk that leaves even that is repeated with the checked step
             bool bad = false;
-            for (int slot = 0; slot < nsteps; slot++) {
+            auto wide_one = [&](int slot, double y) {
                 double S, innov;
-                ekf4_mfma_step_wide<E1 ? 2 : 0>(K, readlane_f64(ychunk, slot), x, S, innov, bad);
+                ekf4_mfma_step_wide<E1 ? 2 : 0>(K, y, x, S, innov, bad);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pw.store_s(x.P, p_off, t * 128u);
                 mw.store_s(x.uq, m_off, t * 32u);
+            };
+            // four steps as straight-line code with their measurements read from LDS (a v_readlane pair per step: 24 issue cycles)
+            if (checked_left > 0 && !redo) { ybuf[lane] = ychunk; wave_lds_fence(); }      // (a speculative pass has staged them already)
+            int wslot = 0;
+            for (; wslot + 4 <= nsteps; wslot += 4) {
+                const double2 ya = *reinterpret_cast<const double2*>(ybuf + wslot), yb = *reinterpret_cast<const double2*>(ybuf + wslot + 2);
+                wide_one(wslot, ya.x); wide_one(wslot + 1, ya.y); wide_one(wslot + 2, yb.x); wide_one(wslot + 3, yb.y);
             }
+            for (; wslot < nsteps; wslot++) wide_one(wslot, readlane_f64(ychunk, wslot));
             if (__builtin_amdgcn_ballot_w64(bad) != 0) {
                 x = x0;
                 for (int slot = 0; slot < nsteps; slot++) {
