@@ -37,6 +37,20 @@ CGP_DEV double horner(double p, double x, double c) {
 #endif
 }
 
+// A Horner step whose addend is a compile-time CONSTANT.  CGP_HORNER_SGPR (the large-batch lane kernels, cgp_inst_lane4.hip): the constant as
+// the instruction's one SCALAR operand -- three-address, no register pair pinned per coefficient, and none of the v_mov_b64 the compiler
+// puts in front of a two-address v_fmac_f64 to load the constant into the destination (58 of them per step in the lane EKF; the scalar
+// moves that materialise the constants issue beside the other wavefront's vector instructions).
+CGP_DEV double horner_c(double p, double x, double c) {
+#ifdef CGP_HORNER_SGPR
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "s"(c));
+    return d;
+#else
+    return horner(p, x, c);
+#endif
+}
+
 // 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
 CGP_DEV double rcp_nr(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -65,19 +79,19 @@ CGP_DEV double div_nr(double n, double d) {
 // kernels, which have other work to overlap; it pays only in the cooperative EKF, see softplus_pair_uniform below.)
 CGP_DEV double exp_poly(double r) {
     double p = 1.0 / 6227020800.0;
-    p = horner(p, r, 1.0 / 479001600.0);
-    p = horner(p, r, 1.0 / 39916800.0);
-    p = horner(p, r, 1.0 / 3628800.0);
-    p = horner(p, r, 1.0 / 362880.0);
-    p = horner(p, r, 1.0 / 40320.0);
-    p = horner(p, r, 1.0 / 5040.0);
-    p = horner(p, r, 1.0 / 720.0);
-    p = horner(p, r, 1.0 / 120.0);
-    p = horner(p, r, 1.0 / 24.0);
-    p = horner(p, r, 1.0 / 6.0);
-    p = horner(p, r, 0.5);
-    p = horner(p, r, 1.0);
-    return horner(p, r, 1.0);
+    p = horner_c(p, r, 1.0 / 479001600.0);
+    p = horner_c(p, r, 1.0 / 39916800.0);
+    p = horner_c(p, r, 1.0 / 3628800.0);
+    p = horner_c(p, r, 1.0 / 362880.0);
+    p = horner_c(p, r, 1.0 / 40320.0);
+    p = horner_c(p, r, 1.0 / 5040.0);
+    p = horner_c(p, r, 1.0 / 720.0);
+    p = horner_c(p, r, 1.0 / 120.0);
+    p = horner_c(p, r, 1.0 / 24.0);
+    p = horner_c(p, r, 1.0 / 6.0);
+    p = horner_c(p, r, 0.5);
+    p = horner_c(p, r, 1.0);
+    return horner_c(p, r, 1.0);
 }
 
 // exp(x): x = k ln2 + r, Taylor of degree 13 on |r| <= ln2 / 2 (truncation 4e-18), v_ldexp_f64.
@@ -106,15 +120,15 @@ CGP_DEV double fast_log_ge1(double z) {
     const double s = div_nr(f, m + 1.0);
     const double s2 = s * s;
     double p = 1.0 / 21.0;
-    p = horner(p, s2, 1.0 / 19.0);
-    p = horner(p, s2, 1.0 / 17.0);
-    p = horner(p, s2, 1.0 / 15.0);
-    p = horner(p, s2, 1.0 / 13.0);
-    p = horner(p, s2, 1.0 / 11.0);
-    p = horner(p, s2, 1.0 / 9.0);
-    p = horner(p, s2, 1.0 / 7.0);
-    p = horner(p, s2, 1.0 / 5.0);
-    p = horner(p, s2, 1.0 / 3.0);
+    p = horner_c(p, s2, 1.0 / 19.0);
+    p = horner_c(p, s2, 1.0 / 17.0);
+    p = horner_c(p, s2, 1.0 / 15.0);
+    p = horner_c(p, s2, 1.0 / 13.0);
+    p = horner_c(p, s2, 1.0 / 11.0);
+    p = horner_c(p, s2, 1.0 / 9.0);
+    p = horner_c(p, s2, 1.0 / 7.0);
+    p = horner_c(p, s2, 1.0 / 5.0);
+    p = horner_c(p, s2, 1.0 / 3.0);
     const double two_s = s + s;
     double lm = fma(two_s, p * s2, two_s);
     lm = fma(k, kLn2Lo, lm);
@@ -126,20 +140,20 @@ CGP_DEV double fast_log_ge1(double z) {
 CGP_DEV void sincos_reduced(double r, double& s0, double& c0) {
     const double r2 = r * r;
     double ps = -1.0 / 355687428096000.0;          // -1/17!
-    ps = horner(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
-    ps = horner(ps, r2, -1.0 / 6227020800.0);         // -1/13!
-    ps = horner(ps, r2, 1.0 / 39916800.0);            //  1/11!
-    ps = horner(ps, r2, -1.0 / 362880.0);             // -1/9!
-    ps = horner(ps, r2, 1.0 / 5040.0);                //  1/7!
-    ps = horner(ps, r2, -1.0 / 120.0);                // -1/5!
-    ps = horner(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
+    ps = horner_c(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
+    ps = horner_c(ps, r2, -1.0 / 6227020800.0);         // -1/13!
+    ps = horner_c(ps, r2, 1.0 / 39916800.0);            //  1/11!
+    ps = horner_c(ps, r2, -1.0 / 362880.0);             // -1/9!
+    ps = horner_c(ps, r2, 1.0 / 5040.0);                //  1/7!
+    ps = horner_c(ps, r2, -1.0 / 120.0);                // -1/5!
+    ps = horner_c(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
     double pc = 1.0 / 20922789888000.0;            //  1/16!
-    pc = horner(pc, r2, -1.0 / 87178291200.0);        // -1/14!
-    pc = horner(pc, r2, 1.0 / 479001600.0);           //  1/12!
-    pc = horner(pc, r2, -1.0 / 3628800.0);            // -1/10!
-    pc = horner(pc, r2, 1.0 / 40320.0);               //  1/8!
-    pc = horner(pc, r2, -1.0 / 720.0);                // -1/6!
-    pc = horner(pc, r2, 1.0 / 24.0);                  //  1/4!
+    pc = horner_c(pc, r2, -1.0 / 87178291200.0);        // -1/14!
+    pc = horner_c(pc, r2, 1.0 / 479001600.0);           //  1/12!
+    pc = horner_c(pc, r2, -1.0 / 3628800.0);            // -1/10!
+    pc = horner_c(pc, r2, 1.0 / 40320.0);               //  1/8!
+    pc = horner_c(pc, r2, -1.0 / 720.0);                // -1/6!
+    pc = horner_c(pc, r2, 1.0 / 24.0);                  //  1/4!
     s0 = fma(-(r * r2), ps, r);                       // r - r^3 (1/3! - r^2/5! + ...)
     c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));        // 1 - r^2/2 + r^4 (1/4! - ...)
 }

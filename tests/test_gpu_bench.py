@@ -104,25 +104,27 @@ def test_default_line_carries_the_other_baseline_configs():
             assert 0 < rf['frac'] < 1
 
 
-def test_six_rank_rehearsal_of_the_scaling_command():
-    """First contact with a multi-GPU node should be uneventful: the driver's N > 1 command with the default shapes on SIX ranks sharing
-    the one GPU (the box allows six processes on its card -- an 8-rank rehearsal is not permitted here; world = 8 itself is covered on CPU
-    by tests/test_dist_gloo.py) -- the parent spawns a fresh child (never re-execs), every rank goes through the headline, the strong C2
-    figure, other_configs and the gathers, rank 0 alone times the host CPU once, and the whole run stays far inside the driver's 600 s."""
+def test_three_rank_rehearsal_of_the_scaling_command():
+    """First contact with a multi-GPU node should be uneventful: the driver's N > 1 command with the default shapes on THREE ranks sharing
+    the one GPU -- the box admits six processes on its card and this test runner is one of them (a six-rank rehearsal was killed by the
+    box's process guard: 8 processes on the GPU); world = 8 itself, with empty shards, is covered on CPU by tests/test_dist_gloo.py.  The
+    parent spawns a fresh child (never re-execs), every rank goes through the headline, the strong C2 figure (ragged: 334 + 334 + 332),
+    other_configs and the gathers, rank 0 alone times the host CPU once, and the whole run stays far inside the driver's 600 s."""
     import time
     t0 = time.time()
-    r = _run('--gpus', '6', '--rehearse', '--steps', '2', '--warmup', '1', '--other-steps', '1')
+    r = _run('--gpus', '3', '--rehearse', '--steps', '2', '--warmup', '1', '--other-steps', '1')
     took = time.time() - t0
-    assert r['n_gpus'] == 6 and r['ranks_seen'] == 6 and r['collectives'].startswith('gloo')
-    assert r['scaling'] == 'weak' and r['config']['batch_per_gpu'] == 1000 and r['config']['global_batch'] == 6000
-    assert r['strong']['global_batch'] == 1000 and r['strong']['batch_per_gpu'] == 167 and r['strong']['gather_ms'] is not None
+    assert r['n_gpus'] == 3 and r['ranks_seen'] == 3 and r['collectives'].startswith('gloo')
+    assert r['scaling'] == 'weak' and r['config']['batch_per_gpu'] == 1000 and r['config']['global_batch'] == 3000
+    assert r['strong']['global_batch'] == 1000 and r['strong']['batch_per_gpu'] == 334 and r['strong']['gather_ms'] is not None
     assert r['gather_ms'] is not None and r['gather_ms'] >= 0
     oc = r['other_configs']
-    assert oc['C3']['batch_per_gpu'] == 167 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 167
-    assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 6 * 512 and oc['C1']['global_batch'] == 6
+    assert oc['C3']['batch_per_gpu'] == 334 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 334
+    assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 3 * 512 and oc['C1']['global_batch'] == 3
+    assert oc['CRLB_ekf']['batch_per_gpu'] == 262144 // 3
     assert 'C2_spread' not in oc                                       # a single-GPU diagnostic: not repeated on every rank
     assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0
-    print(f'six-rank rehearsal of the default line: {took:.0f} s')
+    print(f'three-rank rehearsal of the default line: {took:.0f} s')
     assert took < 400, took
 
 
@@ -136,6 +138,6 @@ def test_two_rank_rehearsal_of_the_default_line():
     oc = r['other_configs']
     assert oc['C3']['batch_per_gpu'] == 500 and oc['C3']['global_batch'] == 1000 and oc['C5']['batch_per_gpu'] == 500
     assert oc['C4']['batch_per_gpu'] == 512 and oc['C4']['global_batch'] == 1024 and oc['C1']['global_batch'] == 2
-    assert all(v['value'] > 0 and v['filter_ms'] > 0 for k, v in oc.items() if k not in ('CRLB_ekf', 'time_split_filters'))
+    assert all(v['value'] > 0 and v['filter_ms'] > 0 for k, v in oc.items() if k not in ('CRLB_ekf', 'CRLB_ghf', 'time_split_filters'))
     assert oc['CRLB_ekf']['full_outputs']['filter_ms'] > 0
     assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['one_core']['value'] > 0
