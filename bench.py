@@ -342,6 +342,9 @@ def roofline_of(kind, B, T, d, filt_ms, smooth_ms, bench_shape=False):
     algo_tflops = algo * units / (pass_ms * 1e-3) / 1e12 if (algo and pass_ms) else None
     hbm["algorithmic_tflops"] = algo_tflops
     hbm["algorithmic_frac"] = algo_tflops / F64_VALU_PEAK_TFLOPS if algo_tflops is not None else None
+    hbm["algorithmic_convention"] = ("SURVEY.md 8d's op count of the REFERENCE's formulas per trial-step, a transcendental priced at 30 flop-equivalents: a "
+                                     "convention for useful work that is comparable across rounds and kernels -- an upper bound on it (the engine's polynomials "
+                                     "execute fewer operations per transcendental), not a measurement; `frac` beside it counts executed instructions")
     if bound != 'valu_f64':
         return hbm
     # sigma-point / RK4 workloads: 80-220 flop per byte against a machine balance of ~10, so the
@@ -355,7 +358,7 @@ def roofline_of(kind, B, T, d, filt_ms, smooth_ms, bench_shape=False):
             "achieved": iss["executed_tflops"] if iss else None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": iss["executed_tflops"] / F64_VALU_PEAK_TFLOPS if iss else None,
             "frac_counts": "executed wave-instructions x 64 lanes (replicated lanes included): issue occupancy, not useful work",
-            "algorithmic_tflops": algo_tflops, "algorithmic_frac": hbm["algorithmic_frac"],
+            "algorithmic_tflops": algo_tflops, "algorithmic_frac": hbm["algorithmic_frac"], "algorithmic_convention": hbm["algorithmic_convention"],
             "algorithmic_flop_per_trial_step": algo,
             "executed_flop_source": iss["source"] if iss else (None if profiled_shape else f"withheld: profiled at B = {WORKLOADS[kind][1]} per GPU, this launch has B = {B}"),
             "valu_per_step": iss["valu_per_step"] if iss else None, "f64_per_step": iss["f64_per_step"] if iss else None,

@@ -59,7 +59,13 @@ def test_default_line_carries_the_other_baseline_configs():
     """The driver's command (default workload and sizes, fewer steps): C1, C3, C4, C5 ride on the same JSON line, each with its
     kernel times, throughput and both roofline fractions (executed and algorithmic) for the float64-bound ones."""
     r = _run('--steps', '3', '--warmup', '1', '--other-steps', '1', '--no-cpu-baseline')
-    assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000 and r['roofline']['traffic'] is not None
+    assert r['config']['batch_per_gpu'] == 1000 and r['config']['T'] == 10000
+    # counter traffic is quoted only from a profile of the very library that ran (sha256 recorded in profiles/r05_ekf_pmc.json); any other
+    # library gets null and the reason -- never a stale figure
+    rf0 = r['roofline']
+    assert rf0['traffic'] is not None or 'counters withheld' in rf0['traffic_source'], rf0
+    if rf0['traffic'] is not None:
+        assert 0.99 < rf0['traffic'] / rf0['algorithmic_bytes_per_launch'] < 1.05 and 'sha256' in rf0['traffic_source']
     oc = r['other_configs']
     assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'CRLB_ghf', 'C2_spread', 'time_split_filters'}
     # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
@@ -102,6 +108,9 @@ def test_default_line_carries_the_other_baseline_configs():
         # round 4 the algorithmic figure of C3 exceeds the executed one: the two are reported side by side, not ordered)
         if rf['frac'] is not None:
             assert 0 < rf['frac'] < 1
+            # the two columns are labelled for what they are (`algorithmic_convention`) and may not drift apart silently: useful work
+            # priced by the convention stays within 25 % above the executed figure (C3 today: 1.03 x; C4, C5 below 1)
+            assert rf['algorithmic_frac'] <= 1.25 * rf['frac'] and 'convention' in rf['algorithmic_convention']
 
 
 def test_three_rank_rehearsal_of_the_scaling_command():
