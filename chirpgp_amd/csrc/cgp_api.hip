@@ -366,14 +366,14 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     const bool sde4 = spec && model->model_id == CGP_M_HARMONIC_SDE && model->n_harm == 1;
     const bool mfma = !(flags & CGP_DPP_KERNEL);
     ShapeLimit limit = sig ? ShapeLimit{8, 1} : ShapeLimit{5, 2};
-    // (round 5: where the large-batch lane kernel of cgp_lane4.hpp takes the launch, one lane per trial wins from 9 / 14 trials per
+    // (round 5: where the large-batch lane kernel of cgp_lane4.hpp takes the launch, one lane per trial wins from 9 / 9 trials per
     // SIMD on -- tools/lane_crossover.sh, profiles/r05_lane_crossover.txt: EKF 0.49 against 0.59 ms at 8192 x 500 and 0.71 against 0.59 at
-    // 10 240 (CRLB records, i.e. with the four-trials-per-wavefront kernel on its branch-free wide step), GH-3 8.6 against 7.7 ms at
-    // 16 384 x 500; the generic lane kernel it replaces there kept the round-3 limits of 20 / 24)
+    // 10 240 (CRLB records, i.e. with the four-trials-per-wavefront kernel on its branch-free wide step), GH-3 4.3 against 5.0 ms at
+    // 8192 x 500 and 6.5 against 5.0 at 12 288 (after the lane kernel's fan stopped running twice on records outside the lean regime); the generic lane kernel it replaces there kept the round-3 limits of 20 / 24)
     const bool lane4 = spec && lane4_filter_fits(io);
     if (method == CGP_F_EKF && chirp4 && mfma && !(flags & CGP_ONE_TRIAL_PER_WAVE)) limit = lane4 ? ShapeLimit{9, 1} : ShapeLimit{20, 1};
     else if (method == CGP_F_EKF && harm8) limit = {8, 1};
-    else if (method == CGP_F_SGP && chirp4 && mfma) limit = (lane4 && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes) ? ShapeLimit{14, 1} : ShapeLimit{24, 1};
+    else if (method == CGP_F_SGP && chirp4 && mfma) limit = (lane4 && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes) ? ShapeLimit{9, 1} : ShapeLimit{24, 1};
     else if (method == CGP_F_SGP && harm8) limit = {11, 1};
     else if (method == CGP_F_CD_EKF && sde4 && mfma) limit = {4, 1};
     else if (method == CGP_F_CD_SGP && sde4 && mfma) limit = {48, 1};

@@ -332,6 +332,25 @@ CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaS
     const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
 }
+// The same for a caller that evaluates the fan step after step on the same 64 trials (one lane per trial, cgp_lane4.hpp): a wavefront
+// whose speculative pass failed -- a lane's frequency state below 1.5: the CRLB jobs' records, a zero-mean GP, in every step -- pays the
+// speculative AND the checked fan, 5852 vector instructions per step at GH-3; it goes straight to the checked fan for the next
+// kSpecSkip steps instead (`skip`: wave-uniform, kept by the caller).
+constexpr int kSpecSkip = 16;
+template <bool CROSS, bool ST>
+CGP_DEV void sgp4_prediction_collapsed_sticky(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
+                                              Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT, int& skip) {
+    if (skip > 0) {
+        skip--;
+        sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+        return;
+    }
+    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+        skip = kSpecSkip;
+    }
+}
 // The same regrouping for n harmonics (d = 2 n + 2; rotating components a < 2 n, linear pair v = 2 n, v + 1), one lane doing
 // all groups: with d = L xi restricted to xi_0..d-2 and g_a = f_a(m + d) of a group's representative,
 //     mp_a = sum W g_a,   Pp_ab = sum W g_a g_b - mp_a mp_b + q delta_ab,   Pp_{a, v+b} = sum_c M_bc (sum W g_a d_{v+c}),
@@ -533,10 +552,14 @@ template <class DM, bool COLL = false> struct SgpPredictLane {
     static constexpr bool LANE_TWO_WAVES = false;
     static constexpr int D = DM::D; static constexpr bool WAVE = false; static constexpr bool USES_LDS = false;
     DM model; SigmaSet sg;
+    mutable int skip = 0;                      // steps left on the checked fan (sgp4_prediction_collapsed_sticky)
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = false; }
     CGP_DEV void large_batch() {}
     CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> unused;
+        if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) {
+            if (COLL || sgp_collapsible<DM>(sg)) { sgp4_prediction_collapsed_sticky<false, true>(model, sg, mf, Pf, mp, Pp, unused, skip); return; }
+        }
         sgp_prediction<DM, false, false, true, COLL>(model, sg, lane, lds, mf, Pf, mp, Pp, unused);
     }
 };
