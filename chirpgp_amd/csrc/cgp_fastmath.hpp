@@ -136,6 +136,31 @@ CGP_DEV double fast_log_ge1(double z) {
     return (z == __builtin_inf()) ? z : y;
 }
 
+// fast_log_ge1 for a FINITE z >= 1 with the exponent taken so that the mantissa lands in [sqrt(1/2), sqrt(2)) directly: k = exponent of
+// z sqrt(2), m = z 2^-k (exact) -- five instructions where frexp + the compare-and-select adjustment of fast_log_ge1 take nine.  (The
+// rounding of z sqrt(2) can leave m an ulp outside the interval at its ends: the series does not care.)
+CGP_DEV double fast_log_ge1_finite(double z) {
+    const int e = __builtin_amdgcn_frexp_exp(z * 1.4142135623730951) - 1;
+    const double m = __builtin_amdgcn_ldexp(z, -e);
+    const double k = (double)e;
+    const double s = div_nr(m - 1.0, m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 21.0;
+    p = horner_c(p, s2, 1.0 / 19.0);
+    p = horner_c(p, s2, 1.0 / 17.0);
+    p = horner_c(p, s2, 1.0 / 15.0);
+    p = horner_c(p, s2, 1.0 / 13.0);
+    p = horner_c(p, s2, 1.0 / 11.0);
+    p = horner_c(p, s2, 1.0 / 9.0);
+    p = horner_c(p, s2, 1.0 / 7.0);
+    p = horner_c(p, s2, 1.0 / 5.0);
+    p = horner_c(p, s2, 1.0 / 3.0);
+    const double two_s = s + s;
+    double lm = fma(two_s, p * s2, two_s);
+    lm = fma(k, kLn2Lo, lm);
+    return fma(k, kLn2Hi, lm);
+}
+
 // sin(r), cos(r) on the reduced range |r| <= pi/4: Taylor to r^17 / r^16 (truncation 5e-17), two independent Horner chains.
 CGP_DEV void sincos_reduced(double r, double& s0, double& c0) {
     const double r2 = r * r;

@@ -153,16 +153,20 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
             if (nll_rows) *nll_slot = cum;
         }
         if constexpr (want_P) {
+            // two passes of 32 trials through the tile; the second is written right behind the reads of the first (DS instructions of a
+            // wavefront execute in order), so the reads' latency is paid once a step
             double* row = tile + (lane & 31) * Lane4::PITCH_P;
+            double pa[2][4], pb[2][4];
             CGP_UNROLL for (int h = 0; h < 2; h++) {
                 if ((lane >> 5) == h) {
                     CGP_UNROLL for (int c = 0; c < 5; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(Pf.a[2 * c], Pf.a[2 * c + 1]);
                 }
                 wave_lds_fence();
-                CGP_UNROLL for (int i = 0; i < 4; i++)
-                    wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)(4 * h + i) * 8u * rowP);
+                CGP_UNROLL for (int i = 0; i < 4; i++) { pa[h][i] = tPa[i * 8 * Lane4::PITCH_P]; pb[h][i] = tPb[i * 8 * Lane4::PITCH_P]; }
                 wave_lds_fence();
             }
+            CGP_UNROLL for (int h = 0; h < 2; h++)
+                CGP_UNROLL for (int i = 0; i < 4; i++) wP.store2(pa[h][i], pb[h][i], voffP + (unsigned)(4 * h + i) * 8u * rowP);
         }
         if constexpr (want_P) voffP += 128u;
     };
@@ -252,18 +256,26 @@ __global__ void __launch_bounds__(64) lane4_filter_kernel(FilterIO io, ModelArgs
             step(y23.y, yq + 129);
             CGP_UNROLL for (int i = 0; i < D; i++) mh[12 + i] = mf.v[i];
             if (want_m) {
+                // four passes of 16 trials through the tile.  A wavefront's DS instructions execute in order, so pass h + 1 may be WRITTEN
+                // right behind the reads of pass h, before their data is back: the reads' latency is paid once a quad, not four times
+                // (the stores of pass h follow the reads of pass h + 1; the compiler counts lgkmcnt for them)
                 double* row = tile + (lane & 15) * Lane4::PITCH_M;
+                double2 va[4], vb[4];
                 CGP_UNROLL for (int h = 0; h < 4; h++) {
                     if ((lane >> 4) == h) {
                         CGP_UNROLL for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(row + 2 * c) = make_double2(mh[2 * c], mh[2 * c + 1]);
                     }
                     wave_lds_fence();
-                    CGP_UNROLL for (int i = 0; i < 2; i++) {
-                        const double2 v = *reinterpret_cast<const double2*>(tM + i * 8 * Lane4::PITCH_M);
-                        wM.store2(v.x, v.y, voffM + (unsigned)(2 * h + i) * 8u * rowM);
-                    }
+                    va[h] = *reinterpret_cast<const double2*>(tM);
+                    vb[h] = *reinterpret_cast<const double2*>(tM + 8 * Lane4::PITCH_M);
                     wave_lds_fence();
+                    if (h > 0) {
+                        wM.store2(va[h - 1].x, va[h - 1].y, voffM + (unsigned)(2 * h - 2) * 8u * rowM);
+                        wM.store2(vb[h - 1].x, vb[h - 1].y, voffM + (unsigned)(2 * h - 1) * 8u * rowM);
+                    }
                 }
+                wM.store2(va[3].x, va[3].y, voffM + 6u * 8u * rowM);
+                wM.store2(vb[3].x, vb[3].y, voffM + 7u * 8u * rowM);
             }
             voffM += 128u;
         }
@@ -464,6 +476,8 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                 cur ^= 1;
             }
             {
+                // (the passes are NOT pipelined as in the filter: at one wavefront per SIMD with all 256 registers taken, the reads held back
+                // cost more than their latency -- eks 7.4 - 7.9 -> 8.15 ms per 262 144 x 500, measured)
                 double* row = tile + (lane & 15) * Lane4::PITCH_M;
                 CGP_UNROLL for (int h = 0; h < 4; h++) {
                     if ((lane >> 4) == h) {

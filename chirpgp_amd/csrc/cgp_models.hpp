@@ -74,6 +74,23 @@ CGP_DEV void softplus_pair(double x, double& sp, double& dsp) {
     dsp = e * rcp_nr(z);            // inf * NaN = NaN where the reference has inf / inf = NaN
 }
 CGP_DEV double softplus(double x) { return fast_log_ge1(fast_exp(x) + 1.0); }
+// The naive form for the large-batch lane kernels (cgp_lane4.hpp), which are bound by their vector instruction count: exp and log without
+// their overflow / underflow / inf selects and with the direct exponent extraction (cgp_fastmath.hpp: fast_log_ge1_finite) -- the same
+// values for x < 700 (an ulp in the log where the mantissa interval's ends are met), 12 instructions less; if ANY lane is at or beyond
+// 700 (or NaN) the wavefront also evaluates softplus_pair and those lanes take it, overflow behaviour and all.
+CGP_DEV void softplus_pair_batch(double x, double& sp, double& dsp) {
+    const double e = fast_exp_core(x);
+    const double z = e + 1.0;
+    sp = fast_log_ge1_finite(z);
+    dsp = e * rcp_nr(z);
+    const bool regular = x < 700.0;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!regular) != 0, 0)) {
+        double sp_n, dsp_n;
+        softplus_pair(x, sp_n, dsp_n);
+        sp = regular ? sp : sp_n;
+        dsp = regular ? dsp : dsp_n;
+    }
+}
 // `uniform` = the argument is the same in all lanes of the wavefront (a wave-per-trial kernel evaluating the model at the
 // trial's mean): one scalar branch then picks the cheap large-x form (cgp_fastmath.hpp).  `wide` = the kernel is latency-
 // rather than occupancy-bound (one wavefront per trial, time-parallel smoother): take the wide common-regime form.
@@ -161,6 +178,12 @@ template <int NH> struct HarmonicLCD {
     static constexpr int IV = D - 2;
     double rho, q, fs, dt;
     double M[4], MS[3];
+    double MM[9];              // the quadratic form M C M^T of the symmetric 2 x 2 block C written out (propagate_blocks): set by setup_blocks()
+    CGP_DEV void setup_blocks() {
+        MM[0] = M[0] * M[0]; MM[1] = 2.0 * (M[0] * M[1]); MM[2] = M[1] * M[1];
+        MM[3] = M[0] * M[2]; MM[4] = fma(M[0], M[3], M[1] * M[2]); MM[5] = M[1] * M[3];
+        MM[6] = M[2] * M[2]; MM[7] = 2.0 * (M[2] * M[3]); MM[8] = M[3] * M[3];
+    }
     bool uniform = false;      // set by wave-per-trial EKF-type callers: propagate() then sees a wave-uniform state
     bool wide = false;         // set by latency-bound callers (wave per trial, time-parallel smoother): softplus_pair_sel
     bool small_angles = false; // set by the large-batch lane kernel (cgp_lane4.hpp): fast_sincos_small in rotations()
@@ -353,6 +376,47 @@ template <int NH> struct HarmonicLCD {
                 }
                 Pp(i, j) = v;
             }
+    }
+    // The filter's prediction alone (no cross-covariance out) for ONE harmonic, by the blocks of J = [R g e_1^T; 0 M] and P = [A B; B^T C]
+    // (R = rho * rotation, g = d f / d u_v, M the Matern-3/2 transition):
+    //     X = R B + g C_0.,   Y = R A + g B_.0^T,   Pp_AA = Y R^T + X_.0 g^T + q I,   Pp_AC = X M^T,   Pp_CC = M C M^T + Sigma_C
+    // with g = dth (-f_1, f_0) taken from the rotated mean, M C M^T as three 3-term quadratic forms with precomputed products (MM) and
+    // every constant addend as the start of its FMA chain: 50 + 12 float64 operations where propagate() spends 72 + 22 on T = J P and T J^T (round 5: the large-batch lane EKF is bound by its
+    // float64 instruction count, cgp_lane4.hpp).  Same quantities up to rounding (sums associate differently: ~1e-16).
+    CGP_DEV void propagate_blocks(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Sym<D>& Pp) const {
+        static_assert(NH == 1, "block form written out for one harmonic");
+        double sp, dsp, c[1], s[1];
+        if (small_angles) softplus_pair_batch(u.v[2], sp, dsp);
+        else softplus_pair_sel(uniform, wide, u.v[2], sp, dsp);
+        const double wdt = (kTwoPi * fs) * dt;
+        double s1, c1;
+        if (small_angles) fast_sincos_small(wdt * sp, s1, c1);
+        else fast_sincos(wdt * sp, s1, c1);
+        c[0] = c1 * rho; s[0] = s1 * rho;
+        const double cc = c[0], ss = s[0];
+        f.v[0] = fma(cc, u.v[0], -(ss * u.v[1]));
+        f.v[1] = fma(ss, u.v[0], cc * u.v[1]);
+        f.v[2] = fma(M[0], u.v[2], M[1] * u.v[3]);
+        f.v[3] = fma(M[2], u.v[2], M[3] * u.v[3]);
+        const double dth = wdt * dsp;
+        const double g0 = -(dth * f.v[1]), g1 = dth * f.v[0];
+        const double A00 = P(0, 0), A10 = P(1, 0), A11 = P(1, 1);
+        const double B00 = P(2, 0), B01 = P(3, 0), B10 = P(2, 1), B11 = P(3, 1);
+        const double C00 = P(2, 2), C10 = P(3, 2), C11 = P(3, 3);
+        const double X00 = fma(g0, C00, fma(cc, B00, -(ss * B10))), X01 = fma(g0, C10, fma(cc, B01, -(ss * B11)));
+        const double X10 = fma(g1, C00, fma(ss, B00, cc * B10)),    X11 = fma(g1, C10, fma(ss, B01, cc * B11));
+        const double Y00 = fma(g0, B00, fma(cc, A00, -(ss * A10))), Y01 = fma(g0, B10, fma(cc, A10, -(ss * A11)));
+        const double Y10 = fma(g1, B00, fma(ss, A00, cc * A10)),    Y11 = fma(g1, B10, fma(ss, A10, cc * A11));
+        Pp(0, 0) = fma(g0, X00, fma(cc, Y00, fma(-ss, Y01, q)));
+        Pp(1, 0) = fma(g0, X10, fma(cc, Y10, -(ss * Y11)));
+        Pp(1, 1) = fma(g1, X10, fma(ss, Y10, fma(cc, Y11, q)));
+        Pp(2, 0) = fma(M[0], X00, M[1] * X01);
+        Pp(3, 0) = fma(M[2], X00, M[3] * X01);
+        Pp(2, 1) = fma(M[0], X10, M[1] * X11);
+        Pp(3, 1) = fma(M[2], X10, M[3] * X11);
+        Pp(2, 2) = fma(MM[0], C00, fma(MM[1], C10, fma(MM[2], C11, MS[0])));
+        Pp(3, 2) = fma(MM[3], C00, fma(MM[4], C10, fma(MM[5], C11, MS[1])));
+        Pp(3, 3) = fma(MM[6], C00, fma(MM[7], C10, fma(MM[8], C11, MS[2])));
     }
     CGP_DEV void add_sigma(Sym<D>& S, double w) const {
         CGP_UNROLL for (int i = 0; i < IV; i++) S(i, i) = fma(w, q, S(i, i));

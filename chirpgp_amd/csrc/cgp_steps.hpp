@@ -525,8 +525,14 @@ template <class DM, bool WAVE_> struct EkfPredict {
     static constexpr int D = DM::D; static constexpr bool WAVE = WAVE_; static constexpr bool USES_LDS = false;
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
-    CGP_DEV void large_batch() { model.small_angles = true; }      // cgp_lane4.hpp
+    CGP_DEV void large_batch() {                                   // cgp_lane4.hpp
+        model.small_angles = true;
+        if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) model.setup_blocks();
+    }
     CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) {
+            if (model.small_angles) { model.propagate_blocks(mf, Pf, mp, Pp); return; }      // large-batch launch: the block form, no T
+        }
         Mat<D> T;
         model.propagate(mf, Pf, mp, T, Pp);
     }
