@@ -51,6 +51,9 @@ CGP_DEV double horner_c(double p, double x, double c) {
 #endif
 }
 
+// (A whole chain as ONE assembly statement, every coefficient moved into VCC as two literals in front of its v_fma_f64, was measured in
+// round 5: no hoisted constants, scalar spills 128 -> 38, hazard padding 195 -> 26 -- and 7 % slower: the scalar moves take the wavefront's
+// issue slots on its dependent chain.)
 // 1 / d by v_rcp_f64 and two Newton steps (full double accuracy for normal d); 0 -> NaN, inf -> NaN, NaN -> NaN.
 CGP_DEV double rcp_nr(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -77,21 +80,12 @@ CGP_DEV double div_nr(double n, double d) {
 
 // sum_{i <= 13} r^i / i!, Horner.  (Estrin's scheme was measured here too: neutral in the sigma-point and lane-per-trial
 // kernels, which have other work to overlap; it pays only in the cooperative EKF, see softplus_pair_uniform below.)
+constexpr double kExpTaylor[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                                   1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
 CGP_DEV double exp_poly(double r) {
-    double p = 1.0 / 6227020800.0;
-    p = horner_c(p, r, 1.0 / 479001600.0);
-    p = horner_c(p, r, 1.0 / 39916800.0);
-    p = horner_c(p, r, 1.0 / 3628800.0);
-    p = horner_c(p, r, 1.0 / 362880.0);
-    p = horner_c(p, r, 1.0 / 40320.0);
-    p = horner_c(p, r, 1.0 / 5040.0);
-    p = horner_c(p, r, 1.0 / 720.0);
-    p = horner_c(p, r, 1.0 / 120.0);
-    p = horner_c(p, r, 1.0 / 24.0);
-    p = horner_c(p, r, 1.0 / 6.0);
-    p = horner_c(p, r, 0.5);
-    p = horner_c(p, r, 1.0);
-    return horner_c(p, r, 1.0);
+    double p = kExpTaylor[0];
+    CGP_UNROLL for (int i = 1; i < 14; i++) p = horner_c(p, r, kExpTaylor[i]);
+    return p;
 }
 
 // exp(x): x = k ln2 + r, Taylor of degree 13 on |r| <= ln2 / 2 (truncation 4e-18), v_ldexp_f64.
@@ -107,6 +101,14 @@ CGP_DEV double fast_exp(double x) {
     return y;
 }
 
+// 1/3 + s2/5 + ... + s2^9/21 (the atanh series of fast_log_ge1 without its leading 1), Horner
+constexpr double kAtanhOdd[10] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0};
+CGP_DEV double atanh_tail_poly(double s2) {
+    double p = kAtanhOdd[0];
+    CGP_UNROLL for (int i = 1; i < 10; i++) p = horner_c(p, s2, kAtanhOdd[i]);
+    return p;
+}
+
 // log(z) for z in [1, +inf] (the softplus argument exp(x) + 1): z = 2^k m, m in [sqrt(1/2), sqrt(2)),
 // s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^20/21)   (|s| <= 0.1716, truncation 2e-17).
 CGP_DEV double fast_log_ge1(double z) {
@@ -119,16 +121,7 @@ CGP_DEV double fast_log_ge1(double z) {
     const double f = m - 1.0;
     const double s = div_nr(f, m + 1.0);
     const double s2 = s * s;
-    double p = 1.0 / 21.0;
-    p = horner_c(p, s2, 1.0 / 19.0);
-    p = horner_c(p, s2, 1.0 / 17.0);
-    p = horner_c(p, s2, 1.0 / 15.0);
-    p = horner_c(p, s2, 1.0 / 13.0);
-    p = horner_c(p, s2, 1.0 / 11.0);
-    p = horner_c(p, s2, 1.0 / 9.0);
-    p = horner_c(p, s2, 1.0 / 7.0);
-    p = horner_c(p, s2, 1.0 / 5.0);
-    p = horner_c(p, s2, 1.0 / 3.0);
+    const double p = atanh_tail_poly(s2);
     const double two_s = s + s;
     double lm = fma(two_s, p * s2, two_s);
     lm = fma(k, kLn2Lo, lm);
@@ -145,16 +138,7 @@ CGP_DEV double fast_log_ge1_finite(double z) {
     const double k = (double)e;
     const double s = div_nr(m - 1.0, m + 1.0);
     const double s2 = s * s;
-    double p = 1.0 / 21.0;
-    p = horner_c(p, s2, 1.0 / 19.0);
-    p = horner_c(p, s2, 1.0 / 17.0);
-    p = horner_c(p, s2, 1.0 / 15.0);
-    p = horner_c(p, s2, 1.0 / 13.0);
-    p = horner_c(p, s2, 1.0 / 11.0);
-    p = horner_c(p, s2, 1.0 / 9.0);
-    p = horner_c(p, s2, 1.0 / 7.0);
-    p = horner_c(p, s2, 1.0 / 5.0);
-    p = horner_c(p, s2, 1.0 / 3.0);
+    const double p = atanh_tail_poly(s2);
     const double two_s = s + s;
     double lm = fma(two_s, p * s2, two_s);
     lm = fma(k, kLn2Lo, lm);
@@ -162,23 +146,14 @@ CGP_DEV double fast_log_ge1_finite(double z) {
 }
 
 // sin(r), cos(r) on the reduced range |r| <= pi/4: Taylor to r^17 / r^16 (truncation 5e-17), two independent Horner chains.
+constexpr double kSinTaylor[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0,
+                                  -1.0 / 120.0, 1.0 / 6.0};                  // -1/17! ... 1/3! (sign folded below)
+constexpr double kCosTaylor[7] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0};
 CGP_DEV void sincos_reduced(double r, double& s0, double& c0) {
     const double r2 = r * r;
-    double ps = -1.0 / 355687428096000.0;          // -1/17!
-    ps = horner_c(ps, r2, 1.0 / 1307674368000.0);       //  1/15!
-    ps = horner_c(ps, r2, -1.0 / 6227020800.0);         // -1/13!
-    ps = horner_c(ps, r2, 1.0 / 39916800.0);            //  1/11!
-    ps = horner_c(ps, r2, -1.0 / 362880.0);             // -1/9!
-    ps = horner_c(ps, r2, 1.0 / 5040.0);                //  1/7!
-    ps = horner_c(ps, r2, -1.0 / 120.0);                // -1/5!
-    ps = horner_c(ps, r2, 1.0 / 6.0);                   //  1/3!  (sign folded below)
-    double pc = 1.0 / 20922789888000.0;            //  1/16!
-    pc = horner_c(pc, r2, -1.0 / 87178291200.0);        // -1/14!
-    pc = horner_c(pc, r2, 1.0 / 479001600.0);           //  1/12!
-    pc = horner_c(pc, r2, -1.0 / 3628800.0);            // -1/10!
-    pc = horner_c(pc, r2, 1.0 / 40320.0);               //  1/8!
-    pc = horner_c(pc, r2, -1.0 / 720.0);                // -1/6!
-    pc = horner_c(pc, r2, 1.0 / 24.0);                  //  1/4!
+    double ps = kSinTaylor[0], pc = kCosTaylor[0];
+    CGP_UNROLL for (int i = 1; i < 8; i++) ps = horner_c(ps, r2, kSinTaylor[i]);
+    CGP_UNROLL for (int i = 1; i < 7; i++) pc = horner_c(pc, r2, kCosTaylor[i]);
     s0 = fma(-(r * r2), ps, r);                       // r - r^3 (1/3! - r^2/5! + ...)
     c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));        // 1 - r^2/2 + r^4 (1/4! - ...)
 }
