@@ -32,6 +32,7 @@
 //     NaN like the reference's Cholesky does.
 #pragma once
 #include <atomic>
+#include <type_traits>
 #include "cgp_coop4.hpp"
 
 namespace cgp {
@@ -254,12 +255,16 @@ __global__ void __launch_bounds__(64) sgp8_coop_kernel(FilterIO io, ModelArgs ma
                 CGP_UNROLL for (int c = 0; c < (a <= D - 2 ? a : D - 1); c++) s = fma(l(a, c), xs[c], s);
                 dd[a] = s;
             }
-            // rho cos / sin of k theta(chi_v), k = 1..NH: without regime branches (one basic block to schedule); the rare
-            // lane outside the common regime sends the wavefront through the checked form afterwards
+            // rho cos / sin of k theta(chi_v), k = 1..NH: without regime branches (one basic block to schedule); a lane outside the
+            // lean regime sends the wavefront through the branch-free ANY form (round 5, cgp_models.hpp: precompute_any) and only from
+            // there through the checked one
             typename HarmonicLCD<NH>::Pre pre;
             bool ok;
             model.precompute_spec(R, m.v[V] + dd[V], pre, ok);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) model.precompute(m.v[V] + dd[V], pre);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+                model.precompute_any(R, m.v[V] + dd[V], pre, ok);
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0) model.precompute(m.v[V] + dd[V], pre);
+            }
             double gg[NL];
             CGP_UNROLL for (int k = 0; k < NH; k++) {
                 const double h0 = m.v[2 * k] + dd[2 * k], h1 = m.v[2 * k + 1] + dd[2 * k + 1];

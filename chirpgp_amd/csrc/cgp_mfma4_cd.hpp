@@ -49,7 +49,7 @@ struct Cd4LaneCoef {
 };
 
 // The fan of one stage: B operands a_q and A operands W d_r of both passes.
-template <bool SPEC, bool TWO, class SM>
+template <int MODE, bool TWO, class SM>
 CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp, const Sym<4>& l,
                           const double (&sd)[3], double m0, double m1, double m2, double (&a)[2], double (&wd)[2], bool& ok) {
     double c0[2], c1[2], d2[2];
@@ -63,7 +63,8 @@ CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneC
     }
     typename SM::Pre pre;
     const double uv = m2 + ((TWO && K.odd) ? d2[1] : d2[0]);
-    if constexpr (SPEC) model.precompute_spec(R, uv, pre, ok);
+    if constexpr (MODE == kFanSpec) model.precompute_spec(R, uv, pre, ok);
+    else if constexpr (MODE == kFanAny) model.precompute_any(R, uv, pre, ok);
     else { model.precompute(uv, pre); ok = true; }
     const double w0 = TWO ? dpp_f64<kQuadBcast0>(pre.w) : pre.w;
     a[0] = fma(fma(K.k1, w0, K.kl0), c0[0], fma(K.kn, w0, K.kl1) * c1[0]);
@@ -75,6 +76,8 @@ CGP_DEV void cd4_mfma_fan(const SM& model, const SoftplusRegs& R, const Cd4LaneC
 
 // One evaluation of the sigma-point moment ODE at (m in column form, P distributed): km = E[a] in column form and the
 // lane's entry of C + C^T + gamma.
+// (a lane outside the lean regime [1.5, 700) sends the wavefront through the branch-free ANY fan -- round 5, cgp_models.hpp:
+// precompute_any -- and only from there through the checked fan with its regime branches)
 template <bool TWO, class SM>
 CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneCoef& K, const Fan4Groups& grp,
                           double mcol, double P, double& kmcol, double& kP) {
@@ -86,8 +89,11 @@ CGP_DEV void cd4_mfma_rhs(const SM& model, const SoftplusRegs& R, const Cd4LaneC
     sd[2] += (dv[3] > 0.0) ? 0.0 : __builtin_nan("");
     const double m0 = row_bcast_f64<0>(mcol), m1 = row_bcast_f64<1>(mcol), m2 = row_bcast_f64<2>(mcol), m3 = row_bcast_f64<3>(mcol);
     double a[2], wd[2]; bool ok;
-    cd4_mfma_fan<true, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) cd4_mfma_fan<false, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
+    cd4_mfma_fan<kFanSpec, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        cd4_mfma_fan<kFanAny, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) cd4_mfma_fan<kFanChecked, TWO>(model, R, K, grp, l, sd, m0, m1, m2, a, wd, ok);
+    }
     double C = mfma4x4(wd[0], a[0], 0.0);
     double F = mfma4x4(grp.W[0], a[0], 0.0);
     if constexpr (TWO) {

@@ -21,6 +21,7 @@
 //   * chol(Pf) is needed by every point: 10 entries gathered with v_readlane, factorisation replicated (as L D L^T, which
 //     keeps the square roots off the pivot-to-pivot chain); the mean is replicated (four quad broadcasts of Pp H^T per step).
 #pragma once
+#include <type_traits>
 #include "cgp_coop8.hpp"
 #include "cgp_coop4_sigma.hpp"
 
@@ -82,7 +83,7 @@ struct Sgp4LaneCoef {
 // ONCE per group: lane q of a quad takes the group of pass q & 1, and the (rho cos, rho sin) pairs reach the quad's four
 // lanes as quad broadcasts.  SPEC: without the regime branches (cgp_models.hpp:precompute_spec); ok = false where that is
 // not valid.
-template <bool SPEC, bool TWO, class DM>
+template <int MODE, bool TWO, class DM>
 CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef& K, const Sym<4>& l, const double (&sd)[3],
                            double u0, double u1, double u2, const double (&xi)[2][3], bool odd, double& z0, double& z1, bool& ok) {
     double x1[2], x2[2], d2[2];
@@ -96,7 +97,8 @@ CGP_DEV void sgp4_mfma_fan(const DM& model, const FanRegs& R, const Sgp4LaneCoef
     }
     typename DM::Pre pre;                                 // rho cos / sin of theta(chi_v)
     const double uv = u2 + ((TWO && odd) ? d2[1] : d2[0]);
-    if constexpr (SPEC) model.precompute_spec(R, uv, pre, ok);
+    if constexpr (MODE == kFanSpec) model.precompute_spec(R, uv, pre, ok);
+    else if constexpr (MODE == kFanAny) model.precompute_any(R, uv, pre, ok);
     else { model.precompute(uv, pre); ok = true; }
     // q = 0: c x1 - s x2;  q = 1: s x1 + c x2;  q = 2, 3: M[q-2][0] x1 + M[q-2][1] x2 (coefficients 0 / +-1 / M: exact)
     const double c0 = TWO ? dpp_f64<kQuadBcast0>(pre.c[0]) : pre.c[0], s0 = TWO ? dpp_f64<kQuadBcast0>(pre.s[0]) : pre.s[0];
@@ -202,9 +204,15 @@ CGP_DEV void sgp4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             // wavefront through the checked forms afterwards
             bool ok;
             double z0, z1 = 0.0;
-            sgp4_mfma_fan<true, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0))
-                sgp4_mfma_fan<false, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
+            // (round 5: first through the branch-free ANY fan -- the full-accuracy softplus for any |x| < 700, cgp_models.hpp:
+            // precompute_any -- and only from there through the checked one with its regime branches.  Starting a wavefront's next
+            // steps with the ANY fan, a second copy of the step chosen between steps, was measured too: 7.2 instead of 8.x ms on
+            // records outside the lean regime, and 1 - 5 % slower on those inside it in the three kernels that got it: not kept.)
+            sgp4_mfma_fan<kFanSpec, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+                sgp4_mfma_fan<kFanAny, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0) sgp4_mfma_fan<kFanChecked, TWO>(model, R, K, l, sd, u0, u1, u2, xi, odd, z0, z1, ok);
+            }
             double Y = mfma4x4(W[0] * z0, z0, 0.0);
             double F = mfma4x4(W[0], z0, 0.0);
             if constexpr (TWO) {

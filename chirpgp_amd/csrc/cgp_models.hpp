@@ -40,6 +40,9 @@ CGP_DEV double log1p_over_t_lean(double t) {
     const double t4 = t2 * t2;
     return horner(horner(a3, t2, a2), t4, horner(a1, t2, a0));
 }
+// the three forms of a sigma-point fan's softplus -> sin / cos chain in the one-wavefront kernels (precompute / precompute_spec /
+// precompute_any below): spec first; if a lane is outside its regime, any; checked as the last resort
+constexpr int kFanChecked = 0, kFanSpec = 1, kFanAny = 2;
 CGP_DEV bool softplus_lane_common(double x) { return x >= 1.5 && x < 700.0; }
 CGP_DEV void softplus_pair_wide(double x, double& sp, double& dsp) {
     const double t = exp_neg_lean_lane(x);
@@ -78,6 +81,15 @@ CGP_DEV double softplus(double x) { return fast_log_ge1(fast_exp(x) + 1.0); }
 // their overflow / underflow / inf selects and with the direct exponent extraction (cgp_fastmath.hpp: fast_log_ge1_finite) -- the same
 // values for x < 700 (an ulp in the log where the mantissa interval's ends are met), 12 instructions less; if ANY lane is at or beyond
 // 700 (or NaN) the wavefront also evaluates softplus_pair and those lanes take it, overflow behaviour and all.
+CGP_DEV double softplus_batch(double x) {
+    double sp = fast_log_ge1_finite(fast_exp_core(x) + 1.0);
+    const bool regular = x < 700.0;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!regular) != 0, 0)) {
+        const double sp_n = softplus(x);
+        sp = regular ? sp : sp_n;
+    }
+    return sp;
+}
 CGP_DEV void softplus_pair_batch(double x, double& sp, double& dsp) {
     const double e = fast_exp_core(x);
     const double z = e + 1.0;
@@ -186,7 +198,7 @@ template <int NH> struct HarmonicLCD {
     }
     bool uniform = false;      // set by wave-per-trial EKF-type callers: propagate() then sees a wave-uniform state
     bool wide = false;         // set by latency-bound callers (wave per trial, time-parallel smoother): softplus_pair_sel
-    bool small_angles = false; // set by the large-batch lane kernel (cgp_lane4.hpp): fast_sincos_small in rotations()
+    bool large_batch = false; // set by the large-batch lane kernels (cgp_lane4.hpp): fast_sincos_small in rotations(), softplus_batch / softplus_pair_batch
     CGP_DEV void setup(const double* __restrict__ p, double dt_, int model_id) {
         dt = dt_;
         if (model_id == 2 /* CGP_M_LASCALA_LCD */) {
@@ -204,7 +216,7 @@ template <int NH> struct HarmonicLCD {
     // recurrence for the overtones (same values as cos(dt k w), sin(dt k w) up to rounding).
     CGP_DEV void rotations(double w, double (&c)[NH], double (&s)[NH]) const {
         double s1, c1;
-        if (small_angles) fast_sincos_small(dt * w, s1, c1);
+        if (large_batch) fast_sincos_small(dt * w, s1, c1);
         else fast_sincos(dt * w, s1, c1);
         double ck = c1, sk = s1;
         c[0] = c1 * rho; s[0] = s1 * rho;
@@ -239,6 +251,25 @@ template <int NH> struct HarmonicLCD {
             p.c[k] = ck * rho; p.s[k] = sk * rho;
         }
     }
+    // precompute_spec() with the branch-free full-accuracy softplus for ANY |uv| < 700 (cgp_fastmath.hpp: softplus_pair_any) in place of
+    // the lean one: the middle tier of the one-wavefront sigma-point kernels (round 5) for records whose frequency state drops below
+    // 1.5, where the lean form does not hold -- they used to take precompute() with its two regime branches behind every speculative
+    // fan.  ok = |uv| < 700 and a rotation angle within pi / 4.
+    CGP_DEV void precompute_any(const FanRegs& R, double uv, Pre& p, bool& ok) const {
+        double sp, unused; bool ok1;
+        softplus_pair_any(uv, sp, unused, ok1);
+        const double x = sp * ((kTwoPi * fs) * dt);
+        ok = ok1 && fabs(x) <= kPiOver4;
+        double s1, c1;
+        sincos_reduced(R, x, s1, c1);
+        double ck = c1, sk = s1;
+        p.c[0] = c1 * rho; p.s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            p.c[k] = ck * rho; p.s[k] = sk * rho;
+        }
+    }
     // The sigma points of one prediction spread around the mean, so their rotation angles differ from the mean's by a
     // small d = dt (w - w0): the fan anchors (cos, sin) at the mean once and every point takes the small-angle rotation
     // by d (sin to d^9, cos to d^8: remainders < 3e-19 for |d| <= 2^-4) instead of a full sincos -- 14 instead of ~45
@@ -246,11 +277,11 @@ template <int NH> struct HarmonicLCD {
     // sincos and those lanes take it.
     struct Anchor { double w0, c1, s1; };
     CGP_DEV void anchor(double uv0, Anchor& a) const {
-        a.w0 = (kTwoPi * softplus_sel(wide, uv0)) * fs;
+        a.w0 = (kTwoPi * (large_batch ? softplus_batch(uv0) : softplus_sel(wide, uv0))) * fs;
         fast_sincos(dt * a.w0, a.s1, a.c1);
     }
     CGP_DEV void precompute(double uv, const Anchor& a, Pre& p) const {
-        const double w = (kTwoPi * softplus_sel(wide, uv)) * fs;
+        const double w = (kTwoPi * (large_batch ? softplus_batch(uv) : softplus_sel(wide, uv))) * fs;
         const double d = dt * (w - a.w0), d2 = d * d;
         const double ps = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
         const double cd = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
@@ -386,11 +417,11 @@ template <int NH> struct HarmonicLCD {
     CGP_DEV void propagate_blocks(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Sym<D>& Pp) const {
         static_assert(NH == 1, "block form written out for one harmonic");
         double sp, dsp, c[1], s[1];
-        if (small_angles) softplus_pair_batch(u.v[2], sp, dsp);
+        if (large_batch) softplus_pair_batch(u.v[2], sp, dsp);
         else softplus_pair_sel(uniform, wide, u.v[2], sp, dsp);
         const double wdt = (kTwoPi * fs) * dt;
         double s1, c1;
-        if (small_angles) fast_sincos_small(wdt * sp, s1, c1);
+        if (large_batch) fast_sincos_small(wdt * sp, s1, c1);
         else fast_sincos(wdt * sp, s1, c1);
         c[0] = c1 * rho; s[0] = s1 * rho;
         const double cc = c[0], ss = s[0];
@@ -463,6 +494,12 @@ template <int NH> struct HarmonicSDE {
         softplus_tail_lean(R, t, q, unused);
         p.w = (kTwoPi * fma(q, t, uv)) * fs;
         ok = softplus_lane_common(uv);
+    }
+    // ... and with the branch-free full-accuracy softplus for any |uv| < 700 (HarmonicLCD::precompute_any): the middle tier
+    CGP_DEV void precompute_any(const SoftplusRegs&, double uv, Pre& p, bool& ok) const {
+        double sp, unused;
+        softplus_pair_any(uv, sp, unused, ok);
+        p.w = (kTwoPi * sp) * fs;
     }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const {
         Pre p;

@@ -526,12 +526,12 @@ template <class DM, bool WAVE_> struct EkfPredict {
     DM model;
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); model.uniform = WAVE; model.wide = WAVE; }
     CGP_DEV void large_batch() {                                   // cgp_lane4.hpp
-        model.small_angles = true;
+        model.large_batch = true;
         if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) model.setup_blocks();
     }
     CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) {
-            if (model.small_angles) { model.propagate_blocks(mf, Pf, mp, Pp); return; }      // large-batch launch: the block form, no T
+            if (model.large_batch) { model.propagate_blocks(mf, Pf, mp, Pp); return; }      // large-batch launch: the block form, no T
         }
         Mat<D> T;
         model.propagate(mf, Pf, mp, T, Pp);
@@ -560,7 +560,9 @@ template <class DM, bool COLL = false> struct SgpPredictLane {
     DM model; SigmaSet sg;
     mutable int skip = 0;                      // steps left on the checked fan (sgp4_prediction_collapsed_sticky)
     CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; model.wide = false; }
-    CGP_DEV void large_batch() {}
+    CGP_DEV void large_batch() {                                   // cgp_lane4.hpp: the checked fan's softplus without its overflow selects
+        if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) model.large_batch = true;
+    }
     CGP_DEV void predict(int lane, double* lds, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
         Mat<D> unused;
         if constexpr (std::is_same<DM, HarmonicLCD<1>>::value) {

@@ -1027,6 +1027,48 @@ def test_wide_step_for_records_outside_the_lean_regime():
             assert rg['wide'] > 0.2 * chunks and rg['checked'] == 0, (label, rg)
 
 
+@pytest.mark.parametrize('kind', ['sgp', 'cd_sgp', 'harmonic'])
+def test_sigma_point_filters_on_records_outside_the_lean_regime(kind):
+    """The one-wavefront sigma-point filters (C3: cgp_mfma4_sigma.hpp, C4: cgp_mfma4_cd.hpp, C5: cgp_coop8.hpp) evaluate a fan's
+    softplus -> sin / cos chain in the lean form first, valid for a frequency state in [1.5, 700); a wavefront with a point outside
+    it repeats the fan with the branch-free full-accuracy form (round 5, cgp_models.hpp: precompute_any) and only beyond |x| = 700
+    with the checked one.  Records that live there -- a chirp the filter never locks on, a start at 0.5 on a 1 Hz chirp, a negative
+    start, a start beyond 700 (sigma points on either side of the ANY form's bound, some past the overflow of the reference's naive
+    softplus at 709.78) -- against the C port."""
+    import copy
+    import bench
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    T, B = 1500, 4
+    nh = 3 if kind == 'harmonic' else 0
+    for m0_v, off, label in ((7.0, 20.0, 'no lock'), (0.5, 1.0, 'low'), (-3.0, 2.0, 'negative start'), (707.0, 8.0, 'beyond 700')):
+        params = np.array([0.1, 0.1, 0.1, 1., 1., m0_v])
+        if kind == 'harmonic':
+            drift, disp, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, 3)
+            sg = SigmaPoints.cubature(8)
+        else:
+            drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+            sg = SigmaPoints.gauss_hermite(4, 3)
+        ys = bench.chirp_batch(B, T, 5, Xi=0.1, offset=off, num_harmonics=nh)
+        if kind == 'cd_sgp':
+            dg = copy.copy(drift)
+            dg.gamma = disp.outer()
+            want = port.filter(port.F_CD_SGP, dg, sg, H, 0.1, m0, P0, 1e-3, ys)
+            got = fs.cd_sgp_filter(drift, disp(None), sg, H, 0.1, m0, P0, 1e-3, ys, **WAVE)
+        else:
+            want = port.filter(port.F_SGP, disc, sg, H, 0.1, m0, P0, 1e-3, ys)
+            got = fs.sgp_filter(disc, sg, H, 0.1, m0, P0, 1e-3, ys, **WAVE)
+        errs = [cs.max_rel_err(g, w) for g, w in zip(got, want)]
+        print(kind, label, [f'{e:.1e}' for e in errs])
+        # (max_rel_err also asserts equal NaN positions.)  Beyond 700 the points still inside [1.5, 700) take the LEAN softplus of the
+        # checked fan, 7e-12 relative: at a state of 700 that is 3e-11 rad of rotation angle a step -- 2e-8 on these covariances, before
+        # and after round 5; the north star's gate is 1e-5
+        gate = 1e-6 if label == 'beyond 700' else 1e-9
+        for e, n in zip(errs, ('mfs', 'Pfs', 'nll')):
+            assert e <= gate, (kind, label, n, e)
+
+
 @pytest.mark.parametrize('nh', [2, 3])
 def test_tile_layout_sigma_filter_axial_and_rotated_cubature(nh):
     """The d = 6 / 8 tile-layout sigma-point filter takes ONE square root per lane and step when every sigma point sits on one axis
