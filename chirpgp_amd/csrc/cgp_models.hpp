@@ -302,6 +302,24 @@ template <int NH> struct HarmonicLCD {
             p.c[k] = ck * rho; p.s[k] = sk * rho;
         }
     }
+    // The anchored form with the FULL-accuracy softplus for finite arguments and no branch (round 5: the large-batch sigma-point lane
+    // kernel on records outside the lean regime -- a body without branches is what lets the scheduler interleave two groups' chains):
+    // ok = false for uv >= 700 (the naive form overflows from 709.78 on) or a rotation angle beyond pi / 4; the caller repeats the fan
+    // with precompute().
+    CGP_DEV void precompute_any(double uv, const Anchor&, Pre& p, bool& ok) const {
+        const double w = (kTwoPi * fast_log_ge1_finite(fast_exp_core(uv) + 1.0)) * fs;
+        const double x = dt * w;
+        double s1, c1;
+        sincos_reduced(x, s1, c1);                    // (not the anchored small-angle form: on the CRLB records a fan is wider than 1/16 rad)
+        ok = uv < 700.0 && fabs(x) <= kPiOver4;
+        double ck = c1, sk = s1;
+        p.c[0] = c1 * rho; p.s[0] = s1 * rho;
+        CGP_UNROLL for (int k = 1; k < NH; k++) {
+            const double cn = fma(ck, c1, -sk * s1), sn = fma(sk, c1, ck * s1);
+            ck = cn; sk = sn;
+            p.c[k] = ck * rho; p.s[k] = sk * rho;
+        }
+    }
     // The anchored form without its two regime branches (lean softplus as is, small-angle rotation as is), for a lane
     // that walks many groups in a loop the scheduler should see as one block: ok = false where precompute(uv, a, p)
     // would have taken a fallback (uv outside [1.5, 700) or |d| > 1/16); the caller then repeats the fan with that.

@@ -269,7 +269,7 @@ CGP_DEV void sgp_prediction(const DM& model, const SigmaSet& sg, int lane, doubl
 // failed Cholesky poisons every output with NaN like the literal sums do.
 // SPEC: the groups' softplus and rotation without regime branches (cgp_models.hpp:precompute_spec), so the loop body is ONE
 // basic block; returns false if some group of this lane was outside the regime -- the caller then repeats with SPEC = false.
-template <bool CROSS, bool ST, bool SPEC>
+template <bool CROSS, bool ST, int MODE>          // MODE: cgp_models.hpp kFanChecked / kFanSpec / kFanAny
 CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
                                             Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
     Sym<4> L; Vec<4> inv;
@@ -280,7 +280,7 @@ CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const S
     const int ng = sg.groups();
     HarmonicLCD<1>::Anchor anchor;
     model.anchor(mf.v[2], anchor);
-    for (int g = 0; g < ng; g++) {
+    auto group = [&](int g) __attribute__((always_inline)) {
         double xg[3], W;
         sg.template group<ST, 4>(g, xg, W);
         const double xi0 = xg[0], xi1 = xg[1], xi2 = xg[2];
@@ -290,7 +290,8 @@ CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const S
         const double d3 = fma(L(3, 2), xi2, fma(L(3, 1), xi1, L(3, 0) * xi0));
         const double h0 = mf.v[0] + d0, h1 = mf.v[1] + d1;
         HarmonicLCD<1>::Pre pre;
-        if constexpr (SPEC) { bool ok; model.precompute_spec(mf.v[2] + d2, anchor, pre, ok); all_ok = all_ok && ok; }
+        if constexpr (MODE == kFanSpec) { bool ok; model.precompute_spec(mf.v[2] + d2, anchor, pre, ok); all_ok = all_ok && ok; }
+        else if constexpr (MODE == kFanAny) { bool ok; model.precompute_any(mf.v[2] + d2, anchor, pre, ok); all_ok = all_ok && ok; }
         else model.precompute(mf.v[2] + d2, anchor, pre);
         const double f0 = pre.c[0] * h0 - pre.s[0] * h1, f1 = pre.s[0] * h0 + pre.c[0] * h1;
         const double w0 = W * f0, w1 = W * f1;
@@ -298,6 +299,15 @@ CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const S
         s00 = fma(w0, f0, s00); s10 = fma(w1, f0, s10); s11 = fma(w1, f1, s11);
         x02 = fma(w0, d2, x02); x12 = fma(w1, d2, x12); x03 = fma(w0, d3, x03); x13 = fma(w1, d3, x13);
         if (CROSS) { c00 = fma(w0, d0, c00); c01 = fma(w1, d0, c01); c10 = fma(w0, d1, c10); c11 = fma(w1, d1, c11); }
+    };
+    if constexpr (MODE != kFanChecked) {
+        // no branch in a group: three groups per iteration, their softplus -> sin / cos chains interleaved by the scheduler (round 5:
+        // GH-3 at 262 144 x 500 on the CRLB records 17.2 -> 14.3 (two) -> 14.0 ms (three))
+        int g = 0;
+        for (; g + 3 <= ng; g += 3) { group(g); group(g + 1); group(g + 2); }
+        for (; g < ng; g++) group(g);
+    } else {
+        for (int g = 0; g < ng; g++) group(g);
     }
     const double poison = L(0, 0) - L(0, 0);          // 0, or NaN when the factorisation failed
     const double M0 = model.M[0], M1 = model.M[1], M2 = model.M[2], M3 = model.M[3];
@@ -329,25 +339,31 @@ CGP_DEV bool sgp4_prediction_collapsed_impl(const HarmonicLCD<1>& model, const S
 template <bool CROSS, bool ST>
 CGP_DEV void sgp4_prediction_collapsed(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
                                        Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT) {
-    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, kFanSpec>(model, sg, mf, Pf, mp, Pp, DT);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        const bool ok2 = sgp4_prediction_collapsed_impl<CROSS, ST, kFanAny>(model, sg, mf, Pf, mp, Pp, DT);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok2) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, kFanChecked>(model, sg, mf, Pf, mp, Pp, DT);
+    }
 }
 // The same for a caller that evaluates the fan step after step on the same 64 trials (one lane per trial, cgp_lane4.hpp): a wavefront
 // whose speculative pass failed -- a lane's frequency state below 1.5: the CRLB jobs' records, a zero-mean GP, in every step -- pays the
-// speculative AND the checked fan, 5852 vector instructions per step at GH-3; it goes straight to the checked fan for the next
-// kSpecSkip steps instead (`skip`: wave-uniform, kept by the caller).
+// speculative AND the checked fan, 5852 vector instructions per step at GH-3; it goes straight to the ANY fan (full-accuracy softplus,
+// no branch in a group: precompute_any; the checked fan behind it only beyond 700 or for a wide fan) for the next kSpecSkip steps instead
+// (`skip`: wave-uniform, kept by the caller).
 constexpr int kSpecSkip = 16;
 template <bool CROSS, bool ST>
 CGP_DEV void sgp4_prediction_collapsed_sticky(const HarmonicLCD<1>& model, const SigmaSet& sg, const Vec<4>& mf, const Sym<4>& Pf,
                                               Vec<4>& mp, Sym<4>& Pp, Mat<4>& DT, int& skip) {
     if (skip > 0) {
         skip--;
-        sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+        const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, kFanAny>(model, sg, mf, Pf, mp, Pp, DT);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, kFanChecked>(model, sg, mf, Pf, mp, Pp, DT);
         return;
     }
-    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, true>(model, sg, mf, Pf, mp, Pp, DT);
+    const bool ok = sgp4_prediction_collapsed_impl<CROSS, ST, kFanSpec>(model, sg, mf, Pf, mp, Pp, DT);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
-        sgp4_prediction_collapsed_impl<CROSS, ST, false>(model, sg, mf, Pf, mp, Pp, DT);
+        const bool ok2 = sgp4_prediction_collapsed_impl<CROSS, ST, kFanAny>(model, sg, mf, Pf, mp, Pp, DT);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok2) != 0, 0)) sgp4_prediction_collapsed_impl<CROSS, ST, kFanChecked>(model, sg, mf, Pf, mp, Pp, DT);
         skip = kSpecSkip;
     }
 }
