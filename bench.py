@@ -482,7 +482,7 @@ def main():
             chunks = B * ((T + 63) // 64)
             regimes['chunks'] = chunks
             regimes['high_share'] = regimes['high'] / chunks if chunks else None
-            regimes['kernel'] = 'ekf4_mfma_kernel (one trial per wavefront)' if (regimes['high'] + regimes['common'] + regimes['redone'] + regimes['checked'] + regimes['wide']) else 'not counted by this launch shape'
+            regimes['kernel'] = 'ekf4_mfma_kernel (one trial per wavefront)' if (regimes['high'] + regimes['common'] + regimes['low'] + regimes['mid'] + regimes['redone'] + regimes['checked'] + regimes['wide']) else 'not counted by this launch shape'
         filt = [a.elapsed_time(b) for n, a, b in events if n == 'filter']
         smooth = [a.elapsed_time(b) for n, a, b in events if n == 'smoother']
         mine = [elapsed, float(np.mean(filt)) if filt else 0.0, float(np.mean(smooth)) if smooth else 0.0]
@@ -625,7 +625,8 @@ def main():
                     rg = _engine.debug_counters(reset=True)
                     _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
                     rows.append({"seed": seed, "Xi": Xi, "offset_hz": offset, "value": B * T / dt_pass, "ms_per_pass": dt_pass * 1e3,
-                                 "high": rg['high'], "common": rg['common'], "redone": rg['redone'], "wide": rg['wide'], "checked": rg['checked'], "high_left": rg['high_left']})
+                                 "high": rg['high'], "common": rg['common'], "low": rg['low'], "mid": rg['mid'], "redone": rg['redone'], "wide": rg['wide'], "checked": rg['checked'],
+                                 "high_left": rg['high_left']})
                     del r, ys
         torch.cuda.empty_cache()
         vals = np.array([r['value'] for r in rows])
@@ -635,9 +636,10 @@ def main():
                 "combinations": len(rows), "steps": steps, "chunks_per_launch": chunks,
                 "value_min": float(vals.min()), "value_median": med, "value_max": float(vals.max()),
                 "slowest_over_median_time": med / float(vals.min()), "slowest": slow,
+                "note": "median and slowest are to be read against the line's own value (the reference's records, seed 0, steps passes)",
                 "redone_plus_checked_share_max": max((r['redone'] + r['checked']) / chunks for r in rows),
                 "redone_plus_checked_share_at_reference_inputs": max((r['redone'] + r['checked']) / chunks for r in rows if (r['Xi'], r['offset_hz']) == (0.1, 8.0)),
-                "wide_share_max": max(r['wide'] / chunks for r in rows),
+                "wide_share_max": max(r['wide'] / chunks for r in rows), "low_share_max": max(r['low'] / chunks for r in rows), "mid_share_max": max(r['mid'] / chunks for r in rows),
                 "by_offset_median": {str(o): float(np.median([r['value'] for r in rows if r['offset_hz'] == o])) for o in (5.5, 8.0, 20.0)},
                 "by_Xi_median": {str(x): float(np.median([r['value'] for r in rows if r['Xi'] == x])) for x in (0.01, 0.1, 1.0)},
                 "rows": rows}

@@ -549,7 +549,7 @@ def debug_philox(ctr, key):
 
 
 DBG_WALK_SEGMENTS, DBG_COUNT_REGIMES = 1, 2
-REGIME_COUNTERS = ('high', 'common', 'redone', 'checked', 'high_left', 'wide')
+REGIME_COUNTERS = ('high', 'common', 'redone', 'checked', 'high_left', 'wide', 'low', 'mid')
 
 
 def reserve_workspace(nbytes, device_index=None):

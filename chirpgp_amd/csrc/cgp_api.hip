@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* _
         case 7: softplus_pair_wide(v, a, b); break;
         case 9: a = rcp_nr1(v); break;
         case 10: { bool ok; softplus_pair_any(v, a, b, ok); if (!ok) { a = __builtin_nan(""); b = a; } break; }      // (not ok -> NaN: the caller's fallback)
+        case 11: softplus_pair_mid(v, a, b); break;                                                                   // (valid for |v| <= 2)
         default: softplus_pair(v, a, b); break;
         }
         o0[i] = a;
@@ -575,7 +576,7 @@ int cgp_squared_error_sums(cgp_ctx* ctx, const double* a, const double* r, int64
 
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream) {
     if (!ctx) return CGP_E_ARG;
-    if (n < 0 || op < 0 || op > 10) return fail(ctx, CGP_E_ARG, "bad op or n");
+    if (n < 0 || op < 0 || op > 11) return fail(ctx, CGP_E_ARG, "bad op or n");
     if (n == 0) return CGP_OK;
     if (!x || !out0) return fail(ctx, CGP_E_ARG, "NULL pointer");
     DeviceScope on_device(ctx->device);

@@ -527,6 +527,54 @@ CGP_DEV void softplus_tail_high(const SpecRegsHigh& H, double t, double& q_scale
     dsp = horner(horner(horner(horner(H.sg[4], t, H.sg[3]), t, H.sg[2]), t, H.sg[1]), t, H.sg[0]);
 }
 
+// The MID regime of the speculative EKF step (round 5): for |x| <= 2, between the two lean regimes,
+//     softplus(x) = x / 2 + g(x^2),   g(w) = log(2 cosh(sqrt(w) / 2));      softplus'(x) = 1 / 2 + x h(x^2),   h(w) = tanh(sqrt(w) / 2) / (2 sqrt(w))
+// with g and h as degree-14 polynomials in w = x^2 (both analytic up to w = -pi^2: Chebyshev interpolation on [0, 4.0008] converges like
+// 7.7^-n; relative error 2.5e-16 / 4.3e-16, the rounding of the coefficients -- tools/gen_math_constants.py).  No exp, no log, no
+// reciprocal: two Estrin evaluations of five dependent levels, where the branch-free full-range form (softplus_pair_any) is a chain of ~ 33.
+// `scale` rides in g's coefficients (and the caller's x / 2 term), `dscale` in h's.
+constexpr double kSoftplusMidG[15] = {0.6931471805599453, 0.1249999999999985, -0.005208333333305166, 0.0003472222220131582, -2.6351685692261904e-05,
+                                      2.1356903149955178e-06, -1.803200077700644e-07, 1.5657248276684575e-08, -1.385960812967277e-09,
+                                      1.2369325852697208e-10, -1.0850756248916867e-11, 8.834323634734408e-13, -6.018381605146707e-14,
+                                      2.903148270175286e-15, -7.119528411200814e-17};
+constexpr double kSoftplusMidH[15] = {0.24999999999999997, -0.02083333333332944, 0.0020833333332603114, -0.00021081349152117946, 2.1356920280814414e-05,
+                                      -2.163870857832512e-06, 2.1923833378278747e-07, -2.2205950615139193e-08, 2.2444102551603243e-09,
+                                      -2.2450104536606832e-10, 2.1645992007368752e-11, -1.8954433287798848e-12, 1.3596116122481806e-13,
+                                      -6.787790406146025e-15, 1.7022413849506242e-16};
+struct SpecRegsMid {
+    double g[15], h[15];
+    CGP_DEV void init(double scale = 1.0, double dscale = 1.0) {
+        CGP_UNROLL for (int i = 0; i < 15; i++) g[i] = FastMathRegs::pin(kSoftplusMidG[i] * scale);
+        CGP_UNROLL for (int i = 0; i < 15; i++) h[i] = FastMathRegs::pin(kSoftplusMidH[i] * dscale);
+    }
+};
+// sum_{i < 15} c[i] w^i, Estrin: five dependent levels behind w
+CGP_DEV double estrin15(const double (&c)[15], double w) {
+    const double w2 = w * w;
+    const double a0 = horner(c[1], w, c[0]), a1 = horner(c[3], w, c[2]), a2 = horner(c[5], w, c[4]), a3 = horner(c[7], w, c[6]);
+    const double a4 = horner(c[9], w, c[8]), a5 = horner(c[11], w, c[10]), a6 = horner(c[13], w, c[12]);
+    const double w4 = w2 * w2;
+    const double b0 = horner(a1, w2, a0), b1 = horner(a3, w2, a2), b2 = horner(a5, w2, a4), b3 = horner(c[14], w2, a6);
+    const double w8 = w4 * w4;
+    const double d0 = horner(b1, w4, b0), d1 = horner(b3, w4, b2);
+    return horner(d1, w8, d0);
+}
+// scale * (softplus(x) - x / 2) and dscale * (softplus'(x) - 1 / 2) / x ... as the two polynomial values: the caller adds the linear terms
+CGP_DEV void softplus_mid_polys(const SpecRegsMid& M, double x, double& g_scaled, double& h_scaled) {
+    const double w = x * x;
+    g_scaled = estrin15(M.g, w);
+    h_scaled = estrin15(M.h, w);
+}
+// the pair itself (scale = dscale = 1): tests, cgp_debug_math
+CGP_DEV void softplus_pair_mid(double x, double& sp, double& dsp) {
+    SpecRegsMid M;
+    M.init();
+    double g, h;
+    softplus_mid_polys(M, x, g, h);
+    sp = fma(0.5, x, g);
+    dsp = fma(x, h, 0.5);
+}
+
 // Pinned coefficients for a per-lane sigma-point fan that is evaluated without regime branches (cgp_mfma4_sigma.hpp,
 // cgp_mfma4_cd.hpp): the lean softplus above (SoftplusRegs) and, for the discrete model's rotation, sin / cos on the
 // reduced range |r| <= pi/4 (Taylor to r^17 / r^16) in Estrin form -- four dependent levels instead of the eight of

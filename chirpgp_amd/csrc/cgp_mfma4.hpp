@@ -205,34 +205,65 @@ CGP_DEV void ekf4_anchor(const Ekf4MfmaConst& K, double u2, Ekf4Anchor& a) {
 // chunk that fails a verdict is repeated with the checked step: with 2^-8 eleven of the bench's 1000 records (largest increment
 // 4.8e-3) repeated a chunk -- and, then still sticky, ran sixteen more on the checked step: 2.10 -> 2.33 ms for the whole launch.
 constexpr unsigned kIncrementBound = 0x3F780000u;
+// The regimes of the speculative step: COMMON u2 in [1.5, 700), HIGH u2 in [5, 700) (shorter polynomials), and -- round 5 -- LOW, u2 in
+// (-700, -1.5]: records the filter has lost (a chirp it never locks on, heavy noise) sit at a NEGATIVE frequency state most of the time
+// (tools/state_histogram.py: 44 - 78 % of the steps of C2_spread's slow record sets below -1.5, 6 - 25 % within +-1.5), where
+//     softplus(u2) = log1p(t),  t = exp(u2) <= 0.22:  theta = ang t q(t),  d softplus / d u2 = t / (1 + t)
+// are the SAME lean polynomials in the same t-range as the common regime's (there t = exp(-u2), theta = ang (u2 + t q(t)), 1 / (1 + t)).
+// MID, |u2| <= 2: softplus and its derivative as two polynomials in u2^2 (cgp_fastmath.hpp: SpecRegsMid) -- no exp, no log, no reciprocal.
+// ANY: the same step with the full-accuracy branch-free softplus for any |u2| < 700 (softplus_pair_any): what a chunk that crosses from one
+// band into the next runs on.
+constexpr int kRegCommon = 0, kRegHigh = 1, kRegLow = 2, kRegAny = 3, kRegMid = 4;
 struct Ekf4Verdict {
     unsigned u = 0u, umin = 0xFFFFFFFFu, d = 0u;
     int di = 0;
-    template <bool HIGH = false> CGP_DEV bool state_in_regime() const {
-        constexpr unsigned lo = HIGH ? 0x40140000u : 0x3FF80000u;
+    bool any_bad = false;                                                   // kRegAny: a step at |u2| >= 700 (or NaN)
+    unsigned uabs = 0u;                                                     // kRegMid: the largest high word of |u2| (NaN above everything)
+    template <int REG = kRegCommon> CGP_DEV bool state_in_regime() const {
+        if constexpr (REG == kRegAny) return !any_bad;
+        if constexpr (REG == kRegMid) return uabs < 0x40000000u;             // |u2| < 2
+        // (raw high words as unsigned numbers: the negative doubles order above the positive ones and by magnitude among themselves)
+        if constexpr (REG == kRegLow) return umin >= 0xBFF80000u && u <= 0xC085DFFFu;           // -1.5 >= u2 > -700 (NaN words lie outside)
+        constexpr unsigned lo = REG == kRegHigh ? 0x40140000u : 0x3FF80000u;
         return u <= 0x4085DFFFu && umin >= lo;
     }
     // 1: the frequency state left the regime, 2: an increment beyond the bound (bits of a wave-uniform code; 0 = the chunk stands)
-    template <bool HIGH = false> CGP_DEV unsigned code() const {
-        const bool state = __builtin_amdgcn_ballot_w64(!state_in_regime<HIGH>()) != 0;
+    template <int REG = kRegCommon> CGP_DEV unsigned code() const {
+        const bool state = __builtin_amdgcn_ballot_w64(!state_in_regime<REG>()) != 0;
         const bool jump = __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound) != 0;
         return (state ? 1u : 0u) | (jump ? 2u : 0u);
     }
-    template <bool HIGH = false> CGP_DEV unsigned long long uncommon() const {
-        return __builtin_amdgcn_ballot_w64(!state_in_regime<HIGH>()) |                                                      // u2 outside [lo, 700)
+    template <int REG = kRegCommon> CGP_DEV unsigned long long uncommon() const {
+        return __builtin_amdgcn_ballot_w64(!state_in_regime<REG>()) |                                                      // u2 outside [lo, 700)
                __builtin_amdgcn_ballot_w64((d & 0x7FFFFFFFu) >= kIncrementBound || ((unsigned)di & 0x7FFFFFFFu) >= kIncrementBound);   // |d| >= 1.5 2^-8
     }
 };
-template <int E1, bool HIGH = false>
+template <int E1, int REG = kRegCommon>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
-                                  double& S, double& innov, Ekf4Verdict& verdict) {
+                                  double& S, double& innov, Ekf4Verdict& verdict, const SpecRegsMid* RM = nullptr) {
     const double u2 = (E1 == 2) ? x.u2_replicated() : x.u2();
-    const double t = HIGH ? exp_neg_high(R, RH, u2) : exp_neg_lean1(R, u2);
-    const double lin = fma(K.angm, u2, -a.th);                                       // off the chain: needs u2 only
-    double qa, dsp;
-    if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);
-    else softplus_tail_lean(R, t, qa, dsp);                                          // qa = ang log1p(t) / t
-    const double d = fma(qa, t, lin);
+    constexpr bool HIGH = REG == kRegHigh, LOW = REG == kRegLow, ANY = REG == kRegAny, MID = REG == kRegMid;
+    double d, jfac;                                                                  // the angle's increment; (kj ang) x the softplus derivative
+    if constexpr (MID) {
+        double ga, hj;                                                               // ang g(u2^2), kja h(u2^2): the scales ride in the coefficients
+        softplus_mid_polys(*RM, u2, ga, hj);
+        d = ga + fma(0.5 * K.angm, u2, -a.th);                                       // (the second term does not wait for the polynomial)
+        jfac = fma(u2, hj, 0.5 * K.kja);
+    } else if constexpr (ANY) {
+        double sp, dspf; bool ok;
+        softplus_pair_any(u2, sp, dspf, ok);
+        verdict.any_bad = verdict.any_bad || !ok;
+        d = fma(K.angm, sp, -a.th);
+        jfac = K.kja * dspf;
+    } else {
+        const double t = HIGH ? exp_neg_high(R, RH, u2) : exp_neg_lean1(R, LOW ? -u2 : u2);     // LOW: t = exp(u2)
+        const double lin = LOW ? -a.th : fma(K.angm, u2, -a.th);                     // off the chain: needs u2 only (LOW: theta = ang t q(t))
+        double qa, dsp;
+        if constexpr (HIGH) softplus_tail_high(RH, t, qa, dsp);
+        else softplus_tail_lean(R, t, qa, dsp);                                      // qa = ang log1p(t) / t
+        d = fma(qa, t, lin);
+        jfac = HIGH ? dsp : LOW ? (K.kja * t) * dsp : K.kja * dsp;                    // (HIGH: K.kja rides in the polynomial, SpecRegsHigh::init; LOW: t / (1 + t))
+    }
     // The rotation by d as three shears (round 4) -- exact for tau = tan(d / 2), s = sin d, and of determinant 1 for ANY tau, s:
     //     A1 = A + tau B,   B' = B - s A1,   A' = A1 + tau B',        tau = d (1/2 + d^2 / 24),   s = d (1 - d^2 / 6)
     // eight operations where cos d, sin d and the four products of the plain rotation took ten (2.19 -> 2.15 ms).  Dropped terms:
@@ -245,12 +276,17 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
     const double B = fma(-sn, A1, a.B);
     const double A = fma(tau, B, A1);
     const unsigned hx = (unsigned)__double2hiint(u2), hd = (unsigned)__double2hiint(d);
-    verdict.u = verdict.u > hx ? verdict.u : hx;
-    verdict.umin = verdict.umin < hx ? verdict.umin : hx;
+    if constexpr (MID) {
+        const unsigned ha = hx & 0x7FFFFFFFu;
+        verdict.uabs = verdict.uabs > ha ? verdict.uabs : ha;
+    } else if constexpr (!ANY) {
+        verdict.u = verdict.u > hx ? verdict.u : hx;
+        verdict.umin = verdict.umin < hx ? verdict.umin : hx;
+    }
     verdict.d = verdict.d > hd ? verdict.d : hd;
     verdict.di = verdict.di > (int)hd ? verdict.di : (int)hd;
     a.th += d; a.A = A; a.B = B;
-    ekf4_mfma_finish_j<E1>(K, y, A, HIGH ? dsp : K.kja * dsp, x, S, innov);          // HIGH: K.kja rides in the polynomial (SpecRegsHigh::init)
+    ekf4_mfma_finish_j<E1>(K, y, A, jfac, x, S, innov);
 }
 
 // Tried with it and dropped (all measured on the bench configuration, same box, A/B): a third, FLAT regime for chunks that start
@@ -330,7 +366,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
     int checked_left = 0;
-    unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0, n_wide = 0;      // chunks by regime (scalars; cgp_debug_counters)
+    unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0, n_wide = 0, n_low = 0, n_mid = 0;      // chunks by regime (scalars; cgp_debug_counters)
     // The rotation pair is re-anchored with the full softplus and sincos (a dependent chain of ~ 70 operations) every FOURTH
     // accepted chunk only (round 4): an accepted chunk hands its last (theta, A, B) to the next one -- one rounding per step in the
     // rotation, 256 steps at most: 3e-14.
@@ -359,77 +395,115 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         ynext = (t0 + 64 + lane < Te) ? ys[t0 + 64 + lane] : 0.0;
         const int nsteps = (Te - t0 < 64) ? (int)(Te - t0) : 64;
         const Ekf4State x0 = x;
-        unsigned uncommon = 0;                                              // Ekf4Verdict::code of the chunk's last speculative pass
-        if (checked_left == 0) {
-            Ekf4Anchor anchor0, anchor_end;
-            if (anchor_age < 0 || anchor_age >= 4) { ekf4_anchor(K, x.u2(), anchor0); anchor_age = 0; }
-            else anchor0 = anchor_live;
-            // The step's measurement: the chunk's 64 values go to LDS once, and every group of steps reads its own with
-            // broadcast ds_read_b128 one group ahead -- a v_readlane pair per step costs 24 issue cycles
-            // (tools/ubench/issue_costs.hip)
-            ybuf[lane] = ychunk;
-            wave_lds_fence();
-            // One speculative pass over the chunk; HIGH: on the short polynomials of the regime u2 >= 5 (SpecRegsHigh).
-            auto chunk = [&](auto high_c) {
-                constexpr bool HIGH = decltype(high_c)::value;
-                Ekf4Anchor anchor = anchor0;
-                Ekf4Verdict verdict;
-                // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in
-                // a vector offset of its own (hoisted out of the loop) -- no scalar add per step
-                auto one = [&](int slot, unsigned k, double y) {
-                    double S, innov;
-                    ekf4_mfma_step_spec1<E1 ? 2 : 0, HIGH>(K, R, RH, y, x, anchor, S, innov, verdict);
-                    park[(slot + k) * kParkStride] = make_double2(S, innov);
-                    const unsigned t = (unsigned)(t0 + slot);
-                    Pw.store_s(x.P, p_off + k * 128u, t * 128u);
-                    mw.store_s(x.uq, m_off + k * 32u, t * 32u);
-                };
-                int slot = 0;
-                // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms;
-                // the same loop written generically over the group size -- arrays of read-ahead registers, one lambda for both
-                // group sizes -- compiled to a schedule that gained nothing, with 8 or with 16 steps)
-                double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
-                double2 yc = *reinterpret_cast<const double2*>(ybuf + 4), yd = *reinterpret_cast<const double2*>(ybuf + 6);
-                for (; slot + 8 <= nsteps; slot += 8) {
-                    const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 8), nb = *reinterpret_cast<const double2*>(ybuf + slot + 10);
-                    const double2 nc = *reinterpret_cast<const double2*>(ybuf + slot + 12), nd = *reinterpret_cast<const double2*>(ybuf + slot + 14);
-                    one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
-                    one(slot, 4u, yc.x); one(slot, 5u, yc.y); one(slot, 6u, yd.x); one(slot, 7u, yd.y);
-                    ya = na; yb = nb; yc = nc; yd = nd;
-                }
-                for (; slot + 4 <= nsteps; slot += 4) {
-                    const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
-                    one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
-                    ya = na; yb = nb;
-                }
-                for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
-                anchor_end = anchor;
-                return verdict.template code<HIGH>();
+        const unsigned hx0 = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2()));
+        const bool low = !nll_final && hx0 - 0xBFFC0000u <= 0xC085DFFFu - 0xBFFC0000u;      // -1.75 >= u2 > -700 at the chunk's start
+        const bool mid = !nll_final && (hx0 & 0x7FFFFFFFu) < 0x3FF80000u;                   // |u2| < 1.5: the MID regime's chunk (it holds while |u2| < 2)
+        // 1.5 <= |u2| < 1.75: within a quarter of a band's end (with 2: the records that sit at -2 -- the 20 Hz chirp never locked on --
+        // lose the LOW regime, 2.42 -> 2.68 ms; the noisy ones gain 2 %)
+        const bool edge = !nll_final && !mid && (hx0 & 0x7FFFFFFFu) < 0x3FFC0000u;
+        // The chunk's measurements go to LDS once, and every group of steps reads its own with broadcast ds_read_b128 one group ahead
+        // -- a v_readlane pair per step costs 24 issue cycles (tools/ubench/issue_costs.hip)
+        ybuf[lane] = ychunk;
+        wave_lds_fence();
+        // the rotation pair at the chunk's first state: carried over from the last accepted chunk, or re-anchored; every attempt of
+        // this chunk starts from it
+        Ekf4Anchor anchor0, anchor_end;
+        if (anchor_age < 0 || anchor_age >= 4) { ekf4_anchor(K, x.u2(), anchor0); anchor_age = 0; }
+        else anchor0 = anchor_live;
+        // One speculative pass over the chunk in regime REG: kRegCommon, kRegHigh (the short polynomials of u2 >= 5: SpecRegsHigh),
+        // kRegLow, kRegAny.
+        auto chunk = [&](auto reg_c) {
+            constexpr int REG = decltype(reg_c)::value;
+            // (the MID regime's 30 coefficients are pinned for the duration of ITS chunks only -- sixty moves and thirty products a chunk:
+            // held for the whole kernel they cost the HIGH chunks of the bench records 3.5 %, measured)
+            SpecRegsMid RM;
+            if constexpr (REG == kRegMid) RM.init(K.angm, K.kja);
+            Ekf4Anchor anchor = anchor0;
+            Ekf4Verdict verdict;
+            // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in
+            // a vector offset of its own (hoisted out of the loop) -- no scalar add per step
+            auto one = [&](int slot, unsigned k, double y) {
+                double S, innov;
+                ekf4_mfma_step_spec1<E1 ? 2 : 0, REG>(K, R, RH, y, x, anchor, S, innov, verdict, &RM);
+                park[(slot + k) * kParkStride] = make_double2(S, innov);
+                const unsigned t = (unsigned)(t0 + slot);
+                Pw.store_s(x.P, p_off + k * 128u, t * 128u);
+                mw.store_s(x.uq, m_off + k * 32u, t * 32u);
             };
+            int slot = 0;
+            // eight steps as straight-line code, then groups of four (a taken loop branch costs ~ 30 cycles: 2.38 -> 2.34 ms;
+            // the same loop written generically over the group size -- arrays of read-ahead registers, one lambda for both
+            // group sizes -- compiled to a schedule that gained nothing, with 8 or with 16 steps)
+            double2 ya = *reinterpret_cast<const double2*>(ybuf), yb = *reinterpret_cast<const double2*>(ybuf + 2);
+            double2 yc = *reinterpret_cast<const double2*>(ybuf + 4), yd = *reinterpret_cast<const double2*>(ybuf + 6);
+            for (; slot + 8 <= nsteps; slot += 8) {
+                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 8), nb = *reinterpret_cast<const double2*>(ybuf + slot + 10);
+                const double2 nc = *reinterpret_cast<const double2*>(ybuf + slot + 12), nd = *reinterpret_cast<const double2*>(ybuf + slot + 14);
+                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
+                one(slot, 4u, yc.x); one(slot, 5u, yc.y); one(slot, 6u, yd.x); one(slot, 7u, yd.y);
+                ya = na; yb = nb; yc = nc; yd = nd;
+            }
+            for (; slot + 4 <= nsteps; slot += 4) {
+                const double2 na = *reinterpret_cast<const double2*>(ybuf + slot + 4), nb = *reinterpret_cast<const double2*>(ybuf + slot + 6);
+                one(slot, 0u, ya.x); one(slot, 1u, ya.y); one(slot, 2u, yb.x); one(slot, 3u, yb.y);
+                ya = na; yb = nb;
+            }
+            for (; slot < nsteps; slot++) one(slot, 0u, readlane_f64(ychunk, slot));
+            anchor_end = anchor;
+            return verdict.template code<REG>();
+        };
+        unsigned uncommon = 1;                                              // Ekf4Verdict::code of the chunk's last speculative pass
+        // (where the state sits at the chunk's start is known: LOW and MID chunks are tried in their regime also while the sticky count runs;
+        // a chunk that starts at the edge of a band goes to the ANY regime at once -- a pass that fails is a pass wasted, and the kernel's
+        // time is that of its slowest wavefront)
+        const bool lean_tried = low || mid || (checked_left == 0 && !edge);
+        if (lean_tried) {
             // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
             // which falls out of it; with 5.5, round 3's threshold, 77 % and 1.7 % repeated: 1.4 % more time in all); one that
             // leaves it is repeated from its saved state in the common regime.
             // (Not for an NLL-only launch: that is the objective of a maximum-likelihood fit, differentiated by finite differences --
             // a chunk that changes regime between two probes would put a 1e-13 step into it, and the optimiser's path with it.)
             bool high = false;
-            if constexpr (E1) high = !nll_final && (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x.u2())) - 0x401A0000u < 0x4085DFFFu - 0x401A0000u;
-            uncommon = 1;
-            if (high) {
-                uncommon = chunk(std::true_type{});
-                if (uncommon != 0) { x = x0; n_high_left++; } else n_high++;
+            if constexpr (E1) high = !nll_final && hx0 - 0x401A0000u < 0x4085DFFFu - 0x401A0000u;
+            if (low) {
+                // (round 5) a chunk that starts at u2 <= -1.75 is tried in the LOW regime: records that have left the common regime sit
+                // there most of the time
+                uncommon = chunk(std::integral_constant<int, kRegLow>{});
+                if (uncommon == 0) n_low++;
+            } else if (mid) {
+                uncommon = chunk(std::integral_constant<int, kRegMid>{});
+                if (uncommon == 0) n_mid++;
+            } else {
+                if (high) {
+                    uncommon = chunk(std::integral_constant<int, kRegHigh>{});
+                    if (uncommon != 0) { x = x0; n_high_left++; } else n_high++;
+                }
+                if (uncommon != 0) {
+                    uncommon = chunk(std::integral_constant<int, kRegCommon>{});
+                    if (uncommon == 0) n_common++;
+                }
             }
-            if (uncommon != 0) {
-                uncommon = chunk(std::false_type{});
-                if (uncommon == 0) n_common++;
-            }
-            if (uncommon == 0) { anchor_live = anchor_end; anchor_age++; } else anchor_age = -1;
         }
-        const bool redo = uncommon != 0;                                    // a scalar: identical in every lane
-        if (checked_left > 0 || redo) {
-            // a record whose frequency state left the regime probably stays outside: the next chunks go straight to the checked
-            // step; a single jump of the angle (code 2 alone) says nothing about the next chunk
-            if (redo) { x = x0; checked_left = (uncommon & 1u) ? kCheckedChunks : 1; n_redo++; }
-            // first on the wide step (branch-free, any |u2| < 700); a chunk that leaves even that is repeated with the checked step
+        if (uncommon != 0) {
+            // a record whose frequency state left the lean regimes probably stays outside: the next chunks go straight to the tiers
+            // below; a single jump of the angle (code 2 alone) says nothing about the next chunk
+            // (a chunk that left the LOW or the MID band says where the NEXT one starts, and that decides its regime: nothing sticky)
+            if (lean_tried) { x = x0; checked_left = (!(low || mid) && (uncommon & 1u)) ? kCheckedChunks : 1; n_redo++; }
+            // (round 5) first in the ANY regime -- the speculative step with the branch-free full-accuracy softplus for any |u2| < 700
+            // (cgp_fastmath.hpp: softplus_pair_any) and the SAME incremental rotation: 6 dependent operations where the wide step below
+            // takes a fresh sincos --, then ...
+            uncommon = chunk(std::integral_constant<int, kRegAny>{});
+            if (uncommon == 0) { if (!lean_tried) n_wide++; }
+        }
+        if (uncommon == 0) {
+            anchor_live = anchor_end; anchor_age++;
+            if (checked_left > 0) checked_left--;
+        } else {
+            // ... on the wide step (full sincos: a jump of the angle beyond the increment bound); a chunk that leaves even that is repeated
+            // with the checked step
+            anchor_age = -1;
+            x = x0;
+            const bool redo = lean_tried;
             bool bad = false;
             auto wide_one = [&](int slot, double y) {
                 double S, innov;
@@ -440,7 +514,6 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 mw.store_s(x.uq, m_off, t * 32u);
             };
             // four steps as straight-line code with their measurements read from LDS (a v_readlane pair per step: 24 issue cycles)
-            if (checked_left > 0 && !redo) { ybuf[lane] = ychunk; wave_lds_fence(); }      // (a speculative pass has staged them already)
             int wslot = 0;
             for (; wslot + 4 <= nsteps; wslot += 4) {
                 const double2 ya = *reinterpret_cast<const double2*>(ybuf + wslot), yb = *reinterpret_cast<const double2*>(ybuf + wslot + 2);
@@ -459,7 +532,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
                 }
                 if (!redo) n_checked++;
             } else if (!redo) n_wide++;
-            checked_left--;
+            if (checked_left > 0) checked_left--;
         }
         if (want_nll && !burn) {
             wave_lds_fence();
@@ -476,6 +549,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         atomicAdd(io.counters + 0, (unsigned long long)n_high); atomicAdd(io.counters + 1, (unsigned long long)n_common);
         atomicAdd(io.counters + 2, (unsigned long long)n_redo); atomicAdd(io.counters + 3, (unsigned long long)n_checked);
         atomicAdd(io.counters + 4, (unsigned long long)n_high_left); atomicAdd(io.counters + 5, (unsigned long long)n_wide);
+        atomicAdd(io.counters + 6, (unsigned long long)n_low); atomicAdd(io.counters + 7, (unsigned long long)n_mid);
     }
 }
 
@@ -595,6 +669,14 @@ __global__ void __launch_bounds__(64) ekf4_mfma_kernel(FilterIO io, ModelArgs ma
 }
 
 
+#endif  // CGP_EKF4_KERNELS
+
+// (round 5) the four-trials-per-wavefront kernel lives in a translation unit of its own (cgp_inst_ekf4_x4.hip): the one-trial kernel's
+// unit is compiled without machine-level loop-invariant code motion (Makefile), which costs this one 14 %
+inline bool ekf4_mfma_x4_fits(const FilterIO& io) { return io.T * 512 <= kOobMaxBytes; }
+int launch_ekf4_mfma_x4(const FilterIO& io, const ModelArgs& ma, hipStream_t stream);
+
+#ifdef CGP_EKF4_X4_KERNELS
 // ---------------------------------------------------------------------------------------------- four trials per wave
 // The four blocks of the MFMA are independent, so for batches beyond one wave per SIMD each block carries its own
 // trial: lane 16 r + 4 b + q works on trial 4 * blockIdx.x + b.  The step functions above are used as they are -- they
@@ -750,8 +832,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, DENS
 }
 
 // 4 T x 128 bytes of covariance rows must fit the 2 GiB window of a wave
-inline bool ekf4_mfma_x4_fits(const FilterIO& io) { return io.T * 512 <= kOobMaxBytes; }
+inline int launch_ekf4_mfma_x4_impl(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
+    if (io.B > 4096) hipLaunchKernelGGL(ekf4_mfma_x4_kernel<true>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+    else hipLaunchKernelGGL(ekf4_mfma_x4_kernel<false>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+#endif  // CGP_EKF4_X4_KERNELS
 
+#ifdef CGP_EKF4_KERNELS
 inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     // the kernels address a trial's covariance rows through a 32-bit byte offset into a 2 GiB buffer window: a record too
@@ -761,10 +849,7 @@ inline int launch_ekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream_t
     if (io.segs > 1)           // time-split with burn-in: one wavefront per (trial, segment)
         hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)(io.B * io.segs)), dim3(64), 0, stream, io, ma);
     else if ((io.B > 1024 || (io.flags & CGP_FOUR_TRIALS_PER_WAVE)) && ekf4_mfma_x4_fits(io) && !(io.flags & CGP_ONE_TRIAL_PER_WAVE))
-    {
-        if (io.B > 4096) hipLaunchKernelGGL(ekf4_mfma_x4_kernel<true>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
-        else hipLaunchKernelGGL(ekf4_mfma_x4_kernel<false>, dim3((unsigned)((io.B + 3) / 4)), dim3(64), 0, stream, io, ma);
-    }
+        return launch_ekf4_mfma_x4(io, ma, stream);
     else
         hipLaunchKernelGGL(ekf4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
     return hip_rc(hipGetLastError());

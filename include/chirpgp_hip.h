@@ -269,7 +269,7 @@ int cgp_debug_philox(cgp_ctx* ctx, const uint32_t* ctr, const uint32_t* key, int
  *     4 softplus pair (out0 = log(exp(x) + 1), out1 = its derivative), 5 / 6 the wave-uniform variants of 4 / 2,
  *     7 the per-lane softplus pair in its wide common-regime form (with the naive fallback), 8 the speculative step's
  *     lean softplus pair (valid for 1.5 <= x < 700 only; ~1e-11), 9 reciprocal with one Newton step, 10 the branch-free softplus pair
- *     for any |x| < 700 (NaN where it reports "not valid").
+ *     for any |x| < 700 (NaN where it reports "not valid"), 11 the polynomial softplus pair of the MID regime (valid for |x| <= 2).
  *     out1 may be NULL for one-output ops. */
 int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out0, double* out1, void* stream);
 
@@ -286,7 +286,8 @@ int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value);
  *   out[2] chunks repeated with the checked step (left the common regime)           out[3] chunks run on the checked step after such a repeat
  *   out[4] chunks that were tried in the HIGH regime, left it and were repeated in the common regime
  *   out[5] chunks run on the WIDE step after such a repeat (branch-free, any |state| < 700; round 5: out[3] counts only those that left even that)
- *   out[6..7] reserved (0) */
+ *   out[6] chunks kept from the LOW regime (round 5: frequency state <= -1.5 throughout, tried for chunks that start at or below -1.75)
+ *   out[7] chunks kept from the MID regime (round 5: |frequency state| < 2 throughout, tried for chunks that start within +-1.75) */
 int cgp_debug_counters(cgp_ctx* ctx, uint64_t* out, int reset, void* stream);
 
 #ifdef __cplusplus

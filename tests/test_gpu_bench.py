@@ -70,7 +70,7 @@ def test_default_line_carries_the_other_baseline_configs():
     assert set(oc) == {'C1', 'C2_low_freq', 'C3', 'C4', 'C5', 'CRLB_ekf', 'CRLB_ghf', 'C2_spread', 'time_split_filters'}
     # the regimes the headline filter ran its 64-step chunks in: counted by the kernel itself (cgp_debug_counters)
     rg = r['regimes']
-    assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['redone'] + rg['wide'] + rg['checked'] == rg['chunks']
+    assert rg['chunks'] == 1000 * 157 and rg['high'] + rg['common'] + rg['low'] + rg['mid'] + rg['redone'] + rg['wide'] + rg['checked'] == rg['chunks']
     assert 0.7 < rg['high_share'] < 0.85 and rg['high_left'] < 0.05 * rg['chunks'] and rg['redone'] < 0.01 * rg['chunks']
     low = oc['C2_low_freq']
     assert (low['batch_per_gpu'], low['T'], low['d']) == (1000, 10000, 4) and low['filter_ms'] > 0 and low['smoother_ms'] > 0
@@ -88,7 +88,11 @@ def test_default_line_carries_the_other_baseline_configs():
     # the headline's dependence on its data, measured: 45 record sets of the headline shape
     sp = oc['C2_spread']
     assert sp['combinations'] == 45 and len(sp['rows']) == 45 and sp['value_min'] <= sp['value_median'] <= sp['value_max']
-    assert sp['slowest_over_median_time'] < 1.15, sp['slowest']                       # no record set more than 15 % slower than the median
+    # Bounded from both sides.  Round 5 first held "no record set more than 1.15 x the median pass" -- true at 1.05, with the median itself
+    # at 0.63 of the headline.  With the LOW / MID / ANY regimes of the speculative step EVERY record set is faster (slowest pass 4.5 -> 3.9
+    # ms) and the median sits at 0.84 of the headline; the ratio of the two moved to 1.19 because the median gained more than the slowest.
+    assert sp['slowest_over_median_time'] < 1.25, sp['slowest']                       # no record set more than 25 % slower than the median
+    assert sp['value_median'] > 0.75 * r['value'], (sp['value_median'], r['value'])   # ... and the median within 25 % of the headline
     assert sp['redone_plus_checked_share_at_reference_inputs'] <= 0.01                # the reference's inputs, any seed: <= 1 % of the chunks repeated
     ts = oc['time_split_filters']
     for k in ('C2_shard', 'C3_shard', 'C4_per_gpu'):                      # the chirp filters forget: junctions at 1e-6 or better, >= 1.4 x

@@ -165,3 +165,23 @@ def test_branch_free_softplus_pair_for_any_argument():
     assert _ulp_err(dsp, [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x]) < 2e-15
     bad, _ = E.debug_math(10, np.array([700., -700., 1e4, np.inf, -np.inf, np.nan]))
     assert np.isnan(bad).all()
+
+
+def test_mid_band_softplus_pair_as_polynomials():
+    """softplus_pair_mid (cgp_fastmath.hpp; the MID regime of the matrix-core EKF's speculative step): for |x| <= 2 the softplus is
+    x / 2 + g(x^2) and its derivative 1 / 2 + x h(x^2), g and h degree-14 polynomials -- no exp, no log, no reciprocal -- to a few ulp
+    of a 200-bit reference (coefficients: tools/gen_math_constants.py)."""
+    import mpmath as mp
+    from chirpgp_amd import _engine as E
+    mp.mp.prec = 200
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-2, 2, 6000), [0., 1e-300, -1e-300, 2., -2., 1.75, -1.75, 1e-8, -1e-8]])
+    sp, dsp = E.debug_math(11, x)
+    # ABSOLUTE accuracy is what the filter needs of them (the rotation angle is a multiple of the softplus, the Jacobian column of the
+    # derivative): a few 1e-16 (two ulp).  Relative to a softplus that is itself small -- 0.127 at x = -2, where x / 2 = -1 and g = 1.127 cancel --
+    # that is up to 3e-15.
+    want_sp = [mp.log1p(mp.exp(mp.mpf(float(v)))) for v in x]
+    want_d = [1 / (1 + mp.exp(-mp.mpf(float(v)))) for v in x]
+    assert max(abs(float(mp.mpf(float(g)) - w)) for g, w in zip(sp, want_sp)) < 1e-15          # (2 ulp at 2.1)
+    assert max(abs(float(mp.mpf(float(g)) - w)) for g, w in zip(dsp, want_d)) < 5e-16
+    assert _ulp_err(sp, want_sp) < 4e-15 and _ulp_err(dsp, want_d) < 3e-15

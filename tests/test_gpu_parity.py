@@ -1020,11 +1020,13 @@ def test_wide_step_for_records_outside_the_lean_regime():
         for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
             assert cs.max_rel_err(g, w) <= 1e-9, (label, n, cs.max_rel_err(g, w))
         chunks = B * ((T + 63) // 64)
-        assert rg['high'] + rg['common'] + rg['redone'] + rg['wide'] + rg['checked'] == chunks
+        assert rg['high'] + rg['common'] + rg['low'] + rg['mid'] + rg['redone'] + rg['wide'] + rg['checked'] == chunks
         if label == 'overflow':
             assert rg['checked'] > 0
         else:
-            assert rg['wide'] > 0.2 * chunks and rg['checked'] == 0, (label, rg)
+            assert rg['wide'] + rg['low'] + rg['mid'] > 0.2 * chunks and rg['checked'] == 0, (label, rg)
+            if label == 'negative start':
+                assert rg['low'] > 0, rg                                # chunks that start at or below -1.75: the LOW regime of the lean step
 
 
 @pytest.mark.parametrize('kind', ['sgp', 'cd_sgp', 'harmonic'])
