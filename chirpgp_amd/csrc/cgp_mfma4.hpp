@@ -24,10 +24,14 @@
 // cuts the step into basic blocks that cannot be interleaved (tools/ekf_variants.py: 167 cycles of a 1070-cycle step
 // for the two never-taken regime checks of softplus and sincos).  So a chunk of 64 steps first runs with NO branches --
 // the common-regime formulas evaluated blindly (ekf4_mfma_step_spec), the verdicts ORed into a scalar -- and only if
-// some step left the common regime (frequency state below ln 2 or above 700, a jump of the rotation angle beyond the
-// increment bound, inf, NaN) is the chunk repeated from its saved state with the checked step, which evaluates the
-// full functions and reproduces the reference's naive arithmetic there.  After a repeat the kernel stays on the
-// checked step for kCheckedChunks chunks, so a record that lives outside the common regime pays at most 1/16 extra.
+// some step left the regime (frequency state outside its band, a jump of the rotation angle beyond the increment bound,
+// inf, NaN) is the chunk repeated from its saved state on the next tier.  Since round 5 the regime of a chunk is chosen from
+// the state at its start -- HIGH (u >= 5), COMMON (u >= 1.5), LOW (u <= -1.5), MID (|u| < 2), all branch-free with short
+// polynomials (Ekf4Verdict below) -- and the tiers behind them are ANY (the same step with the full-accuracy softplus for
+// any |u| < 700), WIDE (a fresh sincos per step: a jump of the angle) and the CHECKED step, which evaluates the full
+// functions with their regime branches and reproduces the reference's naive arithmetic (overflow beyond 700, NaN).  After
+// a chunk left the COMMON regime the kernel stays off it for kCheckedChunks chunks (chunks that start in the LOW or the
+// MID band are tried there all the same), so a record that hovers around its end pays at most 1/16 extra.
 #pragma once
 #include "cgp_coop4.hpp"
 

@@ -44,6 +44,11 @@ CGP_DEV double log1p_over_t_lean(double t) {
 // precompute_any below): spec first; if a lane is outside its regime, any; checked as the last resort
 constexpr int kFanChecked = 0, kFanSpec = 1, kFanAny = 2;
 CGP_DEV bool softplus_lane_common(double x) { return x >= 1.5 && x < 700.0; }
+// The lean softplus on BOTH sides (round 5; the sigma-point fans, which need no derivative): with t = exp(-|x|) <= 0.223 for |x| >= 1.5,
+//     softplus(x) = max(x, 0) + log1p(t) = max(x, 0) + t q(t)
+// -- for x <= -1.5 the same polynomials in the same t-range as for x >= 1.5, one v_max_f64 off the chain.  Records the filter has lost sit at
+// a NEGATIVE frequency state most of the time (tools/state_histogram.py): their fans stay in the lean tier.
+CGP_DEV bool softplus_lane_lean2(double x) { return fabs(x) >= 1.5 && fabs(x) < 700.0; }
 CGP_DEV void softplus_pair_wide(double x, double& sp, double& dsp) {
     const double t = exp_neg_lean_lane(x);
     sp = fma(log1p_over_t_lean(t), t, x);
@@ -232,15 +237,18 @@ template <int NH> struct HarmonicLCD {
     CGP_DEV void precompute(double uv, Pre& p) const { rotations((kTwoPi * softplus_sel(wide, uv)) * fs, p.c, p.s); }
     // precompute() WITHOUT its two regime branches and with pinned coefficients, for kernels that interleave several fans
     // in one basic block: the lean softplus and the reduced-range sin / cos taken as is.  ok = the lane is in the regime
-    // where that is valid (1.5 <= uv < 700 and a rotation angle within pi/4, i.e. n = 0 in the Cody-Waite reduction); the
+    // where that is valid (1.5 <= uv < 700 -- |uv| for the multi-harmonic models -- and a rotation angle within pi/4, i.e. n = 0 in the Cody-Waite reduction); the
     // caller re-evaluates with precompute() if any lane is not.
     CGP_DEV void precompute_spec(const FanRegs& R, double uv, Pre& p, bool& ok) const {
-        const double t = exp_neg_lean(R, uv);
+        // (the two-sided lean form, softplus_lane_lean2, for the multi-harmonic models only: the d = 8 filter on records outside the
+        // common regime 12.7 -> 10.6 ms; the d = 4 matrix-core filter, whose fan straddles the band's end anyway, LOST 3 % to it)
+        constexpr bool TWO_SIDED = NH > 1;
+        const double t = exp_neg_lean(R, TWO_SIDED ? fabs(uv) : uv);
         double q, unused;
         softplus_tail_lean(R, t, q, unused);
-        const double sp = fma(q, t, uv);
+        const double sp = fma(q, t, TWO_SIDED ? fmax(uv, 0.0) : uv);
         const double x = sp * ((kTwoPi * fs) * dt);           // loop-invariant factor: one multiplication on the chain
-        ok = softplus_lane_common(uv) && fabs(x) <= kPiOver4;
+        ok = (TWO_SIDED ? softplus_lane_lean2(uv) : softplus_lane_common(uv)) && fabs(x) <= kPiOver4;
         double s1, c1;
         sincos_reduced(R, x, s1, c1);
         double ck = c1, sk = s1;
