@@ -77,6 +77,12 @@ CGP_DEV double div_nr(double n, double d) {
     const double q = n * r;
     return fma(fma(-d, q, n), r, q);
 }
+// the same from the one-step reciprocal: its 2.2e-15 goes into the quotient squared by the residual correction (<= 1 ulp), two FMAs less
+CGP_DEV double div_nr1(double n, double d) {
+    const double r = rcp_nr1(d);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
 
 // sum_{i <= 13} r^i / i!, Horner.  (Estrin's scheme was measured here too: neutral in the sigma-point and lane-per-trial
 // kernels, which have other work to overlap; it pays only in the cooperative EKF, see softplus_pair_uniform below.)
@@ -136,7 +142,7 @@ CGP_DEV double fast_log_ge1_finite(double z) {
     const int e = __builtin_amdgcn_frexp_exp(z * 1.4142135623730951) - 1;
     const double m = __builtin_amdgcn_ldexp(z, -e);
     const double k = (double)e;
-    const double s = div_nr(m - 1.0, m + 1.0);
+    const double s = div_nr1(m - 1.0, m + 1.0);
     const double s2 = s * s;
     const double p = atanh_tail_poly(s2);
     const double two_s = s + s;
@@ -189,7 +195,18 @@ CGP_DEV void fast_sincos(double x, double& sn, double& cs) {
 // fast_sincos for kernels whose angles are small throughout (one lane per trial at dt = 0.01: the rotation angle is dt 2 pi g(u) ~ 0.06 g):
 // if every active lane's |x| <= pi / 4 the Cody-Waite reduction is the identity (n = 0, r = x, no swap, no sign flip) and is skipped -- the
 // same bits, ~ 18 instructions less; one wave-uniform branch, otherwise fast_sincos as is (NaN and inf take that way).
+// ... and while every lane's |x| <= 1/4 (a frequency below 4 Hz at that step) the series end four terms earlier: sin to x^11, cos to x^12
+// (truncation 2.4e-18 / 4e-20), five instructions less.
+CGP_DEV void sincos_quarter(double r, double& s0, double& c0) {
+    const double r2 = r * r;
+    double ps = kSinTaylor[3], pc = kCosTaylor[2];                       // 1/11!, 1/12!
+    CGP_UNROLL for (int i = 4; i < 8; i++) ps = horner_c(ps, r2, kSinTaylor[i]);
+    CGP_UNROLL for (int i = 3; i < 7; i++) pc = horner_c(pc, r2, kCosTaylor[i]);
+    s0 = fma(-(r * r2), ps, r);
+    c0 = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+}
 CGP_DEV void fast_sincos_small(double x, double& sn, double& cs) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabs(x) <= 0.25)) == 0, 1)) { sincos_quarter(x, sn, cs); return; }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabs(x) <= kPiOver4)) == 0, 1)) { sincos_reduced(x, sn, cs); return; }
     fast_sincos(x, sn, cs);
 }

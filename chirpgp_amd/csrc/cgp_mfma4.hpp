@@ -369,7 +369,7 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double2 park[64 * kParkStride];
     __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
-    int checked_left = 0;
+    int checked_left = 0, spec_off = 0, jump_streak = 0;                    // sticky counts: off the common regime / off every speculative regime
     unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0, n_wide = 0, n_low = 0, n_mid = 0;      // chunks by regime (scalars; cgp_debug_counters)
     // The rotation pair is re-anchored with the full softplus and sincos (a dependent chain of ~ 70 operations) every FOURTH
     // accepted chunk only (round 4): an accepted chunk hands its last (theta, A, B) to the next one -- one rounding per step in the
@@ -460,7 +460,13 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         // (where the state sits at the chunk's start is known: LOW and MID chunks are tried in their regime also while the sticky count runs;
         // a chunk that starts at the edge of a band goes to the ANY regime at once -- a pass that fails is a pass wasted, and the kernel's
         // time is that of its slowest wavefront)
-        const bool lean_tried = low || mid || (checked_left == 0 && !edge);
+        // Every speculative regime rotates by INCREMENTS; records whose angle jumps beyond the increment bound in many chunks (the CRLB jobs'
+        // at dt = 0.01, where the ANY regime behind a failed pass failed the same way: 927 ns a step) back off: after a jump the speculative
+        // regimes are off for 2, 4, 8, 16 chunks (doubling with every jump, one doubling back with every chunk kept in a regime), and those
+        // chunks go straight to the wide step -- 482 ns a step there (423 before the LOW / MID / ANY regimes, when every such chunk went to the
+        // wide step; backing off after ANY failed pass, not just a jump, gave the same 482 and cost the lost-track record sets 5 %)
+        const bool spec_allowed = spec_off == 0;
+        const bool lean_tried = spec_allowed && (low || mid || (checked_left == 0 && !edge));
         if (lean_tried) {
             // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
             // which falls out of it; with 5.5, round 3's threshold, 77 % and 1.7 % repeated: 1.4 % more time in all); one that
@@ -496,13 +502,21 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             // (round 5) first in the ANY regime -- the speculative step with the branch-free full-accuracy softplus for any |u2| < 700
             // (cgp_fastmath.hpp: softplus_pair_any) and the SAME incremental rotation: 6 dependent operations where the wide step below
             // takes a fresh sincos --, then ...
-            uncommon = chunk(std::integral_constant<int, kRegAny>{});
-            if (uncommon == 0) { if (!lean_tried) n_wide++; }
+            // ... unless what failed was the increment bound (code 2): the ANY regime rotates by the same increments
+            auto jumped = [&]() { jump_streak = jump_streak < 4 ? jump_streak + 1 : 4; spec_off = 1 << jump_streak; };
+            if (lean_tried && (uncommon & 2u) != 0) jumped();
+            if (spec_allowed && spec_off == 0) {
+                uncommon = chunk(std::integral_constant<int, kRegAny>{});
+                if (uncommon == 0) { if (!lean_tried) n_wide++; }
+                else if ((uncommon & 2u) != 0) jumped();
+            }
         }
         if (uncommon == 0) {
             anchor_live = anchor_end; anchor_age++;
+            if (jump_streak > 0) jump_streak--;                              // (a chunk kept takes one doubling back, not all of them)
             if (checked_left > 0) checked_left--;
         } else {
+            if (!spec_allowed) spec_off--;
             // ... on the wide step (full sincos: a jump of the angle beyond the increment bound); a chunk that leaves even that is repeated
             // with the checked step
             anchor_age = -1;
