@@ -369,7 +369,9 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
     __shared__ double2 park[64 * kParkStride];
     __shared__ double ybuf[64 + 16];                                        // the chunk's measurements (+ the read-ahead of the last group)
     double cum = 0.0;
-    int checked_left = 0, spec_off = 0, jump_streak = 0;                    // sticky counts: off the common regime / off every speculative regime
+    // sticky counts: off the common regime / off every speculative regime.  (The score starts below zero: two failed passes at a record's
+    // start, before any chunk was kept, stop the trying at once -- the CRLB jobs' records are eight chunks long.)
+    int checked_left = 0, spec_off = 0, jump_streak = 0, spec_score = -4;
     unsigned n_high = 0, n_common = 0, n_redo = 0, n_checked = 0, n_high_left = 0, n_wide = 0, n_low = 0, n_mid = 0;      // chunks by regime (scalars; cgp_debug_counters)
     // The rotation pair is re-anchored with the full softplus and sincos (a dependent chain of ~ 70 operations) every FOURTH
     // accepted chunk only (round 4): an accepted chunk hands its last (theta, A, B) to the next one -- one rounding per step in the
@@ -503,17 +505,21 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             // (cgp_fastmath.hpp: softplus_pair_any) and the SAME incremental rotation: 6 dependent operations where the wide step below
             // takes a fresh sincos --, then ...
             // ... unless what failed was the increment bound (code 2): the ANY regime rotates by the same increments
-            auto jumped = [&]() { jump_streak = jump_streak < 4 ? jump_streak + 1 : 4; spec_off = 1 << jump_streak; };
-            if (lean_tried && (uncommon & 2u) != 0) jumped();
+            auto jumped = [&]() { jump_streak = jump_streak < 4 ? jump_streak + 1 : 4; if (spec_off < (1 << jump_streak)) spec_off = 1 << jump_streak; };
+            // ... and a wavefront whose passes fail more often than they hold (score: +1 a chunk kept, -2 a failed pass, within [-16, 8])
+            // stops trying for 32 chunks at a time: the CRLB jobs' records through this kernel, 6 % kept against 17 % failed
+            auto failed = [&]() { spec_score = spec_score > -14 ? spec_score - 2 : -16; if (spec_score <= -8 && spec_off < 32) spec_off = 32; };
+            if (lean_tried) { failed(); if ((uncommon & 2u) != 0) jumped(); }
             if (spec_allowed && spec_off == 0) {
                 uncommon = chunk(std::integral_constant<int, kRegAny>{});
                 if (uncommon == 0) { if (!lean_tried) n_wide++; }
-                else if ((uncommon & 2u) != 0) jumped();
+                else { failed(); if ((uncommon & 2u) != 0) jumped(); }
             }
         }
         if (uncommon == 0) {
             anchor_live = anchor_end; anchor_age++;
             if (jump_streak > 0) jump_streak--;                              // (a chunk kept takes one doubling back, not all of them)
+            if (spec_score < 8) spec_score++;
             if (checked_left > 0) checked_left--;
         } else {
             if (!spec_allowed) spec_off--;

@@ -5,7 +5,7 @@ from chirpgp_amd import filters_smoothers as fs, tools, _engine
 from chirpgp_amd.models import model_chirp, disc_chirp_lcd
 _, _, m0, P0, H = model_chirp(0.1, 0.1, 1.0, 1.0, 0.1)
 mc = disc_chirp_lcd(0.1, 0.1, 1.0, 1.0)
-B, T = 1000, 2000
+B, T = 1000, int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 _, yss = tools.simulate_measurements(mc, H, 0.1, m0, P0, 0.01, T, 666, batch=B, states=False)
 run = lambda: fs.ekf(mc, H, 0.1, m0, P0, 0.01, yss, flags=0x2)
 run(); torch.cuda.synchronize()
