@@ -414,7 +414,10 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         // the rotation pair at the chunk's first state: carried over from the last accepted chunk, or re-anchored; every attempt of
         // this chunk starts from it
         Ekf4Anchor anchor0, anchor_end;
-        if (anchor_age < 0 || anchor_age >= 4) { ekf4_anchor(K, x.u2(), anchor0); anchor_age = 0; }
+        // (not for a chunk that goes straight to the wide step: the anchor is a dependent chain of ~ 70 operations)
+        const bool spec_allowed = spec_off == 0;
+        if (!spec_allowed) anchor0 = anchor_live;
+        else if (anchor_age < 0 || anchor_age >= 4) { ekf4_anchor(K, x.u2(), anchor0); anchor_age = 0; }
         else anchor0 = anchor_live;
         // One speculative pass over the chunk in regime REG: kRegCommon, kRegHigh (the short polynomials of u2 >= 5: SpecRegsHigh),
         // kRegLow, kRegAny.
@@ -467,7 +470,6 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         // regimes are off for 2, 4, 8, 16 chunks (doubling with every jump, one doubling back with every chunk kept in a regime), and those
         // chunks go straight to the wide step -- 482 ns a step there (423 before the LOW / MID / ANY regimes, when every such chunk went to the
         // wide step; backing off after ANY failed pass, not just a jump, gave the same 482 and cost the lost-track record sets 5 %)
-        const bool spec_allowed = spec_off == 0;
         const bool lean_tried = spec_allowed && (low || mid || (checked_left == 0 && !edge));
         if (lean_tried) {
             // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
@@ -508,7 +510,12 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             auto jumped = [&]() { jump_streak = jump_streak < 4 ? jump_streak + 1 : 4; if (spec_off < (1 << jump_streak)) spec_off = 1 << jump_streak; };
             // ... and a wavefront whose passes fail more often than they hold (score: +1 a chunk kept, -2 a failed pass, within [-16, 8])
             // stops trying for 32 chunks at a time: the CRLB jobs' records through this kernel, 6 % kept against 17 % failed
-            auto failed = [&]() { spec_score = spec_score > -14 ? spec_score - 2 : -16; if (spec_score <= -8 && spec_off < 32) spec_off = 32; };
+            // (a record whose very FIRST chunk fails -- the CRLB jobs' records are eight chunks long -- does not try again for eight)
+            auto failed = [&]() {
+                spec_score = spec_score > -14 ? spec_score - 2 : -16;
+                if (spec_score <= -8 && spec_off < 32) spec_off = 32;
+                if (t0 == span.t_begin && spec_off < 8) spec_off = 8;
+            };
             if (lean_tried) { failed(); if ((uncommon & 2u) != 0) jumped(); }
             if (spec_allowed && spec_off == 0) {
                 uncommon = chunk(std::integral_constant<int, kRegAny>{});
