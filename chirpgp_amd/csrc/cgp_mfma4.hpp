@@ -468,8 +468,9 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
         // Every speculative regime rotates by INCREMENTS; records whose angle jumps beyond the increment bound in many chunks (the CRLB jobs'
         // at dt = 0.01, where the ANY regime behind a failed pass failed the same way: 927 ns a step) back off: after a jump the speculative
         // regimes are off for 2, 4, 8, 16 chunks (doubling with every jump, one doubling back with every chunk kept in a regime), and those
-        // chunks go straight to the wide step -- 482 ns a step there (423 before the LOW / MID / ANY regimes, when every such chunk went to the
-        // wide step; backing off after ANY failed pass, not just a jump, gave the same 482 and cost the lost-track record sets 5 %)
+        // chunks go straight to the wide step (spec_off; the score and the first-chunk rule below feed the same count): 453 - 491 ns a step
+        // there, 432 - 455 for the library before the LOW / MID / ANY regimes, whose sticky count sent every such chunk to the wide step.
+        // (Backing off after ANY failed pass, band exits too, gave the same there and cost the lost-track record sets 5 %.)
         const bool lean_tried = spec_allowed && (low || mid || (checked_left == 0 && !edge));
         if (lean_tried) {
             // A chunk that starts at u2 >= 6.5 is tried in the HIGH regime first (the bench records: 75 % of the chunks, none of
