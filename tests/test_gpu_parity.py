@@ -1000,9 +1000,10 @@ def test_rotation_increments_at_the_admitted_bound():
 
 def test_wide_step_for_records_outside_the_lean_regime():
     """Records whose frequency state lives below 1.5 or wanders through it (a chirp the filter never locks on: 20 Hz against an initial
-    7; a start at 0.5 on a 1 - 2 Hz chirp; a negative start): the matrix-core EKF runs their chunks on the WIDE step (branch-free
-    softplus for any |state| < 700, cgp_fastmath.hpp: softplus_pair_any) -- counted by the kernel -- within 1e-9 of the C port, and only
-    a state beyond 700 (exp overflows in the reference's naive softplus: NaN from there on, in the same places) falls through to the checked step."""
+    7; a start at 0.5 on a 1 - 2 Hz chirp; a negative start): the matrix-core EKF runs their chunks in the LOW / MID / ANY regimes of its
+    speculative step or on the WIDE step (cgp_mfma4.hpp; softplus as lean polynomials on exp(u), as polynomials in u^2, by the branch-free
+    softplus_pair_any) -- counted by the kernel -- within 1e-9 of the C port, and only a state beyond 700 (exp overflows in the reference's
+    naive softplus: NaN from there on, in the same places) falls through to the checked step."""
     import bench
     from chirpgp_amd import filters_smoothers as fs, models as pm, _engine
     from oracle import port
@@ -1026,7 +1027,9 @@ def test_wide_step_for_records_outside_the_lean_regime():
         else:
             assert rg['wide'] + rg['low'] + rg['mid'] > 0.2 * chunks and rg['checked'] == 0, (label, rg)
             if label == 'negative start':
-                assert rg['low'] > 0, rg                                # chunks that start at or below -1.75: the LOW regime of the lean step
+                assert rg['low'] > 0.8 * chunks, rg                     # chunks that start at or below -1.75: the LOW regime of the lean step
+            if label == 'low':
+                assert rg['mid'] > 0.1 * chunks and rg['low'] > 0.1 * chunks, rg      # a start at 0.5: the MID regime, then wherever the state goes
 
 
 @pytest.mark.parametrize('kind', ['sgp', 'cd_sgp', 'harmonic'])
