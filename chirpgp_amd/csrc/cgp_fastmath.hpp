@@ -629,6 +629,78 @@ CGP_DEV void sincos_reduced(const FanRegs& R, double r, double& s0, double& c0) 
     c0 = fma(z2, pc, fma(-0.5, z, 1.0));
 }
 
+// The constants of softplus_pair_any and fast_sincos_spec pinned in registers for the duration of a chunk on the ANY / WIDE tiers of the
+// matrix-core EKF (round 5): that translation unit is built without machine-level loop-invariant code motion (Makefile), so literal
+// operands would be materialised again in every iteration of those tiers' loops -- 138 scalar moves per eight steps, measured.  ~ 90
+// vector moves per 64-step chunk instead.  The softplus is the literal form's operation for operation; sin / cos take the fans' Estrin form.
+struct WideRegs : FanRegs {
+    double ex[11];      // 1/6, 1/24, ..., 1/13!  (exp Taylor from the cubic term on; 1, 1, 1/2 are inline constants)
+    double lg[10];      // 1/3, 1/5, ..., 1/21
+    double sqrt2, two_over_pi, pio2_1, pio2_2, pio2_3;
+    CGP_DEV void init() {
+        FanRegs::init();
+        const double ex_[11] = {1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0,
+                                1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0};
+        const double lg_[10] = {1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0};
+        CGP_UNROLL for (int i = 0; i < 11; i++) ex[i] = FastMathRegs::pin(ex_[i]);
+        CGP_UNROLL for (int i = 0; i < 10; i++) lg[i] = FastMathRegs::pin(lg_[i]);
+        sqrt2 = FastMathRegs::pin(1.4142135623730951);
+        two_over_pi = FastMathRegs::pin(kTwoOverPi);
+        pio2_1 = FastMathRegs::pin(kPio2_1); pio2_2 = FastMathRegs::pin(kPio2_2); pio2_3 = FastMathRegs::pin(kPio2_3);
+    }
+};
+// softplus_pair_any with its constants from W (the same operations in the same order)
+CGP_DEV void softplus_pair_any(const WideRegs& W, double x, double& sp, double& dsp, bool& ok) {
+    const double a = fabs(x);
+    ok = a < 700.0;
+    const double na = -a;
+    const double k = __builtin_rint(na * W.log2e);
+    double r = fma(-k, W.ln2hi, na);
+    r = fma(-k, W.ln2lo, r);
+    const double r2 = r * r;
+    const double e0 = fma(r, 1.0, 1.0), e1 = fma(r, W.ex[0], 0.5), e2 = fma(r, W.ex[2], W.ex[1]), e3 = fma(r, W.ex[4], W.ex[3]);
+    const double e4 = fma(r, W.ex[6], W.ex[5]), e5 = fma(r, W.ex[8], W.ex[7]), e6 = fma(r, W.ex[10], W.ex[9]);
+    const double r4 = r2 * r2;
+    const double f0 = fma(e1, r2, e0), f1 = fma(e3, r2, e2), f2 = fma(e5, r2, e4);
+    const double r8 = r4 * r4;
+    const double g0 = fma(f1, r4, f0), g1 = fma(e6, r4, f2);
+    const double t = __builtin_amdgcn_ldexp(fma(g1, r8, g0), (int)k);
+    const double z = 1.0 + t;
+    const double rz = rcp_nr(z);
+    const bool big = z > W.sqrt2;
+    const double m = big ? 0.5 * z : z;
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double sc = fma(fma(-(m + 1.0), s, m - 1.0), rcp_nr1(m + 1.0), s);
+    const double s2 = sc * sc;
+    const double p0 = fma(s2, W.lg[1], W.lg[0]), p1 = fma(s2, W.lg[3], W.lg[2]), p2 = fma(s2, W.lg[5], W.lg[4]);
+    const double p3 = fma(s2, W.lg[7], W.lg[6]), p4 = fma(s2, W.lg[9], W.lg[8]);
+    const double s4 = s2 * s2;
+    const double q0 = fma(p1, s4, p0), q1 = fma(p3, s4, p2);
+    const double s8 = s4 * s4;
+    const double pl = fma(fma(p4, s8, q1), s8, q0);
+    const double two_s = sc + sc;
+    double lz = fma(two_s, pl * s2, two_s);
+    lz = big ? fma(1.0, W.ln2lo, lz) + W.ln2hi : lz;
+    const double l1p = fma(t - (z - 1.0), rz, lz);
+    sp = (x > 0.0 ? x : 0.0) + l1p;
+    dsp = (x > 0.0 ? 1.0 : t) * rz;
+}
+// fast_sincos_spec with its constants from W (the reduced-range polynomials in the Estrin form of the fans: four dependent levels)
+CGP_DEV void fast_sincos_spec(const WideRegs& W, double x, double& sn, double& cs, bool& ok) {
+    ok = fabs(x) < 1.0e5;
+    const double n = __builtin_rint(x * W.two_over_pi);
+    double r = fma(-n, W.pio2_1, x);
+    r = fma(-n, W.pio2_2, r);
+    r = fma(-n, W.pio2_3, r);
+    double s0, c0;
+    sincos_reduced(static_cast<const FanRegs&>(W), r, s0, c0);
+    const int q = (int)n;
+    const bool swap = (q & 1) != 0;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    sn = __hiloint2double(__double2hiint(a) ^ ((q & 2) << 30), __double2loint(a));
+    cs = __hiloint2double(__double2hiint(b) ^ (((q + 1) & 2) << 30), __double2loint(b));
+}
+
 // The wave-uniform pair with the lean polynomials (regime [1.5, 700), 7e-12 / 1.2e-11; see "the speculative EKF step's
 // softplus" above): evaluated unconditionally, the regime test is a scalar compare consumed by a rarely-taken branch at the end.
 template <class Regs>

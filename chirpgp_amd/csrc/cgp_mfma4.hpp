@@ -140,11 +140,11 @@ CGP_DEV void ekf4_mfma_finish(const Ekf4MfmaConst& K, double y, double c1, doubl
 // even that (the chunk is then repeated with the checked step).  Records whose frequency state wanders below 1.5 -- low signal-to-noise,
 // low or high chirp rates: two thirds of bench.py's C2_spread combinations -- ran 3 x slower on the checked step before.
 template <int E1 = 0>
-CGP_DEV void ekf4_mfma_step_wide(const Ekf4MfmaConst& K, double y, Ekf4State& x, double& S, double& innov, bool& bad) {
+CGP_DEV void ekf4_mfma_step_wide(const Ekf4MfmaConst& K, const WideRegs& W, double y, Ekf4State& x, double& S, double& innov, bool& bad) {
     double sp, dsp, s1, c1;
     bool ok1, ok2;
-    softplus_pair_any(x.u2(), sp, dsp, ok1);
-    fast_sincos_spec(K.ang * sp, s1, c1, ok2);
+    softplus_pair_any(W, x.u2(), sp, dsp, ok1);
+    fast_sincos_spec(W, K.ang * sp, s1, c1, ok2);
     bad = bad || !(ok1 && ok2);
     ekf4_mfma_finish<E1>(K, y, c1, s1, dsp, x, S, innov);
 }
@@ -244,7 +244,7 @@ struct Ekf4Verdict {
 };
 template <int E1, int REG = kRegCommon>
 CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, const SpecRegsHigh& RH, double y, Ekf4State& x, Ekf4Anchor& a,
-                                  double& S, double& innov, Ekf4Verdict& verdict, const SpecRegsMid* RM = nullptr) {
+                                  double& S, double& innov, Ekf4Verdict& verdict, const SpecRegsMid* RM = nullptr, const WideRegs* RW = nullptr) {
     const double u2 = (E1 == 2) ? x.u2_replicated() : x.u2();
     constexpr bool HIGH = REG == kRegHigh, LOW = REG == kRegLow, ANY = REG == kRegAny, MID = REG == kRegMid;
     double d, jfac;                                                                  // the angle's increment; (kj ang) x the softplus derivative
@@ -255,7 +255,8 @@ CGP_DEV void ekf4_mfma_step_spec1(const Ekf4MfmaConst& K, const SpecRegs& R, con
         jfac = fma(u2, hj, 0.5 * K.kja);
     } else if constexpr (ANY) {
         double sp, dspf; bool ok;
-        softplus_pair_any(u2, sp, dspf, ok);
+        if (RW) softplus_pair_any(*RW, u2, sp, dspf, ok);                              // (constants pinned for the chunk: WideRegs)
+        else softplus_pair_any(u2, sp, dspf, ok);
         verdict.any_bad = verdict.any_bad || !ok;
         d = fma(K.angm, sp, -a.th);
         jfac = K.kja * dspf;
@@ -427,13 +428,15 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             // held for the whole kernel they cost the HIGH chunks of the bench records 3.5 %, measured)
             SpecRegsMid RM;
             if constexpr (REG == kRegMid) RM.init(K.angm, K.kja);
+            WideRegs RW;
+            if constexpr (REG == kRegAny) RW.init();
             Ekf4Anchor anchor = anchor0;
             Ekf4Verdict verdict;
             // step `k` of the group that starts at `slot`: the group's row offset rides in the stores' scalar offset, k in
             // a vector offset of its own (hoisted out of the loop) -- no scalar add per step
             auto one = [&](int slot, unsigned k, double y) {
                 double S, innov;
-                ekf4_mfma_step_spec1<E1 ? 2 : 0, REG>(K, R, RH, y, x, anchor, S, innov, verdict, &RM);
+                ekf4_mfma_step_spec1<E1 ? 2 : 0, REG>(K, R, RH, y, x, anchor, S, innov, verdict, &RM, REG == kRegAny ? &RW : nullptr);
                 park[(slot + k) * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pw.store_s(x.P, p_off + k * 128u, t * 128u);
@@ -537,9 +540,11 @@ CGP_DEV void ekf4_mfma_trial(const FilterIO& io, const ModelArgs& ma) {
             x = x0;
             const bool redo = lean_tried;
             bool bad = false;
+            WideRegs W;                                                     // (the wide step's constants, pinned for this chunk)
+            W.init();
             auto wide_one = [&](int slot, double y) {
                 double S, innov;
-                ekf4_mfma_step_wide<E1 ? 2 : 0>(K, y, x, S, innov, bad);
+                ekf4_mfma_step_wide<E1 ? 2 : 0>(K, W, y, x, S, innov, bad);
                 park[slot * kParkStride] = make_double2(S, innov);
                 const unsigned t = (unsigned)(t0 + slot);
                 Pw.store_s(x.P, p_off, t * 128u);
