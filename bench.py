@@ -243,6 +243,111 @@ def cpu_baseline(wl, target_seconds=10.0):
             "best_of": 3}
 
 
+LINE_LIMIT = 4096          # bytes of the ONE contract line on stdout (round 5's 24.7 KB line was not parsed by the driver)
+DETAILS_NAME = 'bench_details.json'
+
+
+def _finite(x):
+    """JSON has no NaN / Infinity: every non-finite float becomes null (recursively), so a strict parser accepts the output."""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, (np.floating,)):
+        return _finite(float(x))
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def _sig(x, digits=6):
+    """floats rounded to `digits` significant figures (the line is a report, not a checkpoint)"""
+    if isinstance(x, float) and math.isfinite(x) and x != 0.0:
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def write_details(result):
+    """Everything bench.py measured (other_configs, the 45 C2_spread records, time_split_filters, issue_profile, the long provenance
+    strings) as ONE strict-JSON file next to bench.py -- or in the temp directory when the tree is read-only -- and never on stdout.
+    Returns the path (None if it could not be written anywhere)."""
+    import tempfile
+    text = json.dumps(_finite(result), allow_nan=False, indent=1)
+    for folder in (ROOT, os.path.join(ROOT, 'gpurun_out'), tempfile.gettempdir()):
+        try:
+            path = os.path.join(folder, DETAILS_NAME)
+            with open(path, 'w') as f:
+                f.write(text)
+            return path
+        except OSError:
+            continue
+    return None
+
+
+def contract_line(result, details_path=None):
+    """The ONE line of stdout: the contract's fields, `roofline` and `cpu_baseline` trimmed to their numbers and a short provenance, a
+    summary of the regimes and of the other configurations -- bounded by LINE_LIMIT whatever the run measured.  Everything else is in the
+    details file."""
+    r = _finite(result)
+    keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "collectives", "hbm_gbs_total", "hbm_frac_per_gpu", "gather_ms")
+    line = {k: r[k] for k in keep if k in r}
+    rf = r.get("roofline") or {}
+    roof = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                   "algorithmic_bytes_per_launch", "waves_per_simd")}
+    src = rf.get("traffic_source")
+    roof["traffic_source"] = (src[:117] + '...') if isinstance(src, str) and len(src) > 120 else src
+    if isinstance(rf.get("hbm"), dict):
+        roof["hbm"] = {k: rf["hbm"].get(k) for k in ("achieved", "peak", "unit", "frac")}
+    line["roofline"] = roof
+    k = r.get("kernels") or {}
+    line["kernels"] = {x: k.get(x) for x in ("filter_ms", "smoother_ms", "filter_ms_max_over_ranks", "smoother_ms_max_over_ranks")}
+    cb = r.get("cpu_baseline")
+    if cb is not None:
+        c = {x: cb.get(x) for x in ("value", "unit", "cores", "kind") if x in cb}
+        sample = cb.get("sample")
+        c["sample"] = (sample[:157] + '...') if isinstance(sample, str) and len(sample) > 160 else sample
+        if "error" in cb:
+            c["error"] = str(cb["error"])[:160]
+        if isinstance(cb.get("one_core"), dict):
+            c["one_core_value"] = cb["one_core"].get("value")
+        line["cpu_baseline"] = c
+        for x in ("gpu_over_cpu", "gpu_over_cpu_one_core"):
+            if x in r:
+                line[x] = r[x]
+    rg = r.get("regimes")
+    if rg:
+        line["regimes"] = {x: rg.get(x) for x in ("chunks", "high", "common", "low", "mid", "wide", "redone", "checked", "high_share")}
+    if isinstance(r.get("strong"), dict):
+        line["strong"] = {x: r["strong"].get(x) for x in ("value", "global_batch", "batch_per_gpu", "ms_per_step", "gather_ms")}
+    oc = r.get("other_configs")
+    if oc:
+        summ = {}
+        for tag in ("C1", "C2_low_freq", "C3", "C4", "C5"):
+            if tag in oc:
+                summ[tag] = {"value": oc[tag].get("value"), "filter_ms": oc[tag].get("filter_ms"), "smoother_ms": oc[tag].get("smoother_ms")}
+        sp = oc.get("C2_spread")
+        if sp:
+            summ["C2_spread"] = {x: sp.get(x) for x in ("combinations", "value_min", "value_median", "value_max")}
+        line["other_configs"] = summ
+    line["details"] = details_path
+    line = _sig(line)
+    text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    for drop in ("other_configs", "strong", "regimes", "kernels"):      # never reached with today's fields; a guarantee, not a plan
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT and '\n' not in text
+    return text
+
+
 WORKLOADS = {
     # kind: (label, default trials, default T, default scaling, which roof bounds it in the large-batch limit)
     'kf': ("C1: linear KF+RTS, frozen-frequency chirp (plumbing)", 1, 1000, 'weak', 'hbm'),
@@ -745,7 +850,8 @@ def main():
             if result["cpu_baseline"].get("value"):
                 result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
                 result["gpu_over_cpu_one_core"] = result["value"] / result["cpu_baseline"]["one_core"]["value"]
-        print(json.dumps(result))
+        details = write_details(result)
+        print(contract_line(result, details))
 
 
 if __name__ == '__main__':

@@ -52,7 +52,7 @@ class CgpInit(C.Structure):
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
            'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
-           'cgp_reserve_workspace')
+           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash')
 
 _lib = None
 _lock = threading.Lock()
@@ -109,8 +109,34 @@ def load_library():
         lib.cgp_debug_philox.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, _vp]
         lib.cgp_reserve_workspace.restype = C.c_int
         lib.cgp_reserve_workspace.argtypes = [_vp, C.c_size_t, _vp]
+        lib.cgp_release_workspace.restype = C.c_int
+        lib.cgp_release_workspace.argtypes = [_vp, _vp]
+        lib.cgp_source_hash.restype = C.c_char_p
+        lib.cgp_source_hash.argtypes = []
+        built_from, tree = lib.cgp_source_hash().decode(), source_hash()
+        if tree is not None and built_from != tree:
+            raise RuntimeError(f'{LIB_PATH} is stale: built from sources {built_from[:16]}..., the checked-out csrc/ + include/ hash to '
+                               f'{tree[:16]}... -- rebuild it (`make -C chirpgp_amd/csrc`); there is no CPU fallback')
         _lib = lib
         return lib
+
+
+def source_hash():
+    """sha256 of the sources a library of this tree is built from -- csrc/*.hip, csrc/*.hpp (byte order of the names), csrc/Makefile,
+    include/chirpgp_hip.h, concatenated: what csrc/Makefile embeds as cgp_source_hash().  None where the sources are not shipped
+    (a binary-only install), in which case nothing can be compared."""
+    import glob
+    import hashlib
+    src = os.path.join(_HERE, 'csrc')
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.hpp')))
+    files = [os.path.join(src, n) for n in names] + [os.path.join(src, 'Makefile'), os.path.join(os.path.dirname(_HERE), 'include', 'chirpgp_hip.h')]
+    if not names or not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 _contexts = {}
@@ -557,6 +583,12 @@ def reserve_workspace(nbytes, device_index=None):
     cgp_reserve_workspace) -- needed only before capturing such launches into a graph."""
     ctx = context(device_index)
     _check(ctx, load_library().cgp_reserve_workspace(ctx, int(nbytes), _stream()), 'cgp_reserve_workspace')
+
+
+def release_workspace(device_index=None):
+    """Free the current stream's scratch buffer and forget the stream (include/chirpgp_hip.h: cgp_release_workspace)."""
+    ctx = context(device_index)
+    _check(ctx, load_library().cgp_release_workspace(ctx, _stream()), 'cgp_release_workspace')
 
 
 def debug_set(key, value, device_index=None):

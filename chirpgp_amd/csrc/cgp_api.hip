@@ -249,8 +249,31 @@ int cgp_reserve_workspace(cgp_ctx* ctx, size_t bytes, void* stream) {
     if (bytes == 0) return CGP_OK;
     DeviceScope on_device(ctx->device);
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
-    if (!ctx_workspace(ctx, (hipStream_t)stream, bytes)) return fail(ctx, CGP_E_HIP, "workspace allocation failed");
+    std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);
+    if (!ctx_workspace(ctx, (hipStream_t)stream, bytes, /*reserve=*/true)) return fail(ctx, CGP_E_HIP, "workspace allocation failed");
     return CGP_OK;
+}
+
+int cgp_release_workspace(cgp_ctx* ctx, void* stream) {
+    if (!ctx) return CGP_E_ARG;
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);
+    std::lock_guard<std::mutex> lock(ctx->ws_mutex);
+    auto it = ctx->ws.find((hipStream_t)stream);
+    if (it == ctx->ws.end()) return CGP_OK;
+    if (it->second.p) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, CGP_E_HIP, "hipStreamSynchronize failed (is the stream being captured?)"); }
+        (void)hipFree(it->second.p);
+    }
+    ctx->ws.erase(it);
+    return CGP_OK;
+}
+
+const char* cgp_source_hash(void) {
+    return
+#include "cgp_source_hash.inc"
+    ;
 }
 
 int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value) {
@@ -314,6 +337,9 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     if ((method == CGP_F_EKF_KPT) != (model->model_id == CGP_M_KPT)) return fail(ctx, CGP_E_ARG, "CGP_F_EKF_KPT goes with CGP_M_KPT only");
     DeviceScope on_device(ctx->device);
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    // One call's launches are enqueued as a unit: the per-stream scratch of the time-split forms (memset, kernel, fix-up) is protected by
+    // stream order only if two host threads that share this context AND a stream cannot interleave their launches.
+    std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);
 
     FilterIO io;
     io.H = init->H; io.H_stride = init->H_stride;
@@ -374,7 +400,7 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
     const bool lane4 = spec && lane4_filter_fits(io);
     if (method == CGP_F_EKF && chirp4 && mfma && !(flags & CGP_ONE_TRIAL_PER_WAVE)) limit = lane4 ? ShapeLimit{9, 1} : ShapeLimit{20, 1};
     else if (method == CGP_F_EKF && harm8) limit = {8, 1};
-    else if (method == CGP_F_SGP && chirp4 && mfma) limit = (lane4 && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes) ? ShapeLimit{9, 1} : ShapeLimit{24, 1};
+    else if (method == CGP_F_SGP && chirp4 && mfma) limit = (lane4 && sigma_lds_bytes(ma, 4) <= (size_t)kLane4SigLdsMaxBytes) ? ShapeLimit{9, 1} : ShapeLimit{24, 1};
     else if (method == CGP_F_SGP && harm8) limit = {11, 1};
     else if (method == CGP_F_CD_EKF && sde4 && mfma) limit = {4, 1};
     else if (method == CGP_F_CD_SGP && sde4 && mfma) limit = {48, 1};
@@ -397,7 +423,7 @@ static int filter_impl(cgp_ctx* ctx, int method, const cgp_model* model, const c
             rc = dispatch_filter_coop8_ekf(model->n_harm, io, ma, st);
         else if (method == CGP_F_SGP && wave && !(flags & CGP_GENERIC_KERNEL) && model->model_id == CGP_M_HARMONIC_LCD && coop8_filter_sgp_ok(model->n_harm, io.T, ma))
             rc = dispatch_filter_coop8_sgp(model->n_harm, io, ma, st);
-        else if ((method == CGP_F_EKF || (method == CGP_F_SGP && sigma_lds_bytes(ma, 4) <= (size_t)kSigLdsMaxBytes)) && model->n_harm == 1 && !wave &&
+        else if ((method == CGP_F_EKF || (method == CGP_F_SGP && sigma_lds_bytes(ma, 4) <= (size_t)kLane4SigLdsMaxBytes)) && model->n_harm == 1 && !wave &&
                  !(flags & CGP_GENERIC_KERNEL) && lane4_filter_fits(io))
             rc = dispatch_filter_lane4(method, io, ma, st);                                      // large batches: cgp_lane4.hpp
         else rc = dispatch_filter_disc_harm(method, model->n_harm, wave, io, ma, st);
@@ -455,6 +481,7 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     if (model->model_id == CGP_M_KPT) return fail(ctx, CGP_E_ARG, "the KPT model has no smoother in the reference");
     DeviceScope on_device(ctx->device);
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
+    std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);        // (see filter_impl: compose + apply of one call stay together)
 
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;

@@ -12,9 +12,13 @@ struct cgp_ctx {
     unsigned long long* counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): eight device counters, NULL = off
     unsigned long long* counters_mem = nullptr;  // the allocation (kept while counting is switched off)
     // Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers):
-    // ONE buffer per stream, kept by the context and grown on demand (cgp::ctx_workspace).  Work on one stream is ordered, so two
-    // launches never hold the same buffer at once; threads that share a context use different streams or serialise themselves.
-    struct Workspace { void* p = nullptr; size_t bytes = 0; };
+    // ONE buffer per stream, kept by the context and grown on demand (cgp::ctx_workspace).  Work on one stream is ordered, and the
+    // launches of one C-ABI call are enqueued under `launch_mutex`, so two calls never hold the same buffer at once -- whatever the
+    // threads that share the context do (round 6; ADVICE r5: the lock used to be dropped before the kernels were enqueued).
+    // `pinned`: sized by cgp_reserve_workspace -- a captured graph may hold the pointer, so it is never freed or regrown by a launch
+    // (a launch that needs more gets NULL); only cgp_reserve_workspace / cgp_release_workspace / cgp_destroy touch it.
+    struct Workspace { void* p = nullptr; size_t bytes = 0; bool pinned = false; };
+    std::recursive_mutex launch_mutex;
     std::mutex ws_mutex;
     std::unordered_map<hipStream_t, Workspace> ws;
 };
@@ -38,11 +42,15 @@ inline int fail(cgp_ctx* ctx, int code, const std::string& msg) {
 // The stream's scratch buffer of at least `bytes` bytes, or NULL (allocation failed, or the buffer would have to grow while the
 // stream is being captured into a graph: size it first with cgp_reserve_workspace).  Growing waits for the stream's queued work --
 // which may still use the old buffer -- and frees it; a buffer that is large enough is returned without any HIP call.
-inline void* ctx_workspace(cgp_ctx* ctx, hipStream_t st, size_t bytes) {
+// The caller holds ctx->launch_mutex until its last kernel is enqueued (cgp_filter / cgp_smoother do), so no other call on this
+// context can be between "fetched the pointer" and "enqueued its kernels" while the buffer is replaced here.
+inline void* ctx_workspace(cgp_ctx* ctx, hipStream_t st, size_t bytes, bool reserve = false) {
     if (!ctx) return nullptr;
     std::lock_guard<std::mutex> lock(ctx->ws_mutex);
     cgp_ctx::Workspace& w = ctx->ws[st];
+    if (reserve) w.pinned = true;
     if (w.bytes >= bytes && w.p) return w.p;
+    if (w.pinned && !reserve && w.p) return nullptr;      // a reserved buffer is only regrown by cgp_reserve_workspace itself
     if (w.p) {
         if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         (void)hipFree(w.p);

@@ -8,7 +8,7 @@ namespace cgp {
 int dispatch_filter_lane4_sgp(const FilterIO& io, const ModelArgs& ma, hipStream_t st) {
     using DM = HarmonicLCD<1>;
     using Meas = LinearMeasurement<4>;
-    if (sigma_lds_bytes(ma, 4) > (size_t)kSigLdsMaxBytes) return CGP_E_UNSUPPORTED;
+    if (sigma_lds_bytes(ma, 4) > (size_t)kLane4SigLdsMaxBytes) return CGP_E_UNSUPPORTED;
     // the collapsed quadrature alone where the host has checked the set for it (fewer registers, less code)
     if (sgp_collapsible_host<DM>(ma)) return hip_rc(launch_lane4_filter<SgpPredictLane<DM, true>, Meas>(io, ma, st));
     return hip_rc(launch_lane4_filter<SgpPredictLane<DM>, Meas>(io, ma, st));

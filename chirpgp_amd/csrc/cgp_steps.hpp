@@ -22,6 +22,10 @@ constexpr int kFanLdsDoubles = kRedChunk * kRedLd + kRedChunk;
 // reads the staged copy is a compile-time property (template parameter ST of the accessors): the wave-per-trial shapes
 // always do -- the host routes sets that do not fit to the one-lane-per-trial kernels -- so no per-access branch exists.
 constexpr int kSigLdsMaxBytes = 44 * 1024;   // + 17 KB static reduction buffer < the 64 KB default LDS limit of a launch
+// The large-batch lane kernel of the sigma-point filter (cgp_lane4.hpp: lane4_filter_kernel<SgpPredictLane>) has 28.7 KB of static LDS
+// (measurement buffer 16 KB + covariance tile 3 KB + mean tile 9 KB) in front of the staged set: 34 KB more keeps a launch under 64 KB.
+// A larger set (about 880 points at d = 4) takes the generic lane kernel, which reads its set from global memory.
+constexpr int kLane4SigLdsMaxBytes = 34 * 1024;
 // LDS pointers carry their address space explicitly: the reads become ds_read_* (not flat_load with an aperture test).
 using LdsConstDoublePtr = const __attribute__((address_space(3))) double*;
 using LdsConstIntPtr = const __attribute__((address_space(3))) int*;

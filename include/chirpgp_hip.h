@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 130          /* 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
+#define CGP_VERSION 140          /* 0.1.4: cgp_release_workspace, cgp_source_hash, pinned reserved workspaces, per-call launch lock; 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -213,8 +213,21 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
  * waits for the stream -- illegal while the stream is being captured into a graph -- so a caller that captures its launches sizes the
  * buffer first: `bytes` >= 8 * (2 (d + d^2) + 1) * B * segments for a time-split filter, 8 * 40 * B * segments (d = 4) or
  * 8 * 112 * B * segments (d <= 8) for a time-split smoother (a smoother that finds no workspace falls back to its one-wavefront-
- * per-trial form, which needs none).  Threads that share a context must use different streams. */
+ * per-trial form, which needs none).
+ * Threads: the launches of one cgp_filter / cgp_smoother call are enqueued as a unit (a per-context lock held until the last kernel of
+ * the call is queued), so host threads may share a context and even a stream; a buffer is only replaced between calls, after the
+ * stream has drained.
+ * Graphs: a buffer sized by cgp_reserve_workspace is PINNED -- a captured graph bakes its address in, so no later launch on that stream
+ * frees or regrows it: a launch that would need more than was reserved gets none (the time-split filter fails with CGP_E_HIP, a
+ * smoother takes its one-wavefront-per-trial form).  Reserve for the largest call the stream will see while a graph that used the
+ * buffer is alive; cgp_reserve_workspace with a larger size regrows it (outside capture only: it waits for the stream), and
+ * cgp_release_workspace frees it and forgets the stream (call it before destroying a stream whose handle may be reused). */
 int cgp_reserve_workspace(cgp_ctx* ctx, size_t bytes, void* stream);
+int cgp_release_workspace(cgp_ctx* ctx, void* stream);
+
+/* sha256 (hex) of the sources this library was built from: every .hip and .hpp file of csrc/ (byte order of their names), then
+ * csrc/Makefile and this header, concatenated.  The Python layer recomputes it from the checked-out tree and refuses a stale library. */
+const char* cgp_source_hash(void);
 
 /* Smoothers: reads mfs / Pfs, writes mss / Pss (row T-1 is the filtering row T-1). */
 int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,

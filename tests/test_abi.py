@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     assert set(names) == set(eng.EXPORTS), (names, eng.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in chirpgp_hip.h but not exported'
-    assert lib.cgp_version() == 130
+    assert lib.cgp_version() == 140
 
 
 def test_struct_layouts_match_header():
@@ -62,3 +62,16 @@ def test_product_does_not_import_oracle():
             if f.endswith(('.py', '.hip', '.hpp', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in txt, f'{f} mentions oracle'
+
+
+def test_a_stale_library_is_refused(monkeypatch):
+    """the GPU box runs the shipped .so, nothing there calls build().  The library carries the sha256 of the
+    sources it was built from (cgp_source_hash, csrc/Makefile) and the Python layer refuses one that does not match the tree."""
+    lib, eng = _lib()
+    assert lib.cgp_source_hash().decode() == eng.source_hash() and len(eng.source_hash()) == 64
+    monkeypatch.setattr(eng, '_lib', None)
+    monkeypatch.setattr(eng, 'source_hash', lambda: '0' * 64)
+    with pytest.raises(RuntimeError, match='stale'):
+        eng.load_library()
+    monkeypatch.setattr(eng, 'source_hash', lambda: None)            # binary-only install: nothing to compare with
+    assert eng.load_library() is not None

@@ -84,3 +84,36 @@ def test_real_launch_reaches_both_ranks():
     assert p.stderr.count('bench.py needs a GPU') >= 1, p.stderr[-2000:]
     assert 'local_rank: 0' in p.stderr and 'local_rank: 1' in p.stderr, p.stderr[-2000:]
     assert '"n_gpus"' not in p.stdout
+
+
+def test_contract_line_is_compact_strict_json():
+    """the driver could not parse a 24.7 KB line.  The line is built by bench.contract_line from the full record; fed round 5's
+    committed record (profiles/r05_bench_c2.json: 45 spread rows, every other config) plus non-finite values and absurdly long strings it
+    must stay one strict-JSON line under 4 KB that still carries the contract's fields, `roofline` and `cpu_baseline`."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_c2.json')))
+    assert len(json.dumps(full)) > 20000
+    full['gather_ms'] = float('nan')
+    full['roofline']['traffic_source'] = 'x' * 5000
+    full['cpu_baseline']['sample'] = 'y' * 5000
+    full['other_configs']['C4']['value'] = float('inf')
+    text = bench.contract_line(full, '/somewhere/bench_details.json')
+    assert '\n' not in text and len(text) < bench.LINE_LIMIT == 4096
+
+    def no_constants(tok):
+        raise AssertionError(tok)
+    line = json.loads(text, parse_constant=no_constants)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'ranks_seen', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'kernels', 'roofline', 'cpu_baseline', 'gpu_over_cpu', 'regimes', 'details'):
+        assert k in line, k
+    assert line['gather_ms'] is None and line['other_configs']['C4']['value'] is None
+    rf = line['roofline']
+    assert rf['bound'] == 'hbm' and rf['frac'] == pytest.approx(full['roofline']['frac'], rel=1e-5) and rf['peak'] == 8000.0
+    assert rf['traffic'] == pytest.approx(full['roofline']['traffic'], rel=1e-5) and 'algorithmic_frac' not in rf
+    cb = line['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] == full['cpu_baseline']['cores'] and cb['value'] > 0 and len(cb['sample']) <= 160
+    assert line['config']['workload'].startswith('C2') and 'model' not in line['config']
+    # the details file is strict JSON too
+    import tempfile
+    assert json.loads(json.dumps(bench._finite(full), allow_nan=False))['steps'] == full['steps']

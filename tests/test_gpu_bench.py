@@ -15,9 +15,24 @@ def _run(*argv):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), p.stdout           # exactly one line on stdout, and it is the JSON line
+    assert len(lines[0]) < 4096, len(lines[0])                              # a 24.7 KB line was not parsed by the driver
+    line = json.loads(lines[0], parse_constant=_no_constants)               # strict JSON: no NaN / Infinity tokens
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'details'):
+        assert k in line, k
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(line['roofline'])
+    assert 'algorithmic_frac' not in line['roofline']                       # a convention, kept in the details file only
+    # the full record (every field the line had up to round 5) sits in the details file the line names
+    with open(line['details']) as f:
+        full = json.load(f, parse_constant=_no_constants)
+    assert full['value'] == pytest.approx(line['value'], rel=1e-5) and full['steps'] == line['steps']
+    return full
+
+
+def _no_constants(tok):
+    raise AssertionError(f'non-finite token {tok} in bench.py output')
 
 
 def test_two_rank_rehearsal_prints_one_line_for_both_ranks():
@@ -39,6 +54,7 @@ def test_single_gpu_line_carries_roofline_and_cpu_baseline():
     assert r['n_gpus'] == 1 and r['roofline']['bound'] == 'hbm' and r['roofline']['frac'] > 0
     assert 'traffic_source' in r['roofline'] and r['roofline']['algorithmic_frac'] > 0
     cb = r['cpu_baseline']
+    assert cb['sample'] and cb['unit'] == 'trial-steps/s'
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['best_of'] == 3
     assert cb['one_core']['cores'] == 1 and 0 < cb['one_core']['value'] <= cb['value'] * 1.5
     assert '-march=native' in cb['build'] and '-DFIXED_D=4' in cb['build']

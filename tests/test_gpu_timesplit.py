@@ -263,3 +263,66 @@ def test_linear_models_split_on_request_only():
         assert np.array_equal(a, w)
         assert not np.array_equal(s, w)
         cs.assert_close(s, w, 1e-6, 'rts split on request')
+
+
+def test_threads_sharing_a_context_and_a_stream():
+    """the time-split forms keep their scratch in ONE buffer per (context, stream).  Host threads of one process share
+    the context and, unless they set their own, torch's default stream; ctypes releases the GIL, so their compose / apply launches used to
+    be free to interleave (compose_A, compose_B, apply_A -> A smoothed with B's maps).  A call's launches are now enqueued under a
+    per-context lock: eight threads, different inputs and batch sizes (so the buffer also GROWS under them), each result equal to the
+    single-threaded one bit for bit."""
+    import threading
+    import torch
+    from chirpgp_amd import filters_smoothers as fs
+    c = cs.chirp_case(T=1300, seed=47)
+    jobs = []
+    for i in range(8):
+        f = _filter_inputs(c, 2 + 3 * i, 100 + i)
+        jobs.append((torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()))
+    ref = [tuple(t.clone() for t in fs.eks(c.disc, m, P, c.dt, **SPLIT)) for m, P in jobs]
+    ys = [torch.from_numpy(c.ys[None, :] + 0.01 * np.random.default_rng(i).standard_normal((3 + i, c.ys.size))).cuda() for i in range(8)]
+    fref = [fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, y, time_split=(4, 512)) for y in ys]
+    torch.cuda.synchronize()
+    out, fout, errs = [None] * 8, [None] * 8, []
+
+    def work(i):
+        try:
+            for _ in range(6):
+                out[i] = fs.eks(c.disc, jobs[i][0], jobs[i][1], c.dt, **SPLIT)
+                fout[i] = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, ys[i], time_split=(4, 512))
+        except Exception as e:                                       # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(8):
+        for g, w in zip(out[i], ref[i]):
+            assert torch.equal(g, w), i
+        for g, w in zip(fout[i], fref[i]):
+            assert torch.equal(g, w), i
+
+
+def test_a_reserved_workspace_is_pinned():
+    """a captured graph bakes the workspace pointer in, so a buffer sized by cgp_reserve_workspace is never freed or
+    regrown by a launch -- a time-split filter that needs more fails loudly, a smoother takes its one-wavefront form -- until
+    cgp_release_workspace (or a larger reserve)."""
+    import torch
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    c = cs.chirp_case(T=1300, seed=48)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        _engine.reserve_workspace(4096)                    # (rounded up to one MiB)
+        big = torch.from_numpy(c.ys[None, :] + np.zeros((640, 1))).cuda()
+        with pytest.raises(RuntimeError, match='workspace'):
+            fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, big, time_split=(8, 256))      # 8 x 41 x 640 x 8 B = 1.6 MiB > the pinned MiB
+        f = _filter_inputs(c, 640, 5)
+        got = fs.eks(c.disc, f[0], f[1], c.dt, **SPLIT)                                  # falls back to the whole-record walk: same results
+        _engine.release_workspace()
+        ok = fs.ekf(c.disc, c.H, c.Xi, c.m0, c.P0, c.dt, big, time_split=(8, 256))
+        whole = fs.eks(c.disc, f[0], f[1], c.dt, **WHOLE)
+    s.synchronize()
+    assert torch.isfinite(ok[0]).all()
+    for g, w in zip(got, whole):
+        cs.assert_close(g, w, 1e-11, 'pinned-workspace fallback')
