@@ -492,6 +492,11 @@ def main():
                          f'or let `python bench.py --gpus {args.gpus}` start the ranks itself')
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL; must be set before HIP initialises
+    # stdout carries ONE line, the contract line: whatever a library prints on file descriptor 1 meanwhile (gloo announces its peers
+    # there) goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -851,7 +856,8 @@ def main():
                 result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
                 result["gpu_over_cpu_one_core"] = result["value"] / result["cpu_baseline"]["one_core"]["value"]
         details = write_details(result)
-        print(contract_line(result, details))
+        os.write(line_fd, (contract_line(result, details) + '\n').encode())
+    os.close(line_fd)
 
 
 if __name__ == '__main__':

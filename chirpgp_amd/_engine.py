@@ -49,10 +49,15 @@ class CgpInit(C.Structure):
                 ('m0', _vp), ('m0_stride', C.c_int64), ('P0', _vp), ('P0_stride', C.c_int64)]
 
 
+class CgpSmoothOut(C.Structure):
+    _fields_ = [('mss', _vp), ('Pss', _vp), ('comp', C.c_int32), ('func', C.c_int32), ('comp_mean', _vp), ('comp_var', _vp),
+                ('expect', _vp), ('xi', _vp), ('w', _vp), ('order', C.c_int32)]
+
+
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
            'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
-           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash')
+           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select')
 
 _lib = None
 _lock = threading.Lock()
@@ -88,6 +93,9 @@ def load_library():
         lib.cgp_smoother.restype = C.c_int
         lib.cgp_smoother.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_smoother_select.restype = C.c_int
+        lib.cgp_smoother_select.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
+                                            _vp, _vp, C.c_int64, C.c_int64, C.POINTER(CgpSmoothOut), C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_gaussian_expectation_fn.restype = C.c_int
@@ -431,8 +439,33 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         return res + (junction,) if return_junction_error else res
 
 
-def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
-    """cgp_smoother with NumPy / torch marshalling.  (T, d) / (T, d, d) or with a leading batch axis."""
+E_UNSUPPORTED = -2
+_FUNCS = {'softplus': 0, 'g': 0, 'exp': 1, 'identity': 2, 'square': 3}
+_gh_cache = {}
+
+
+def _gh_rule(order):
+    """Nodes and weights of the reference's 1-D Gauss-Hermite rule (SigmaPoints.gauss_hermite(1, order), quadratures.py:156-196)."""
+    if order not in _gh_cache:
+        from chirpgp_amd.quadratures import SigmaPoints
+        sg = SigmaPoints.gauss_hermite(1, order)
+        _gh_cache[order] = (np.asarray(sg.xi, dtype=np.float64).reshape(-1), np.asarray(sg.w, dtype=np.float64).reshape(-1))
+    return _gh_cache[order]
+
+
+class SmootherSelection(dict):
+    """The selected outputs of a smoother call: keys 'mean', 'var', 'expect' (those that were asked for), each (T,) or (B, T)."""
+    __getattr__ = dict.get
+
+
+def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0, want=(True, True), select=None):
+    """cgp_smoother / cgp_smoother_select with NumPy / torch marshalling.  (T, d) / (T, d, d) or with a leading batch axis.
+
+    ``select = dict(comp=k, mean=True, var=True, expect='softplus' | 'exp' | 'identity' | 'square' | None, order=10)`` asks the launch
+    for the smoothed marginal of state component k as well: its mean mss[..., k], its variance Pss[..., k, k] and / or E[f(V)] by 1-D
+    Gauss-Hermite (quadratures.py:234-274 -- the step behind the smoother in every driver of the reference, demos/ekfs_mle.py:69-77).
+    The call then returns ``(mss, Pss, selection)``; with ``want=(False, False)`` the full rows are not written at all (None in their
+    place) and a d = 4 smoother moves 8 - 24 bytes a step instead of 160 (include/chirpgp_hip.h: cgp_smoother_select)."""
     torch = _torch()
     like_numpy = not _is_torch(mfs)
     m, P = dev(mfs), dev(Pfs)
@@ -445,17 +478,66 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0):
     if d != int(spec.d):
         raise ValueError(f'model dimension {spec.d} != data dimension {d}')
     _check_dimension(spec)
+    if select is None and not (want[0] and want[1]):
+        raise ValueError('a smoother without `select` writes both mss and Pss')
     with torch.cuda.device(m.device):
         ctx = context(m.device.index)
         keep = [m, P]
         model = _model_struct(spec, gamma, B, keep)
         sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
-        mss, Pss = torch.empty_like(m), torch.empty_like(P)
         lib, st = load_library(), _stream()
-        rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), C.byref(sig) if sig is not None else None,
-                                                         float(dt), _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), st))
-        _check(ctx, rc, 'cgp_smoother')
-        return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
+        sig_ref = C.byref(sig) if sig is not None else None
+        if select is None:
+            mss, Pss = torch.empty_like(m), torch.empty_like(P)
+            rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), sig_ref,
+                                                             float(dt), _ptr(m), _ptr(P), B, T, _ptr(mss), _ptr(Pss), int(flags), st))
+            _check(ctx, rc, 'cgp_smoother')
+            return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
+        unknown = set(select) - {'comp', 'mean', 'var', 'expect', 'order'}
+        if unknown:
+            raise ValueError(f'select: unknown keys {sorted(unknown)}')
+        comp = int(select['comp'])
+        if comp < 0:
+            comp += d                                   # "-2": the frequency state of every chirp model
+        if not 0 <= comp < d:
+            raise ValueError(f'select: component {select["comp"]} outside the state dimension {d}')
+        func = select.get('expect')
+        if func is not None and func is not False and str(func) not in _FUNCS:
+            raise ValueError(f'select: expect must be one of {sorted(_FUNCS)} (an enumerated integrand: a Python callable cannot run in a kernel)')
+        want_e = func is not None and func is not False
+        order = int(select.get('order', 10))
+        opts = dict(dtype=torch.float64, device=m.device)
+        o = CgpSmoothOut()
+        o.comp, o.func, o.order = comp, (_FUNCS[str(func)] if want_e else 0), order
+        sel = {}
+        for key, field in (('mean', 'comp_mean'), ('var', 'comp_var')):
+            if select.get(key, False):
+                sel[key] = torch.empty((B, T), **opts)
+                setattr(o, field, _ptr(sel[key]))
+        if want_e:
+            xi, w = _gh_rule(order)
+            xi_d, w_d = dev_const(xi), dev_const(w)
+            keep += [xi_d, w_d]
+            sel['expect'] = torch.empty((B, T), **opts)
+            o.expect, o.xi, o.w = _ptr(sel['expect']), _ptr(xi_d), _ptr(w_d)
+        if not sel:
+            raise ValueError('select asks for none of mean / var / expect')
+        mss = torch.empty_like(m) if want[0] else None
+        Pss = torch.empty_like(P) if want[1] else None
+        o.mss, o.Pss = _ptr(mss), _ptr(Pss)
+        rc = _timed('smoother', lambda: lib.cgp_smoother_select(ctx, int(method), C.byref(model), sig_ref, float(dt), _ptr(m), _ptr(P), B, T,
+                                                                C.byref(o), int(flags), st))
+        if rc == E_UNSUPPORTED and (mss is None or Pss is None):
+            # a kernel that can only gather the selection from its full rows: give it (temporary) rows
+            tm = mss if mss is not None else torch.empty_like(m)
+            tP = Pss if Pss is not None else torch.empty_like(P)
+            o.mss, o.Pss = _ptr(tm), _ptr(tP)
+            rc = _timed('smoother', lambda: lib.cgp_smoother_select(ctx, int(method), C.byref(model), sig_ref, float(dt), _ptr(m), _ptr(P), B, T,
+                                                                    C.byref(o), int(flags), st))
+            keep += [tm, tP]
+        _check(ctx, rc, 'cgp_smoother_select')
+        selection = SmootherSelection({k: _out(v, like_numpy, squeeze) for k, v in sel.items()})
+        return (None if mss is None else _out(mss, like_numpy, squeeze), None if Pss is None else _out(Pss, like_numpy, squeeze), selection)
 
 
 FN_SOFTPLUS, FN_EXP, FN_IDENTITY, FN_SQUARE = 0, 1, 2, 3

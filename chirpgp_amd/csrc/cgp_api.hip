@@ -132,6 +132,12 @@ __global__ void __launch_bounds__(256) squared_error_sums_kernel(const double* _
     }
 }
 
+// cgp_smoother_select behind a kernel that writes full rows only: the selected marginal read back out of mss / Pss
+__global__ void __launch_bounds__(256) smooth_select_kernel(const double* __restrict__ mss, const double* __restrict__ Pss, int64_t n, int d, SmoothSel sel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        sel_write(sel, i, mss[i * d + sel.comp], Pss[i * d * d + sel.comp * (d + 1)]);
+}
+
 __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* __restrict__ x, int64_t n,
                                                          double* __restrict__ o0, double* __restrict__ o1) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -466,13 +472,23 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
     return filter_impl(ctx, method, model, sigma, init, dt, ys, ys_stride, ys_repeat, ys_index, B, T, mfs, Pfs, nll, flags, stream, segments, burn_in, junction_err);
 }
 
-int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
-                 const double* mfs, const double* Pfs, int64_t B, int64_t T, double* mss, double* Pss,
-                 uint32_t flags, void* stream) {
+static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
+                         const double* mfs, const double* Pfs, int64_t B, int64_t T, const cgp_smooth_out* out,
+                         uint32_t flags, void* stream) {
     if (!ctx) return CGP_E_ARG;
     if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
     if (B == 0 || T == 0) return CGP_OK;
-    if (!mfs || !Pfs || !mss || !Pss) return fail(ctx, CGP_E_ARG, "mfs / Pfs / mss / Pss must be set");
+    if (!out) return fail(ctx, CGP_E_ARG, "out is NULL");
+    double* const mss = out->mss;
+    double* const Pss = out->Pss;
+    const bool want_sel = out->comp_mean || out->comp_var || out->expect;
+    if (!mfs || !Pfs) return fail(ctx, CGP_E_ARG, "mfs / Pfs must be set");
+    if (!want_sel && (!mss || !Pss)) return fail(ctx, CGP_E_ARG, "mfs / Pfs / mss / Pss must be set");
+    if (want_sel) {
+        if (!model || out->comp < 0 || out->comp >= model->d) return fail(ctx, CGP_E_ARG, "cgp_smooth_out.comp outside 0..d-1");
+        if (out->expect && (out->func < CGP_FN_SOFTPLUS || out->func > CGP_FN_SQUARE || out->order < 1 || !out->xi || !out->w))
+            return fail(ctx, CGP_E_ARG, "cgp_smooth_out.expect needs func, order >= 1, xi and w");
+    }
     if (method < CGP_S_EKS || method > CGP_S_CD_SGP) return fail(ctx, CGP_E_ARG, "unknown smoother method");
     const bool sde = method == CGP_S_CD_EKS || method == CGP_S_CD_SGP;
     const bool sig = method == CGP_S_SGP || method == CGP_S_CD_SGP;
@@ -524,35 +540,84 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     else if (method == CGP_S_CD_SGP && sde4) limit = {48, 1};
     const bool wave = choose_wave(ctx, B, flags, limit, sig ? sigma : nullptr);
     hipStream_t st = (hipStream_t)stream;
+    // which kernel takes the launch -- decided before anything is enqueued, because only some of them write the selected outputs themselves
+    enum Route { kCoop8Linear, kWalk4Linear, kDiscLinear, kCoop8Harm, kWalk4Harm, kLane4, kDiscHarm, kSdeLinear, kCoop4CdSgp, kCoop4CdEks, kSdeHarm, kNone };
+    Route route = kNone;
     switch (model->model_id) {
     case CGP_M_LINEAR:
         // 5 <= d <= 8, one wavefront per trial: maps built per lane, applied cooperatively in the tile layout (cgp_coop8.hpp)
-        if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && coop8_smoother_ok(model->d, T, ma)) rc = dispatch_smoother_coop8_linear(method, model->d, io, ma, st);
+        if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && coop8_smoother_ok(model->d, T, ma)) route = kCoop8Linear;
         // d = 4: gains per lane, the recursion walked on the matrix cores (cgp_walk4.hpp)
-        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->d == 4 && walk4_smoother_fits(T, ma)) rc = dispatch_smoother_walk4_linear(method, io, ma, st);
-        else rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st);
+        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->d == 4 && walk4_smoother_fits(T, ma)) route = kWalk4Linear;
+        else route = kDiscLinear;
         break;
     case CGP_M_HARMONIC_LCD:
     case CGP_M_LASCALA_LCD:
-        if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm >= 2 && coop8_smoother_ok(model->d, T, ma) && coop8_smoother_harm_ok(method, ma)) rc = dispatch_smoother_coop8_harm(method, model->n_harm, io, ma, st);
-        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm == 1 && walk4_smoother_fits(T, ma)) rc = dispatch_smoother_walk4_harm(method, io, ma, st);
-        else if (method == CGP_S_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io))
-            rc = dispatch_smoother_lane4(method, model->model_id, io, ma, st);                 // one lane per trial: cgp_lane4.hpp
-        else rc = dispatch_smoother_disc_harm(method, model->n_harm, wave, io, ma, st);
+        if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm >= 2 && coop8_smoother_ok(model->d, T, ma) && coop8_smoother_harm_ok(method, ma)) route = kCoop8Harm;
+        else if (affine && wave && !(flags & CGP_GENERIC_KERNEL) && model->n_harm == 1 && walk4_smoother_fits(T, ma)) route = kWalk4Harm;
+        else if (method == CGP_S_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io)) route = kLane4;      // one lane per trial: cgp_lane4.hpp
+        else route = kDiscHarm;
         break;
-    case CGP_M_LINEAR_SDE:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;
+    case CGP_M_LINEAR_SDE:   route = kSdeLinear; break;
     case CGP_M_HARMONIC_SDE:
-        if (method == CGP_S_CD_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdsgp(io, ma, st);
-        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) rc = dispatch_smoother_coop4_cdeks(io, ma, st);
-        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io))
-            rc = dispatch_smoother_lane4(method, model->model_id, io, ma, st);                 // one lane per trial: cgp_lane4.hpp
-        else rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st);
+        if (method == CGP_S_CD_SGP && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) route = kCoop4CdSgp;
+        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && wave && !(flags & CGP_GENERIC_KERNEL)) route = kCoop4CdEks;
+        else if (method == CGP_S_CD_EKS && model->n_harm == 1 && !wave && !(flags & CGP_GENERIC_KERNEL) && lane4_smoother_fits(io)) route = kLane4;   // one lane per trial: cgp_lane4.hpp
+        else route = kSdeHarm;
         break;
+    default: break;
+    }
+    // selected outputs (cgp_smoother_select): written by the kernel itself where it is one of the d = 4 walks / lane kernels or the tile-layout
+    // kernels (mss / Pss then optional); any other kernel writes the full rows and a gather launch reads the marginal back out of them
+    const bool sel_native = route == kWalk4Linear || route == kWalk4Harm || route == kLane4 || route == kCoop8Linear || route == kCoop8Harm;
+    if (want_sel) {
+        if (sel_native) {
+            io.sel.comp = out->comp; io.sel.func = out->func; io.sel.order = out->order;
+            io.sel.mean = out->comp_mean; io.sel.var = out->comp_var; io.sel.expect = out->expect;
+            io.sel.xi = out->xi; io.sel.w = out->w;
+        } else if (!mss || !Pss)
+            return fail(ctx, CGP_E_UNSUPPORTED, "this (method, model, launch shape) writes selected outputs from its full rows only: pass mss and Pss as well");
+    }
+    switch (route) {
+    case kCoop8Linear: rc = dispatch_smoother_coop8_linear(method, model->d, io, ma, st); break;
+    case kWalk4Linear: rc = dispatch_smoother_walk4_linear(method, io, ma, st); break;
+    case kDiscLinear:  rc = dispatch_smoother_disc_linear(method, model->d, wave, io, ma, st); break;
+    case kCoop8Harm:   rc = dispatch_smoother_coop8_harm(method, model->n_harm, io, ma, st); break;
+    case kWalk4Harm:   rc = dispatch_smoother_walk4_harm(method, io, ma, st); break;
+    case kLane4:       rc = dispatch_smoother_lane4(method, model->model_id, io, ma, st); break;
+    case kDiscHarm:    rc = dispatch_smoother_disc_harm(method, model->n_harm, wave, io, ma, st); break;
+    case kSdeLinear:   rc = dispatch_smoother_sde_linear(method, model->d, wave, io, ma, st); break;
+    case kCoop4CdSgp:  rc = dispatch_smoother_coop4_cdsgp(io, ma, st); break;
+    case kCoop4CdEks:  rc = dispatch_smoother_coop4_cdeks(io, ma, st); break;
+    case kSdeHarm:     rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st); break;
     default: rc = CGP_E_ARG;
+    }
+    if (rc == CGP_OK && want_sel && !sel_native) {
+        SmoothSel sel;
+        sel.comp = out->comp; sel.func = out->func; sel.order = out->order;
+        sel.mean = out->comp_mean; sel.var = out->comp_var; sel.expect = out->expect; sel.xi = out->xi; sel.w = out->w;
+        const int64_t n = B * T, blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(smooth_select_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, mss, Pss, n, model->d, sel);
+        if (hipGetLastError() != hipSuccess) rc = CGP_E_HIP;
     }
     if (rc == CGP_E_UNSUPPORTED) return fail(ctx, rc, "this (method, model, dimension) combination is not compiled in");
     if (rc == CGP_E_HIP) return fail(ctx, rc, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return rc;
+}
+
+int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
+                 const double* mfs, const double* Pfs, int64_t B, int64_t T, double* mss, double* Pss,
+                 uint32_t flags, void* stream) {
+    cgp_smooth_out out;
+    memset(&out, 0, sizeof(out));
+    out.mss = mss; out.Pss = Pss; out.comp = -1;
+    return smoother_impl(ctx, method, model, sigma, dt, mfs, Pfs, B, T, &out, flags, stream);
+}
+
+int cgp_smoother_select(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
+                        const double* mfs, const double* Pfs, int64_t B, int64_t T, const cgp_smooth_out* out,
+                        uint32_t flags, void* stream) {
+    return smoother_impl(ctx, method, model, sigma, dt, mfs, Pfs, B, T, out, flags, stream);
 }
 
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,

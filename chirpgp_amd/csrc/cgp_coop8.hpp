@@ -518,12 +518,16 @@ constexpr int kRowDoubles = 45;                   // Pf (packed lower, 36) | mf 
 constexpr int kRowmf = 36, kRowZero = 44;
 struct Elem8WalkOperands { double gA0, gA1, gB0, gB1, gM, Ppv, mpc, Pfv, mfr; };
 
-template <class Elem>
+// SEL (cgp_smoother_select): the lanes that hold the selected component's smoothed mean and variance leave them in LDS step by step;
+// behind a tile's walk every lane finishes ITS step (the marginal itself, E[f(V)] by 1-D Gauss-Hermite) -- one coalesced 512-byte
+// store per output and tile.  mss / Pss may be NULL then (a window of zero bytes drops their stores).
+template <class Elem, bool SEL = false>
 __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, ModelArgs ma) {      // one wavefront per trial, the whole record
     constexpr int D = Elem::D;
     static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
     __shared__ double elems[16 * kElemDoubles];      // (G, Pp, mp) of a quarter tile: 13.9 KB
     __shared__ double rows[64 * kRowDoubles];        // (Pf, mf) of the whole tile: 23.0 KB -- together 36.9 KB: four workgroups a CU
+    __shared__ double selbuf[SEL ? 128 : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -557,13 +561,15 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     const unsigned bS = entry ? 8u * (unsigned)(i * D + j) : kOobOffset;
     const unsigned bms = mean_lane ? 8u * (unsigned)i : kOobOffset;
     OobWindow wPs, wms;
-    wPs.init(Pss, T * D * D * 8); wms.init(mss, T * D * 8);
+    wPs.init(io.Pss ? Pss : nullptr, T * D * D * 8); wms.init(io.mss ? mss : nullptr, T * D * 8);
 
     // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
     double Ps = entry ? Pfs[(T - 1) * D * D + ((i >= j) ? i * D + j : j * D + i)] : 0.0;
     double xc = (4 * J + r < D) ? mfs[(T - 1) * D + 4 * J + r] : 0.0;
-    if (entry) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
-    if (mean_lane) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+    if (entry && (!SEL || io.Pss)) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
+    if (mean_lane && (!SEL || io.mss)) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+    if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
+    const bool sel_var_lane = SEL && entry && i == io.sel.comp && j == io.sel.comp, sel_mean_lane = SEL && mean_lane && i == io.sel.comp;
 
     for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
         const int64_t base = hi - 63;                                      // step of lane 0 (may be negative in the last tile)
@@ -623,8 +629,16 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
                 const unsigned step = (unsigned)(base + s);
                 wPs.store(Ps, bS + step * (unsigned)(D * D * 8));
                 wms.store(ym, bms + step * (unsigned)(D * 8));
+                if constexpr (SEL) {
+                    if (sel_var_lane) selbuf[64 + s] = Ps;
+                    if (sel_mean_lane) selbuf[s] = ym;
+                }
                 cur = nxt;
             }
+            wave_lds_fence();
+        }
+        if constexpr (SEL) {
+            if (mystep >= 0) sel_write(io.sel, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
             wave_lds_fence();
         }
     }
@@ -633,11 +647,13 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
 // ---- the affine form: records (G, C, c); the time-split passes, and the whole record with CGP_TIME_SPLIT-style maps
 struct Elem8Operands { double gA0, gA1, gB0, gB1, gM, Cv, cr; };
 
-template <class Elem, int MODE>
+template <class Elem, int MODE, bool SEL = false>
 __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArgs ma) {
     constexpr int D = Elem::D;
     static_assert(D >= 5 && D <= 8, "tile layout of an 8 x 8 matrix");
+    static_assert(!(SEL && MODE == kWalkCompose), "pass 1 of the time-split form writes nothing");
     __shared__ double elems[32 * kElemDoubles];
+    __shared__ double selbuf[SEL ? 128 : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -673,7 +689,7 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
     const unsigned bS = entry ? 8u * (unsigned)(i * D + j) : kOobOffset;
     const unsigned bms = mean_lane ? 8u * (unsigned)i : kOobOffset;
     OobWindow wPs, wms;
-    wPs.init(MODE == kWalkCompose ? nullptr : Pss, T * D * D * 8); wms.init(MODE == kWalkCompose ? nullptr : mss, T * D * 8);
+    wPs.init((MODE == kWalkCompose || !io.Pss) ? nullptr : Pss, T * D * D * 8); wms.init((MODE == kWalkCompose || !io.mss) ? nullptr : mss, T * D * 8);
 
     // carry: Ps in tile layout, ms with lane (r, (I, J), q) holding ms[4 J + r]; last row copied verbatim (filters_smoothers.py:140-142)
     double Ps = entry ? Pfs[(T - 1) * D * D + ((i >= j) ? i * D + j : j * D + i)] : 0.0;
@@ -681,9 +697,11 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
     double Acc = (entry && i == j) ? 1.0 : 0.0;      // pass 1: the composed linear part, A <- G A
     if constexpr (MODE == kWalkCompose) { Ps = 0.0; xc = 0.0; }
     if (MODE != kWalkCompose && seg == 0) {
-        if (entry) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
-        if (mean_lane) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+        if (entry && (!SEL || io.Pss)) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
+        if (mean_lane && (!SEL || io.mss)) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
+        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
     }
+    const bool sel_var_lane = SEL && entry && i == io.sel.comp && j == io.sel.comp, sel_mean_lane = SEL && mean_lane && i == io.sel.comp;
     // one step of the recursion with the operands o: W = Ps' G^T, Ps = G W + C, ms = G ms' + c
     auto step = [&](const Elem8Operands& o, double& ym) {
         const double W = mfma4x4(blk_rows_of_k1(Ps), o.gB1, mfma4x4(blk_rows_of_k0(Ps), o.gB0, 0.0));
@@ -750,9 +768,17 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
                     const unsigned st = (unsigned)(base + s);
                     wPs.store(Ps, bS + st * (unsigned)(D * D * 8));
                     wms.store(ym, bms + st * (unsigned)(D * 8));
+                    if constexpr (SEL) {
+                        if (sel_var_lane) selbuf[64 + s] = Ps;
+                        if (sel_mean_lane) selbuf[s] = ym;
+                    }
                 }
                 cur = nxt;
             }
+            wave_lds_fence();
+        }
+        if constexpr (SEL) {
+            if (mystep >= 0) sel_write(io.sel, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
             wave_lds_fence();
         }
     }
@@ -786,10 +812,13 @@ inline hipError_t launch_coop8_smoother(const SmootherIO& io_in, const ModelArgs
         }
     }
     const int segs = walk_segments(io_in, per_cu);
-    if (segs <= 1) {
-        hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+    const bool sel = io_in.sel.comp >= 0;
+    auto whole = [&]() {
+        if (sel) hipLaunchKernelGGL((coop8_smoother_kernel<Elem, true>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+        else hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
         return hipGetLastError();
-    }
+    };
+    if (segs <= 1) return whole();
     // time-split: two passes with the segments' maps in the context's per-stream workspace (nothing the caller sees)
     SmootherIO io = io_in;
     io.segs = segs;
@@ -798,14 +827,12 @@ inline hipError_t launch_coop8_smoother(const SmootherIO& io_in, const ModelArgs
     io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
     void* ws = ctx_workspace(io.host_ctx, stream, sizeof(double) * kMap8Doubles * (size_t)io.B * io.segs);
     hipError_t e;
-    if (!ws) {                           // no workspace (allocation failed, or growth inside a graph capture): the one-wave-per-trial form needs none
-        hipLaunchKernelGGL((coop8_smoother_kernel<Elem>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
-        return hipGetLastError();
-    }
+    if (!ws) return whole();             // no workspace (allocation failed, pinned too small, growth inside a graph capture): the one-wave-per-trial form needs none
     io.ws = (double*)ws;
     const unsigned grid = (unsigned)(io.B * io.segs);
     hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
-    hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    if (sel) hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkApply, true>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    else hipLaunchKernelGGL((coop8_split_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
     e = hipGetLastError();
     return e;
 }

@@ -68,6 +68,41 @@ __device__ __forceinline__ FilterSpan filter_span(const FilterIO& io, int64_t v)
     return {b, t_begin, t_out, t_end, s, io.seg_state ? io.seg_state + (b * io.segs + s) * io.seg_stride : nullptr};
 }
 
+// Selected outputs of a smoother launch (cgp_smoother_select; SURVEY 8f-2: the step right behind the smoother in every driver of the
+// reference keeps mss[:, k], Pss[:, k, k] and E[g(V)] of that marginal -- demos/ekfs_mle.py:69-77, quadratures.py:234-274):
+// per (trial, step) the smoothed mean and variance of ONE state component and / or E[f(V)], V ~ N(mean, variance), by 1-D
+// Gauss-Hermite -- written as [B][T] arrays by the kernel that produced them, so that a pipeline that needs nothing else (mss / Pss
+// NULL) writes 8 - 24 bytes a step instead of 8 (d + d^2).
+struct SmoothSel {
+    int comp = -1;                          // state component; < 0: nothing selected
+    int func = 0, order = 0;                // CGP_FN_* integrand and number of nodes of `expect`
+    double* __restrict__ mean = nullptr;    // [B][T] or NULL
+    double* __restrict__ var = nullptr;     // [B][T] or NULL
+    double* __restrict__ expect = nullptr;  // [B][T] or NULL
+    const double* __restrict__ xi = nullptr;   // [order] nodes, the reference's scaling (sqrt(2) x the Hermite roots)
+    const double* __restrict__ w = nullptr;    // [order] weights, normalised
+};
+// E[f(m + s Z)] over the rule's nodes: the loop of quadratures.py:218-231 for d = 1, the same operations as cgp_gaussian_expectation_fn.
+CGP_DEV double gh_expectation(int func, double m, double s, const double* __restrict__ xi, const double* __restrict__ w, int order) {
+    double acc = 0.0;
+    for (int p = 0; p < order; p++) {
+        const double x = fma(s, xi[p], m);
+        double f;
+        if (func == CGP_FN_SOFTPLUS) f = log(exp(x) + 1.0);                 // models.py:50, the naive form as is
+        else if (func == CGP_FN_EXP) f = exp(x);
+        else if (func == CGP_FN_SQUARE) f = x * x;
+        else f = x;
+        acc = fma(w[p], f, acc);
+    }
+    return acc;
+}
+// one (trial, step) of the selected outputs; idx = trial * T + step
+CGP_DEV void sel_write(const SmoothSel& s, int64_t idx, double m, double v) {
+    if (s.mean) s.mean[idx] = m;
+    if (s.var) s.var[idx] = v;
+    if (s.expect) s.expect[idx] = gh_expectation(s.func, m, sqrt(v), s.xi, s.w, s.order);
+}
+
 struct SmootherIO {
     const double* __restrict__ mfs;
     const double* __restrict__ Pfs;
@@ -83,6 +118,7 @@ struct SmootherIO {
     int tiles_per_seg = 0;
     double* __restrict__ ws = nullptr;
     cgp_ctx* host_ctx = nullptr;  // host side only: the context whose per-stream workspace (cgp::ctx_workspace) serves `ws`
+    SmoothSel sel;                // cgp_smoother_select: selected outputs (mss / Pss may then be NULL); comp < 0: off
 };
 
 // Dynamic LDS (sized by the launch): the staged sigma-point set.  The static LDS in front of it (the 17 152-byte

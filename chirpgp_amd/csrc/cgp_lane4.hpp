@@ -348,7 +348,12 @@ CGP_DEV unsigned lane4_row_piece(int lane, int p) {
     return (unsigned)(i * Lane4S::PITCH + (i & 1) * 16 + s * 128 + ((p - s) & 7) * 16);
 }
 
-template <class Step>
+// SEL (cgp_smoother_select): per step every lane also parks the selected component's smoothed mean / variance / E[f(V)] -- whichever
+// are wanted, `nsel` of them -- in LDS, [16 steps][64 trials + 1]; every 16 steps (one 128-byte line of a [B][T] array per trial: trials
+// of equal line phase share a wavefront, period = 16 / gcd(T, 16)) the wavefront writes them as whole lines, eight 16-byte-per-lane
+// store instructions per output.  The full outputs are optional then (mss / Pss NULL: 8 - 24 bytes a step leave instead of 160).
+struct Lane4Sel { static constexpr int PITCH = 65, DOUBLES = 16 * 65; };
+template <class Step, bool SEL = false>
 __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, ModelArgs ma, int period) {
     static_assert(Step::D == 4 && !Step::WAVE && !Step::USES_SIGMA, "one lane per trial, d = 4, no sigma-point set");
     constexpr int D = 4;
@@ -370,16 +375,26 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
-    double* __restrict__ mss = io.mss + trial * T * D;
-    double* __restrict__ Pss = io.Pss + trial * T * D * D;
+    const bool want_m = !SEL || io.mss != nullptr, want_P = !SEL || io.Pss != nullptr;      // (wave-uniform)
+    double* __restrict__ mss = want_m ? io.mss + trial * T * D : nullptr;
+    double* __restrict__ Pss = want_P ? io.Pss + trial * T * D * D : nullptr;
+    // the selected outputs: `nsel` arrays parked in the dynamic LDS in the order mean, variance, expectation
+    const int comp = SEL ? io.sel.comp : 0;
+    const bool sel_m = SEL && io.sel.mean, sel_v = SEL && io.sel.var, sel_e = SEL && io.sel.expect;
+    double* const selM = SEL ? dyn_lds() : nullptr;
+    double* const selV = selM + (sel_m ? Lane4Sel::DOUBLES : 0);
+    double* const selE = selV + (sel_v ? Lane4Sel::DOUBLES : 0);
+    auto pick_mean = [&](const Vec<D>& m) { return comp == 0 ? m.v[0] : comp == 1 ? m.v[1] : comp == 2 ? m.v[2] : m.v[3]; };
+    auto pick_var = [&](const Sym<D>& P) { return comp == 0 ? P.a[0] : comp == 1 ? P.a[2] : comp == 2 ? P.a[5] : P.a[9]; };      // the diagonal of the packed lower triangle
 
     // filters_smoothers.py:140-142: the last smoothing row is the last filtering row (copied verbatim, all 16 covariance entries)
     Vec<D> ms; Sym<D> Ps;
     load_vec<D>(mfs + (T - 1) * D, ms);
     load_sym<D>(Pfs + (T - 1) * D * D, Ps);
     if (valid) {
-        CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
-        CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i];
+        if (want_m) { CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i]; }
+        if (want_P) { CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i]; }
+        if constexpr (SEL) sel_write(io.sel, trial * T + T - 1, pick_mean(ms), pick_var(Ps));
     }
     // one row outside the whole quads: inputs and outputs straight from / to this lane's rows (a handful per record)
     auto edge = [&](int64_t t) __attribute__((always_inline)) {
@@ -388,20 +403,31 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
         load_sym<D>(Pfs + t * D * D, Pf);
         step.step(lane, lds, mf, Pf, ms, Ps);
         if (valid) {
-            store_vec<D>(mss + t * D, ms);
-            store_sym_full<D>(Pss + t * D * D, Ps);
+            if (want_m) store_vec<D>(mss + t * D, ms);
+            if (want_P) store_sym_full<D>(Pss + t * D * D, Ps);
+            if constexpr (SEL) sel_write(io.sel, trial * T + t, pick_mean(ms), pick_var(Ps));
         }
     };
-    // rows [a_lo, a_lo + 4 nq) are whole lines of four means for every trial of this wavefront (wave-uniform: period * T is a multiple of 4)
-    const int a_lo = (int)((4 - ((block_first * T) & 3)) & 3);
-    const int64_t nq = (T - 1 > a_lo) ? (T - 1 - a_lo) / 4 : 0;
+    // rows [a_lo, a_lo + 4 nq) are whole lines of four means for every trial of this wavefront (wave-uniform: period * T is a multiple of 4);
+    // SEL: whole lines of SIXTEEN doubles of a [B][T] array (period * T a multiple of 16), and a whole number of them
+    const int a_lo = SEL ? (int)((16 - ((block_first * T) & 15)) & 15) : (int)((4 - ((block_first * T) & 3)) & 3);
+    const int64_t nq = (T - 1 > a_lo) ? ((T - 1 - a_lo) / 4) & (SEL ? ~(int64_t)3 : ~(int64_t)0) : 0;
     for (int64_t t = T - 2; t >= (nq > 0 ? a_lo + 4 * nq : 0); t--) edge(t);     // (no whole quad: every row goes this way)
     if (nq > 0) {
         // output windows over this wavefront's trials, per-lane offsets of (trial 8 i + sub, piece pc), as in the filter
         OobWindow wP, wM;
         const int64_t span = (int64_t)(nvalid - 1) * period + 1;
-        wP.init(io.Pss + block_first * T * 16, span * T * 128);
-        wM.init(io.mss + block_first * T * 4, span * T * 32);
+        wP.init(want_P ? io.Pss + block_first * T * 16 : nullptr, span * T * 128);
+        wM.init(want_m ? io.mss + block_first * T * 4 : nullptr, span * T * 32);
+        OobWindow wSm, wSv, wSe;                                         // the selected outputs: [B][T] doubles
+        if constexpr (SEL) {
+            wSm.init(sel_m ? io.sel.mean + block_first * T : nullptr, span * T * 8);
+            wSv.init(sel_v ? io.sel.var + block_first * T : nullptr, span * T * 8);
+            wSe.init(sel_e ? io.sel.expect + block_first * T : nullptr, span * T * 8);
+        }
+        const unsigned rowS = (unsigned)(T * period) * 8u;
+        const int nflush = SEL ? 8 * ((sel_m ? 1 : 0) + (sel_v ? 1 : 0) + (sel_e ? 1 : 0)) : 0;      // store instructions of one flush
+        int pending = 0;                                                 // ... issued since the last DMA request (SEL without full outputs)
         const int sub = lane >> 3, pc = lane & 7;
         const unsigned rowP = (unsigned)(T * period) * 128u, rowM = (unsigned)(T * period) * 32u;
         const int64_t t_hi = a_lo + 4 * nq - 1;                          // the first row of the quads (processed downwards)
@@ -436,9 +462,18 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                 const int64_t t = a + s4;
                 // this row's covariances were requested a step ago: wait for them, not for the stores issued since (8 covariance stores;
                 // behind the last row of a quad also 8 stores of means)
-                if (first) lane4_wait_vm<0>();
-                else if (s4 == 3) lane4_wait_vm<16>();
-                else lane4_wait_vm<8>();
+                if constexpr (SEL) {
+                    // counted only where nothing but a flush was stored since the request (the selected outputs alone: the fast case)
+                    if (first || want_P || want_m || pending == 0) lane4_wait_vm<0>();
+                    else if (pending == 8) lane4_wait_vm<8>();
+                    else if (pending == 16) lane4_wait_vm<16>();
+                    else lane4_wait_vm<24>();
+                    pending = 0;
+                } else {
+                    if (first) lane4_wait_vm<0>();
+                    else if (s4 == 3) lane4_wait_vm<16>();
+                    else lane4_wait_vm<8>();
+                }
                 first = false;
                 if (t > a_lo) lane4_dma_rows(pbase + (unsigned)(cur ^ 1) * (Lane4S::ROWS * 8u), gP + (t - 1) * 16, tr_step * 16, sub, nvalid, lastP + (t - 1) * 16);
                 if (s4 == 3) {
@@ -459,7 +494,27 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                     Pf.a[6] = p6.x; Pf.a[7] = p6.y; Pf.a[8] = p7.x; Pf.a[9] = p7.y;                 // the lower triangle, like load_sym
                 }
                 step.step(lane, lds, mf, Pf, ms, Ps);
-                {
+                if constexpr (SEL) {
+                    const int slot = (int)((t - a_lo) & 15);
+                    const double m_k = pick_mean(ms), v_k = pick_var(Ps);
+                    if (sel_m) selM[slot * Lane4Sel::PITCH + lane] = m_k;
+                    if (sel_v) selV[slot * Lane4Sel::PITCH + lane] = v_k;
+                    if (sel_e) selE[slot * Lane4Sel::PITCH + lane] = gh_expectation(io.sel.func, m_k, sqrt(v_k), io.sel.xi, io.sel.w, io.sel.order);
+                    if (slot == 0) {
+                        // sixteen steps of 64 trials: lane (sub, pc) writes the steps 2 pc, 2 pc + 1 of the trials 8 i + sub -- whole 128-byte lines
+                        wave_lds_fence();
+                        const unsigned off0 = (unsigned)sub * rowS + (unsigned)t * 8u + (unsigned)pc * 16u;
+                        const int at = (2 * pc) * Lane4Sel::PITCH + sub;
+                        CGP_UNROLL for (int i = 0; i < 8; i++) {
+                            if (sel_m) wSm.store2(selM[at + 8 * i], selM[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
+                            if (sel_v) wSv.store2(selV[at + 8 * i], selV[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
+                            if (sel_e) wSe.store2(selE[at + 8 * i], selE[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
+                        }
+                        wave_lds_fence();
+                        pending = nflush;
+                    }
+                }
+                if (want_P) {
                     double* row = tile + (lane & 31) * Lane4::PITCH_P;
                     CGP_UNROLL for (int h = 0; h < 2; h++) {
                         if ((lane >> 5) == h) {
@@ -475,7 +530,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                 CGP_UNROLL for (int i = 0; i < D; i++) mh[4 * s4 + i] = ms.v[i];
                 cur ^= 1;
             }
-            {
+            if (want_m) {
                 // (the passes are NOT pipelined as in the filter: at one wavefront per SIMD with all 256 registers taken, the reads held back
                 // cost more than their latency -- eks 7.4 - 7.9 -> 8.15 ms per 262 144 x 500, measured)
                 double* row = tile + (lane & 15) * Lane4::PITCH_M;
@@ -506,6 +561,14 @@ inline int lane4_smoother_period(int64_t T) {
 template <class Step>
 inline hipError_t launch_lane4_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    if (io.sel.comp >= 0) {
+        // selected outputs: trials grouped by the phase of their [B][T] rows against the 128-byte lines (the filter's period)
+        const int period = lane4_period(io.T);
+        const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+        const int nsel = (io.sel.mean ? 1 : 0) + (io.sel.var ? 1 : 0) + (io.sel.expect ? 1 : 0);
+        hipLaunchKernelGGL((lane4_smoother_kernel<Step, true>), dim3((unsigned)(groups * period)), dim3(64), sizeof(double) * Lane4Sel::DOUBLES * nsel, stream, io, ma, period);
+        return hipGetLastError();
+    }
     const int period = lane4_smoother_period(io.T);
     const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
     hipLaunchKernelGGL((lane4_smoother_kernel<Step>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);

@@ -50,10 +50,16 @@ CGP_DEV double blk_bcast0(double x) {
     return dpp_banks_f64<kRowRor12, 0x8>(dpp_banks_f64<kRowRor8, 0x4>(dpp_banks_f64<kRowRor4, 0x2>(x, x), x), x);
 }
 
-template <class Elem, int MODE = kWalkWhole>
+// SEL (cgp_smoother_select): the walk also leaves the selected component's smoothed mean and variance of every step of the tile in
+// LDS (two ds_write per quad, by the lanes that hold them); behind the walk every lane finishes ITS step -- the marginal itself and / or
+// E[f(V)] by 1-D Gauss-Hermite, 64 steps at a time, one coalesced 512-byte store per output and tile.  mss / Pss may be NULL then
+// (a window of zero bytes drops their stores).
+template <class Elem, int MODE = kWalkWhole, bool SEL = false>
 __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(Elem::D == 4, "d = 4 kernel");
+    static_assert(!(SEL && MODE == kWalkCompose), "pass 1 of the time-split form writes nothing");
     __shared__ double recs[64 * kWalkRec];
+    __shared__ double selbuf[SEL ? 128 : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int64_t trial = (MODE == kWalkWhole) ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / (unsigned)io.segs);
@@ -69,7 +75,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     double* __restrict__ mss = io.mss + trial * T * 4;
     double* __restrict__ Pss = io.Pss + trial * T * 16;
     OobWindow wPs, wms;                               // which lanes store is an offset, not a branch (cgp_coop4.hpp)
-    wPs.init(MODE == kWalkCompose ? nullptr : Pss, T * 128); wms.init(MODE == kWalkCompose ? nullptr : mss, T * 32);   // pass 1 stores nothing
+    wPs.init((MODE == kWalkCompose || !io.Pss) ? nullptr : Pss, T * 128); wms.init((MODE == kWalkCompose || !io.mss) ? nullptr : mss, T * 32);   // pass 1 stores nothing
     // the segment's tiles: tile j covers the steps T - 2 - 64 j - 63 .. T - 2 - 64 j (segment 0 is the LAST in time)
     const int64_t hi_first = (MODE == kWalkWhole) ? T - 2 : T - 2 - 64 * (int64_t)seg * io.tiles_per_seg;
     const int64_t hi_stop = (MODE == kWalkWhole) ? 0 : max((int64_t)0, hi_first - 64 * (int64_t)io.tiles_per_seg + 1);   // tiles with hi >= hi_stop
@@ -86,9 +92,11 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     double Acc = (r == q) ? 1.0 : 0.0;                // pass 1: the composed linear part, A <- M A
     if constexpr (MODE == kWalkCompose) { Ps = 0.0; ms = 0.0; }
     if (MODE != kWalkCompose && seg == 0) {
-        if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
-        if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+        if (lane < 16 && (!SEL || io.Pss)) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
+        if (lane < 4 && (!SEL || io.mss)) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * 4 + io.sel.comp], Pfs[(T - 1) * 16 + io.sel.comp * 5]); }
     }
+    const bool sel_var_lane = SEL && r == io.sel.comp && q == io.sel.comp, sel_mean_lane = SEL && r == io.sel.comp && q == 0;
     if constexpr (MODE == kWalkApply) {
         // carry-in of this segment: the maps of the segments later in time, applied in order to the last filtering row
         const double* __restrict__ maps = io.ws + trial * io.segs * kWalkMapDoubles;
@@ -159,6 +167,10 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
                 const unsigned step = (unsigned)(base + 4 * Q);
                 wPs.store(Psn, offP + step * 128u);
                 wms.store(msn, offm + step * 32u);
+                if constexpr (SEL) {
+                    if (sel_var_lane) selbuf[64 + 4 * Q + b] = Psn;
+                    if (sel_mean_lane) selbuf[4 * Q + b] = msn;
+                }
                 Ps = blk_bcast0(Psn);                                      // block 0 = step 4 Q: the next quad's carry
                 ms = blk_bcast0(msn);
             }
@@ -189,6 +201,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             wave_lds_fence();
             walk(base);
             wave_lds_fence();
+            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) elem.map(mf, Pf, G, c, C);
             write_record(base - 64 + lane >= 0, G, c, C);
             wave_lds_fence();
@@ -211,6 +224,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             wave_lds_fence();
             walk(base);
             wave_lds_fence();
+            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
         }
     }
     if constexpr (MODE == kWalkCompose) {
@@ -244,10 +258,13 @@ inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs
         }
     }
     const int segs = walk_segments(io_in, per_cu);
-    if (segs <= 1) {
-        hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+    const bool sel = io_in.sel.comp >= 0;
+    auto whole = [&]() {
+        if (sel) hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole, true>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
+        else hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
         return hipGetLastError();
-    }
+    };
+    if (segs <= 1) return whole();
     // time-split: two passes with the segments' maps in the context's per-stream workspace (nothing the caller sees)
     SmootherIO io = io_in;
     io.segs = segs;
@@ -256,14 +273,12 @@ inline hipError_t launch_walk4_smoother(const SmootherIO& io_in, const ModelArgs
     io.segs = (int)((tiles + io.tiles_per_seg - 1) / io.tiles_per_seg);           // no empty segments
     void* ws = ctx_workspace(io.host_ctx, stream, sizeof(double) * kWalkMapDoubles * (size_t)io.B * io.segs);
     hipError_t e;
-    if (!ws) {                           // no workspace (allocation failed, or growth inside a graph capture): the one-wave-per-trial form needs none
-        hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkWhole>), dim3((unsigned)io_in.B), dim3(64), dyn, stream, io_in, ma);
-        return hipGetLastError();
-    }
+    if (!ws) return whole();             // no workspace (allocation failed, pinned too small, growth inside a graph capture): the one-wave-per-trial form needs none
     io.ws = (double*)ws;
     const unsigned grid = (unsigned)(io.B * io.segs);
     hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkCompose>), dim3(grid), dim3(64), dyn, stream, io, ma);
-    hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    if (sel) hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkApply, true>), dim3(grid), dim3(64), dyn, stream, io, ma);
+    else hipLaunchKernelGGL((walk4_smoother_kernel<Elem, kWalkApply>), dim3(grid), dim3(64), dyn, stream, io, ma);
     e = hipGetLastError();
     return e;
 }

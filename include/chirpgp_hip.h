@@ -234,6 +234,30 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
                  double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
                  double* mss, double* Pss, uint32_t flags, void* stream);
 
+/* Smoothers with selected outputs -- the step right behind the smoother in every driver of the reference, fused into it
+ * (demos/ekfs_mle.py:69-77: gaussian_expectation(ms = mss[:, 2], chol_Ps = sqrt(Pss[:, 2, 2]), func = g), then rmse; quadratures.py:234-274).
+ * Besides (or instead of) the full rows a launch writes, per trial and step, the smoothed mean and variance of ONE state component and
+ * E[f(V)], V ~ N(mean, variance), by 1-D Gauss-Hermite -- [B][T] arrays, each optional.  With mss = Pss = NULL a d = 4 smoother writes
+ * 8 - 24 bytes a step instead of 160.  The d = 4 discrete smoothers (rts, eks, sgp_smoother; both launch shapes of eks, cd_eks one lane
+ * per trial) and the d = 5 .. 8 tile-layout smoothers write the selected outputs themselves; every other kernel needs mss and Pss as
+ * well (CGP_E_UNSUPPORTED without them) and the selection is gathered from the full rows by a second launch.  Row T - 1 is the
+ * filtering row's marginal.  A negative variance gives NaN in `expect`, like sqrt in the reference's call. */
+typedef struct cgp_smooth_out {
+    double*       mss;         /* [B][T][d] or NULL                                                             */
+    double*       Pss;         /* [B][T][d][d] or NULL                                                          */
+    int32_t       comp;        /* state component k of the three arrays below, 0 <= k < d                        */
+    int32_t       func;        /* CGP_FN_* integrand of `expect`                                                 */
+    double*       comp_mean;   /* [B][T]: mss[b][t][k], or NULL                                                  */
+    double*       comp_var;    /* [B][T]: Pss[b][t][k][k], or NULL                                               */
+    double*       expect;      /* [B][T]: E[f(V)], or NULL                                                       */
+    const double* xi;          /* [order] nodes (DEVICE), the reference's scaling: sqrt(2) x the Hermite roots   */
+    const double* w;           /* [order] weights (DEVICE), normalised                                           */
+    int32_t       order;
+} cgp_smooth_out;
+int cgp_smoother_select(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
+                        double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
+                        const cgp_smooth_out* out, uint32_t flags, void* stream);
+
 /* E[softplus(V)] for n scalar Gaussian marginals N(ms[i], sd[i]^2) by 1-D Gauss-Hermite of the given order
  * (nodes xi[order], weights w[order] already in the reference's scaling): quadratures.py:234-274 with func = g. */
 int cgp_gaussian_expectation(cgp_ctx* ctx, const double* ms, const double* sd, int64_t n, int64_t in_stride,

@@ -1,0 +1,331 @@
+"""Generates tests/golden/exact_*.npz: the path's formulas evaluated in 60-digit arithmetic (mpmath), rounded to float64 at the end.
+
+Why.  The reference cannot run in this pipeline (no JAX: SURVEY.md 8c), so the float64 oracles (oracle/np_filters.py, oracle/c/port.c)
+are pinned by the reference's property tests only.  What separates ANY float64 evaluation of the reference's formulas -- XLA's, NumPy's,
+the C port's, the HIP kernels' -- from each other is rounding: operation order, fused multiply-adds, the libm behind exp / log / sin /
+cos.  This script evaluates the same recursions with a unit roundoff of 1e-60, i.e. their exact values for float64 inputs, so that the
+distance of every float64 implementation from that common reference can be measured in units of 2^-53 (tests/test_exact.py): the
+"amplification" of the recursion.  XLA's result is an evaluation of the same kind and sits within the same distance of the exact value --
+that bounds what the unrunnable reference could differ by, against the north star's 1e-5 gate.  (Parity stays "partial" by the rules.)
+
+Restated here, independently of oracle/ (plain lists of mpf, no NumPy linear algebra), following the reference line by line:
+    ekf / eks                         filters_smoothers.py:55-85, 222-264, 317-349     (jacfwd -> complex step with h = 1e-45 at 100 digits)
+    sgp_filter / sgp_smoother         filters_smoothers.py:88-121, 446-531             (Gauss-Hermite order 3: nodes 0, +-sqrt 3; weights 2/3, 1/6, 1/6)
+    cd_sgp_filter / cd_sgp_smoother   filters_smoothers.py:124-137, 534-632; quadratures.py:34-81
+    chirp model                       models.py:50, 61-73, 76-119, 264-311, 437-459
+Inputs: the toy chirp of demos/ekfs_mle.py:16-39 at the MLE start point, T = 500 (cd: 300), dt = 1e-3 -- one record at Xi = 0.1 (tracks)
+and one at Xi = 1 on a 5.5 Hz chirp started at frequency state 7 (the estimate slides from 7 to 4.4 through the regime boundaries of the
+headline kernel's speculative step; "exact_lost": the filter starts 1.5 Hz off and is ten times noisier).
+
+    python -m tests.golden.make_exact          (about two minutes)
+"""
+import math
+import os
+import sys
+
+import numpy as np
+from mpmath import mp, mpf, mpc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.dirname(os.path.abspath(__file__))
+mp.dps = 100
+H_STEP = mpf(10) ** -45
+NAN = mpf('nan')
+
+
+# ------------------------------------------------------------------------------------------------ small dense algebra on lists
+def zeros(n, m):
+    return [[mpf(0)] * m for _ in range(n)]
+
+
+def matmul(A, B):
+    return [[sum(A[i][k] * B[k][j] for k in range(len(B))) for j in range(len(B[0]))] for i in range(len(A))]
+
+
+def matvec(A, x):
+    return [sum(A[i][k] * x[k] for k in range(len(x))) for i in range(len(A))]
+
+
+def tr(A):
+    return [list(r) for r in zip(*A)]
+
+
+def madd(A, B, s=1):
+    return [[a + s * b for a, b in zip(ra, rb)] for ra, rb in zip(A, B)]
+
+
+def mscale(A, s):
+    return [[a * s for a in r] for r in A]
+
+
+def vadd(a, b, s=1):
+    return [x + s * y for x, y in zip(a, b)]
+
+
+def outer(a, b):
+    return [[x * y for y in b] for x in a]
+
+
+def chol(P):
+    """lower Cholesky factor; all-NaN where the matrix is not positive definite (JAX semantics)"""
+    n = len(P)
+    L = zeros(n, n)
+    for j in range(n):
+        s = P[j][j] - sum(L[j][k] ** 2 for k in range(j))
+        if not (s > 0):
+            return [[NAN] * n for _ in range(n)]
+        L[j][j] = mp.sqrt(s)
+        for i in range(j + 1, n):
+            L[i][j] = (P[i][j] - sum(L[i][k] * L[j][k] for k in range(j))) / L[j][j]
+    return L
+
+
+def cho_solve(P, R):
+    """P^-1 R through the Cholesky factor (R a matrix)"""
+    n = len(P)
+    L = chol(P)
+    cols = []
+    for c in range(len(R[0])):
+        y = [mpf(0)] * n
+        for i in range(n):
+            y[i] = (R[i][c] - sum(L[i][k] * y[k] for k in range(i))) / L[i][i]
+        x = [mpf(0)] * n
+        for i in reversed(range(n)):
+            x[i] = (y[i] - sum(L[k][i] * x[k] for k in range(i + 1, n))) / L[i][i]
+        cols.append(x)
+    return tr(cols)
+
+
+def blkdiag(*blocks):
+    blocks = [b if isinstance(b, list) else [[b]] for b in blocks]
+    n = sum(len(b) for b in blocks)
+    out = zeros(n, n)
+    k = 0
+    for b in blocks:
+        for i, r in enumerate(b):
+            for j, v in enumerate(r):
+                out[k + i][k + j] = v
+        k += len(b)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the chirp model (models.py)
+def g(x):
+    return mp.log(mp.exp(x) + 1)                                        # models.py:50
+
+
+def m32_solution(ell, sigma, dt):                                        # models.py:61-73
+    gam = mp.sqrt(3) / ell
+    eta = dt * gam
+    beta = sigma ** 2 * mp.exp(-2 * eta)
+    e = mp.exp(-eta)
+    F = [[(1 + eta) * e, dt * e], [-dt * gam ** 2 * e, (1 - eta) * e]]
+    off = 2 * dt ** 2 * gam ** 3 * beta
+    S = [[sigma ** 2 - beta * (2 * eta + 2 * eta ** 2 + 1), off],
+         [off, gam ** 2 * (sigma ** 2 + beta * (2 * eta - 2 * eta ** 2 - 1))]]
+    return F, S
+
+
+def build_chirp_model(params):
+    """models.py:437-459 with 76-119 and 264-311: (drift, b, cond_m_cov, m0, P0, H); params = lam, b, delta, ell, sigma, m0_v (float64 -> exact)"""
+    lam, b, delta, ell, sigma, m0_v = (mpf(float(p)) for p in params)
+    gam = mp.sqrt(3) / ell
+
+    def drift(u):
+        w = 2 * mp.pi * g(u[2])
+        return [-lam * u[0] - w * u[1], w * u[0] - lam * u[1], u[3], -(gam ** 2) * u[2] - 2 * gam * u[3]]
+    disp = blkdiag(b, b, mpf(0), 2 * sigma * (mp.sqrt(3) / ell) ** mpf('1.5'))
+
+    def cond_m_cov(u, dt):
+        w = 2 * mp.pi * g(u[2])
+        c, s, e = mp.cos(dt * w), mp.sin(dt * w), mp.exp(-lam * dt)
+        Fm, Sm = m32_solution(ell, sigma, dt)
+        mean = [e * (c * u[0] - s * u[1]), e * (s * u[0] + c * u[1]), Fm[0][0] * u[2] + Fm[0][1] * u[3], Fm[1][0] * u[2] + Fm[1][1] * u[3]]
+        q = b ** 2 * dt if lam == 0 else b ** 2 / (2 * lam) * (1 - mp.exp(-2 * lam * dt))
+        return mean, blkdiag(q, q, Sm)
+    m0 = [mpf(0), mpf(0), m0_v, mpf(0)]
+    P0 = blkdiag(delta, delta, [[sigma ** 2, mpf(0)], [mpf(0), (mp.sqrt(3) / ell) ** 2 * sigma ** 2]])
+    H = [mpf(0), mpf(1), mpf(0), mpf(0)]
+    return drift, disp, cond_m_cov, m0, P0, H
+
+
+def jacobian(f, x):
+    """jacfwd: the exact derivative -- complex step, error h^2 = 1e-90"""
+    cols = []
+    for j in range(len(x)):
+        xc = [mpc(v) for v in x]
+        xc[j] = mpc(x[j], H_STEP)
+        cols.append([mp.im(v) / H_STEP for v in f(xc)])
+    return tr(cols)
+
+
+# ------------------------------------------------------------------------------------------------ filters_smoothers.py
+def linear_update(mp_, Pp, H, Xi, y):                                   # :55-68
+    PH = matvec(Pp, H)
+    S = sum(h * v for h, v in zip(H, PH)) + Xi
+    K = [v / S for v in PH]
+    pred = sum(h * v for h, v in zip(H, mp_))
+    scale2 = mp.sqrt(S) ** 2
+    nll = (mp.log(2 * mp.pi * scale2) + (y - pred) ** 2 / scale2) / 2      # :44-45
+    return vadd(mp_, [k * (y - pred) for k in K]), madd(Pp, mscale(outer(K, K), S), -1), nll
+
+
+def smoother_common(DT, mf, Pf, mp_, Pp, ms, Ps):                       # :71-85
+    G = tr(cho_solve(Pp, DT))
+    return vadd(mf, matvec(G, vadd(ms, mp_, -1))), madd(Pf, matmul(matmul(G, madd(Ps, Pp, -1)), tr(G)))
+
+
+class GH3:
+    """SigmaPoints.gauss_hermite(4, 3), quadratures.py:156-196: dimension 0 varies fastest"""
+    def __init__(self, d=4):
+        nodes = [mpf(0), mp.sqrt(3), -mp.sqrt(3)]                        # sqrt(2) x the roots of H_3, flipped order of np.roots: (0, +, -) ... any order: a sum
+        w1 = [mpf(2) / 3, mpf(1) / 6, mpf(1) / 6]
+        self.xi, self.w = [], []
+        for n in range(3 ** d):
+            idx = [(n // 3 ** r) % 3 for r in range(d)]
+            self.xi.append([nodes[i] for i in idx])
+            wt = mpf(1)
+            for i in idx:
+                wt *= w1[i]
+            self.w.append(wt)
+
+    def points(self, m, L):
+        return [vadd(m, matvec(L, x)) for x in self.xi]
+
+    def expect_vec(self, vals):
+        return [sum(w * v[i] for w, v in zip(self.w, vals)) for i in range(len(vals[0]))]
+
+    def expect_outer(self, a, b):
+        n, m = len(a[0]), len(b[0])
+        return [[sum(w * x[i] * y[j] for w, x, y in zip(self.w, a, b)) for j in range(m)] for i in range(n)]
+
+
+def sgp_prediction(sg, cond_m_cov, dt, mf, Pf):                         # :88-121
+    chi = sg.points(mf, chol(Pf))
+    ev = [cond_m_cov(c, dt) for c in chi]
+    fm = [e[0] for e in ev]
+    mp_ = sg.expect_vec(fm)
+    Ecov = zeros(4, 4)
+    for w, e in zip(sg.w, ev):
+        Ecov = madd(Ecov, mscale(e[1], w))
+    Pp = madd(madd(sg.expect_outer(fm, fm), Ecov), outer(mp_, mp_), -1)
+    return mp_, Pp, chi, fm
+
+
+def cd_sgp_common(sg, drift, b, m, P):                                  # :124-137
+    chi = sg.points(m, chol(P))
+    fa = [drift(c) for c in chi]
+    mp_ = sg.expect_vec(fa)
+    _Pp = sg.expect_outer([vadd(c, m, -1) for c in chi], fa)
+    return mp_, madd(madd(_Pp, tr(_Pp)), matmul(b, tr(b)))
+
+
+def rk4(ode, m, P, dt, *fixed):                                         # quadratures.py:34-81
+    k1m, k1P = ode(m, P, *fixed)
+    k2m, k2P = ode(vadd(m, k1m, dt / 2), madd(P, k1P, dt / 2), *fixed)
+    k3m, k3P = ode(vadd(m, k2m, dt / 2), madd(P, k2P, dt / 2), *fixed)
+    k4m, k4P = ode(vadd(m, k3m, dt), madd(P, k3P, dt), *fixed)
+    km = [a + 2 * b_ + 2 * c + d for a, b_, c, d in zip(k1m, k2m, k3m, k4m)]
+    kP = madd(madd(madd(k1P, k2P, 2), k3P, 2), k4P)
+    return vadd(m, km, dt / 6), madd(P, kP, dt / 6)
+
+
+def run_filter(step, m0, P0, ys):
+    mf, Pf, nll = m0, P0, mpf(0)
+    out = []
+    for y in ys:
+        mf, Pf, inc = step(mf, Pf, y)
+        nll += inc
+        out.append((mf, Pf, nll))
+    return out
+
+
+def run_smoother(step, filt):
+    ms, Ps = filt[-1][0], filt[-1][1]
+    out = [(ms, Ps)]
+    for mf, Pf, _ in reversed(filt[:-1]):
+        ms, Ps = step(ms, Ps, mf, Pf)
+        out.append((ms, Ps))
+    return out[::-1]
+
+
+def pipelines(params, Xi, dt, ys, cd_T):
+    drift, b, cond, m0, P0, H = build_chirp_model(params)
+    Xi, dt = mpf(float(Xi)), mpf(float(dt))
+    ys = [mpf(float(y)) for y in ys]
+    sg = GH3()
+    gamma = matmul(b, tr(b))
+    res = {}
+
+    def ekf_step(mf, Pf, y):                                            # :222-264
+        J = jacobian(lambda u: cond(u, dt)[0], mf)
+        mp_, Sig = cond(mf, dt)
+        return linear_update(mp_, madd(matmul(matmul(J, Pf), tr(J)), Sig), H, Xi, y)
+
+    def eks_step(ms, Ps, mf, Pf):                                       # :317-349
+        J = jacobian(lambda u: cond(u, dt)[0], mf)
+        mp_, Sig = cond(mf, dt)
+        return smoother_common(matmul(J, Pf), mf, Pf, mp_, madd(matmul(matmul(J, Pf), tr(J)), Sig), ms, Ps)
+    f = run_filter(ekf_step, m0, P0, ys)
+    res['ekf'], res['eks'] = f, run_smoother(eks_step, f)
+    print('  ekf + eks done', flush=True)
+
+    def sgpf_step(mf, Pf, y):                                           # :446-490
+        mp_, Pp, _, _ = sgp_prediction(sg, cond, dt, mf, Pf)
+        return linear_update(mp_, Pp, H, Xi, y)
+
+    def sgps_step(ms, Ps, mf, Pf):                                      # :493-531
+        mp_, Pp, chi, fm = sgp_prediction(sg, cond, dt, mf, Pf)
+        D = madd(sg.expect_outer(chi, fm), outer(mf, mp_), -1)
+        return smoother_common(tr(D), mf, Pf, mp_, Pp, ms, Ps)
+    f = run_filter(sgpf_step, m0, P0, ys)
+    res['sgp_filter'], res['sgp_smoother'] = f, run_smoother(sgps_step, f)
+    print('  sgp_filter + sgp_smoother done', flush=True)
+
+    def cdf_step(mf, Pf, y):                                            # :534-582
+        mp_, Pp = rk4(lambda m, P: cd_sgp_common(sg, drift, b, m, P), mf, Pf, dt)
+        return linear_update(mp_, Pp, H, Xi, y)
+
+    def cds_ode(m, P, mf, Pf):                                          # :585-632
+        G = cho_solve(Pf, gamma)
+        _m, _P = cd_sgp_common(sg, drift, b, m, P)
+        return vadd(_m, matvec(tr(G), vadd(m, mf, -1))), madd(madd(madd(_P, matmul(tr(G), P)), matmul(P, G)), mscale(gamma, 2), -1)
+
+    def cds_step(ms, Ps, mf, Pf):
+        return rk4(cds_ode, ms, Ps, -dt, mf, Pf)
+    f = run_filter(cdf_step, m0, P0, ys[:cd_T])
+    res['cd_sgp_filter'], res['cd_sgp_smoother'] = f, run_smoother(cds_step, f)
+    print('  cd_sgp_filter + cd_sgp_smoother done', flush=True)
+    return res
+
+
+def to_f64(res):
+    flat = {}
+    for name, rows in res.items():
+        flat[name + '.0'] = np.array([[float(v) for v in r[0]] for r in rows])
+        flat[name + '.1'] = np.array([[[float(v) for v in row] for row in r[1]] for r in rows])
+        if len(rows[0]) == 3:
+            flat[name + '.2'] = np.array([float(r[2]) for r in rows])
+    return flat
+
+
+def records():
+    """(name, params, Xi, dt, ys): float64 inputs, drawn with NumPy only"""
+    sys.path.insert(0, ROOT)
+    import bench
+    T, dt = 500, 1e-3
+    track = bench.chirp_batch(1, T, 4242, dt=dt, Xi=0.1)[0]
+    lost = bench.chirp_batch(1, T, 4243, dt=dt, Xi=1.0, offset=5.5)[0]
+    p = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
+    return (('exact_track', p, 0.1, dt, track), ('exact_lost', p, 1.0, dt, lost))
+
+
+def main():
+    for name, p, Xi, dt, ys in records():
+        print(name, flush=True)
+        res = pipelines(p, Xi, dt, ys, cd_T=300)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), ys=ys, params=p, Xi=Xi, dt=dt, digits=mp.dps, **to_f64(res))
+
+
+if __name__ == '__main__':
+    main()

@@ -36,6 +36,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(eng.CgpModel) == 48
     assert ctypes.sizeof(eng.CgpSigma) == 40
     assert ctypes.sizeof(eng.CgpInit) == 64
+    assert ctypes.sizeof(eng.CgpSmoothOut) == 72
 
 
 def test_null_context_is_rejected_without_gpu():
