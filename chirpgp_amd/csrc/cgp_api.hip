@@ -134,8 +134,11 @@ __global__ void __launch_bounds__(256) squared_error_sums_kernel(const double* _
 
 // cgp_smoother_select behind a kernel that writes full rows only: the selected marginal read back out of mss / Pss
 __global__ void __launch_bounds__(256) smooth_select_kernel(const double* __restrict__ mss, const double* __restrict__ Pss, int64_t n, int d, SmoothSel sel) {
+    __shared__ double ghrule[2 * kGhMaxOrder];
+    sel_stage_rule(sel, ghrule, threadIdx.x);
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        sel_write(sel, i, mss[i * d + sel.comp], Pss[i * d * d + sel.comp * (d + 1)]);
+        sel_write(sel, ghrule, i, mss[i * d + sel.comp], Pss[i * d * d + sel.comp * (d + 1)]);
 }
 
 __global__ void __launch_bounds__(256) debug_math_kernel(int op, const double* __restrict__ x, int64_t n,
@@ -486,8 +489,8 @@ static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const
     if (!want_sel && (!mss || !Pss)) return fail(ctx, CGP_E_ARG, "mfs / Pfs / mss / Pss must be set");
     if (want_sel) {
         if (!model || out->comp < 0 || out->comp >= model->d) return fail(ctx, CGP_E_ARG, "cgp_smooth_out.comp outside 0..d-1");
-        if (out->expect && (out->func < CGP_FN_SOFTPLUS || out->func > CGP_FN_SQUARE || out->order < 1 || !out->xi || !out->w))
-            return fail(ctx, CGP_E_ARG, "cgp_smooth_out.expect needs func, order >= 1, xi and w");
+        if (out->expect && (out->func < CGP_FN_SOFTPLUS || out->func > CGP_FN_SQUARE || out->order < 1 || out->order > kGhMaxOrder || !out->xi || !out->w))
+            return fail(ctx, CGP_E_ARG, "cgp_smooth_out.expect needs func, 1 <= order <= 32, xi and w");
     }
     if (method < CGP_S_EKS || method > CGP_S_CD_SGP) return fail(ctx, CGP_E_ARG, "unknown smoother method");
     const bool sde = method == CGP_S_CD_EKS || method == CGP_S_CD_SGP;

@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     __shared__ double elems[16 * kElemDoubles];      // (G, Pp, mp) of a quarter tile: 13.9 KB
     __shared__ double rows[64 * kRowDoubles];        // (Pf, mf) of the whole tile: 23.0 KB -- together 36.9 KB: four workgroups a CU
     __shared__ double selbuf[SEL ? 128 : 1];
+    __shared__ double ghrule[SEL ? 2 * kGhMaxOrder : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -539,6 +540,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     elem.setup(ma, trial);
     for (int k = lane; k < 16 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / Pp / Pf and the zero slots stay zero
     for (int k = lane; k < 64 * kRowDoubles; k += 64) rows[k] = 0.0;
+    if constexpr (SEL) sel_stage_rule(io.sel, ghrule, lane);
     if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
     double xc = (4 * J + r < D) ? mfs[(T - 1) * D + 4 * J + r] : 0.0;
     if (entry && (!SEL || io.Pss)) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
     if (mean_lane && (!SEL || io.mss)) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
-    if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
+    if constexpr (SEL) { if (lane == 0) sel_write(io.sel, ghrule, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
     const bool sel_var_lane = SEL && entry && i == io.sel.comp && j == io.sel.comp, sel_mean_lane = SEL && mean_lane && i == io.sel.comp;
 
     for (int64_t hi = T - 2; hi >= 0; hi -= 64) {
@@ -638,7 +640,7 @@ __global__ void __launch_bounds__(64) coop8_smoother_kernel(SmootherIO io, Model
             wave_lds_fence();
         }
         if constexpr (SEL) {
-            if (mystep >= 0) sel_write(io.sel, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
+            if (mystep >= 0) sel_write(io.sel, ghrule, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
             wave_lds_fence();
         }
     }
@@ -654,6 +656,7 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
     static_assert(!(SEL && MODE == kWalkCompose), "pass 1 of the time-split form writes nothing");
     __shared__ double elems[32 * kElemDoubles];
     __shared__ double selbuf[SEL ? 128 : 1];
+    __shared__ double ghrule[SEL ? 2 * kGhMaxOrder : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int I = b >> 1, J = b & 1;
@@ -665,6 +668,7 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
     Elem elem;
     elem.setup(ma, trial);
     for (int k = lane; k < 32 * kElemDoubles; k += 64) elems[k] = 0.0;      // pads of G / C and the zero slot stay zero
+    if constexpr (SEL) sel_stage_rule(io.sel, ghrule, lane);
     if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, D); else __syncthreads();
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
@@ -699,7 +703,7 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
     if (MODE != kWalkCompose && seg == 0) {
         if (entry && (!SEL || io.Pss)) Pss[(T - 1) * D * D + i * D + j] = Pfs[(T - 1) * D * D + i * D + j];
         if (mean_lane && (!SEL || io.mss)) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i];
-        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
+        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, ghrule, trial * T + T - 1, mfs[(T - 1) * D + io.sel.comp], Pfs[(T - 1) * D * D + io.sel.comp * (D + 1)]); }
     }
     const bool sel_var_lane = SEL && entry && i == io.sel.comp && j == io.sel.comp, sel_mean_lane = SEL && mean_lane && i == io.sel.comp;
     // one step of the recursion with the operands o: W = Ps' G^T, Ps = G W + C, ms = G ms' + c
@@ -778,7 +782,7 @@ __global__ void __launch_bounds__(64) coop8_split_kernel(SmootherIO io, ModelArg
             wave_lds_fence();
         }
         if constexpr (SEL) {
-            if (mystep >= 0) sel_write(io.sel, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
+            if (mystep >= 0) sel_write(io.sel, ghrule, trial * T + mystep, selbuf[lane], selbuf[64 + lane]);
             wave_lds_fence();
         }
     }

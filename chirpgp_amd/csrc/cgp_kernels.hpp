@@ -82,8 +82,59 @@ struct SmoothSel {
     const double* __restrict__ xi = nullptr;   // [order] nodes, the reference's scaling (sqrt(2) x the Hermite roots)
     const double* __restrict__ w = nullptr;    // [order] weights, normalised
 };
-// E[f(m + s Z)] over the rule's nodes: the loop of quadratures.py:218-231 for d = 1, the same operations as cgp_gaussian_expectation_fn.
+// E[f(m + s Z)] over the rule's nodes: the loop of quadratures.py:218-231 for d = 1.  The softplus integrand (the reference's g,
+// models.py:50: the one every driver uses) in three tiers, chosen per LANE so that an element's value does not depend on its neighbours
+// in the wavefront (a tier is evaluated by the wavefront only if one of its lanes needs it):
+//   1. every node x >= 6 (a frequency above 6 Hz with its whole Gauss-Hermite fan):  log(e^x + 1) = x + log1p(t), t = e^-x <= 2.5e-3, the
+//      exponential by the degree-7 near-minimax polynomial of the speculative EKF step (5.5e-11 of t, i.e. 2e-14 of the softplus) and
+//      log1p by six terms of its series (truncation t^7 / 7 < 1e-19): ~25 instructions a node;
+//   2. any |x| < 700: the branch-free full-accuracy softplus of cgp_fastmath.hpp (softplus_pair_any), ~80 a node;
+//   3. otherwise (overflow, inf, NaN) and for the other integrands: the library functions, as cgp_gaussian_expectation_fn evaluates them.
+CGP_DEV double exp_neg_lean_lit(double x) {
+    const double nx = -x;
+    const double k = __builtin_rint(nx * kLog2e);
+    double r = fma(-k, kLn2Hi, nx);
+    r = fma(-k, kLn2Lo, r);
+    const double r2 = r * r;
+    const double a0 = fma(kExpLean[1], r, kExpLean[0]), a1 = fma(kExpLean[3], r, kExpLean[2]);
+    const double a2 = fma(kExpLean[5], r, kExpLean[4]), a3 = fma(kExpLean[7], r, kExpLean[6]);
+    const double r4 = r2 * r2;
+    return __builtin_amdgcn_ldexp(fma(fma(a3, r2, a2), r4, fma(a1, r2, a0)), (int)k);
+}
 CGP_DEV double gh_expectation(int func, double m, double s, const double* __restrict__ xi, const double* __restrict__ w, int order) {
+    double fast = 0.0;
+    bool have = false;
+    if (func == CGP_FN_SOFTPLUS) {
+        // the fan's extreme nodes decide the lane's tier before anything is evaluated (NaN: neither)
+        double reach = 0.0;
+        for (int p = 0; p < order; p++) reach = fmax(reach, fabs(xi[p]));
+        reach *= fabs(s);
+        const bool tier1 = (m - reach >= 6.0) && (m + reach < 700.0);
+        const bool tier2 = !tier1 && (m - reach > -700.0) && (m + reach < 700.0);
+        if (__builtin_amdgcn_ballot_w64(tier1) != 0) {
+            double acc = 0.0;
+            for (int p = 0; p < order; p++) {
+                const double x = fma(s, xi[p], m);
+                const double t = exp_neg_lean_lit(x);
+                double q = fma(t, -1.0 / 6.0, 1.0 / 5.0);                      // log1p(t) / t = 1 - t/2 + t^2/3 - t^3/4 + t^4/5 - t^5/6
+                q = fma(q, t, -1.0 / 4.0); q = fma(q, t, 1.0 / 3.0); q = fma(q, t, -0.5); q = fma(q, t, 1.0);
+                acc = fma(w[p], fma(q, t, x), acc);
+            }
+            fast = acc;
+        }
+        if (__builtin_amdgcn_ballot_w64(tier2) != 0) {
+            double acc = 0.0;
+            for (int p = 0; p < order; p++) {
+                const double x = fma(s, xi[p], m);
+                double sp, dsp; bool okp;
+                softplus_pair_any(x, sp, dsp, okp);
+                acc = fma(w[p], sp, acc);
+            }
+            fast = tier2 ? acc : fast;
+        }
+        have = tier1 || tier2;
+        if (__builtin_amdgcn_ballot_w64(!have) == 0) return fast;
+    }
     double acc = 0.0;
     for (int p = 0; p < order; p++) {
         const double x = fma(s, xi[p], m);
@@ -94,13 +145,26 @@ CGP_DEV double gh_expectation(int func, double m, double s, const double* __rest
         else f = x;
         acc = fma(w[p], f, acc);
     }
-    return acc;
+    return have ? fast : acc;
+}
+// The same as a CALL: the epilogue of the wave-per-trial smoothers runs once per tile, outside their walks -- a call keeps its three
+// loops out of kernels that are scheduled around matrix instructions (inlined, hipcc 7.2's "Rewrite AGPR-Copy-MFMA" pass crashed on
+// coop8_split_kernel<SgpsElement<LinearDisc<8>>, kWalkApply, true> under -amdgpu-mfma-vgpr-form).
+__device__ __attribute__((noinline)) double gh_expectation_call(int func, double m, double s, const double* __restrict__ xi, const double* __restrict__ w, int order) {
+    return gh_expectation(func, m, s, xi, w, order);
+}
+// The rule's nodes and weights staged in LDS once per workgroup (rule[0 .. order) nodes, rule[32 .. 32 + order) weights; order <= 32,
+// checked by the C-ABI): read from global memory inside the node loop, every iteration waited for two dependent loads -- the epilogue of
+// the lane kernel cost 11 ms per 262 144 x 500 instead of 3.  The caller fences (wave_lds_fence / __syncthreads) before the first use.
+constexpr int kGhMaxOrder = 32;
+CGP_DEV void sel_stage_rule(const SmoothSel& s, double* rule, int tid) {
+    if (s.expect && tid < s.order) { rule[tid] = s.xi[tid]; rule[kGhMaxOrder + tid] = s.w[tid]; }
 }
 // one (trial, step) of the selected outputs; idx = trial * T + step
-CGP_DEV void sel_write(const SmoothSel& s, int64_t idx, double m, double v) {
+CGP_DEV void sel_write(const SmoothSel& s, const double* rule, int64_t idx, double m, double v) {
     if (s.mean) s.mean[idx] = m;
     if (s.var) s.var[idx] = v;
-    if (s.expect) s.expect[idx] = gh_expectation(s.func, m, sqrt(v), s.xi, s.w, s.order);
+    if (s.expect) s.expect[idx] = gh_expectation_call(s.func, m, sqrt(v), rule, rule + kGhMaxOrder, s.order);
 }
 
 struct SmootherIO {

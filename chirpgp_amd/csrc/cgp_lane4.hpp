@@ -352,15 +352,20 @@ CGP_DEV unsigned lane4_row_piece(int lane, int p) {
 // are wanted, `nsel` of them -- in LDS, [16 steps][64 trials + 1]; every 16 steps (one 128-byte line of a [B][T] array per trial: trials
 // of equal line phase share a wavefront, period = 16 / gcd(T, 16)) the wavefront writes them as whole lines, eight 16-byte-per-lane
 // store instructions per output.  The full outputs are optional then (mss / Pss NULL: 8 - 24 bytes a step leave instead of 160).
-struct Lane4Sel { static constexpr int PITCH = 65, DOUBLES = 16 * 65; };
-template <class Step, bool SEL = false>
+// SELN = steps per flush: 16 (whole lines) for ONE selected output; 8 (aligned half lines, written 8 steps apart by the same wavefront) for
+// two or three -- their 16-step buffers would take the workgroup past 40 KB of LDS, three workgroups a CU instead of four.
+template <int SELN> struct Lane4Sel { static constexpr int PITCH = 65, DOUBLES = SELN * 65, LPT = SELN / 2, TPI = 64 / LPT; };
+template <class Step, int SELN = 0>
 __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, ModelArgs ma, int period) {
+    constexpr bool SEL = SELN > 0;
+    using LS = Lane4Sel<SEL ? SELN : 16>;
     static_assert(Step::D == 4 && !Step::WAVE && !Step::USES_SIGMA, "one lane per trial, d = 4, no sigma-point set");
     constexpr int D = 4;
     __shared__ __attribute__((aligned(16))) double pin[2 * Lane4S::ROWS];
     __shared__ __attribute__((aligned(16))) double min_[Lane4S::ROWS];
     __shared__ __attribute__((aligned(16))) double tile[Lane4::TILE];
     __shared__ double lds[Step::USES_LDS ? kFanLdsDoubles : 1];
+    __shared__ double ghrule[SEL ? 2 * kGhMaxOrder : 1];
     const int lane = threadIdx.x;
     const int64_t group = (int64_t)(blockIdx.x / (unsigned)period);
     const int64_t block_first = group * 64 * period + (int64_t)(blockIdx.x % (unsigned)period);
@@ -369,6 +374,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
     const int nvalid = nv < 64 ? (int)nv : 64;
     const bool valid = lane < nvalid;
     const int64_t trial = block_first + (int64_t)period * (valid ? lane : nvalid - 1);
+    if constexpr (SEL) { sel_stage_rule(io.sel, ghrule, lane); wave_lds_fence(); }
 
     Step step;
     step.setup(ma, trial);
@@ -382,8 +388,8 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
     const int comp = SEL ? io.sel.comp : 0;
     const bool sel_m = SEL && io.sel.mean, sel_v = SEL && io.sel.var, sel_e = SEL && io.sel.expect;
     double* const selM = SEL ? dyn_lds() : nullptr;
-    double* const selV = selM + (sel_m ? Lane4Sel::DOUBLES : 0);
-    double* const selE = selV + (sel_v ? Lane4Sel::DOUBLES : 0);
+    double* const selV = selM + (sel_m ? LS::DOUBLES : 0);
+    double* const selE = selV + (sel_v ? LS::DOUBLES : 0);
     auto pick_mean = [&](const Vec<D>& m) { return comp == 0 ? m.v[0] : comp == 1 ? m.v[1] : comp == 2 ? m.v[2] : m.v[3]; };
     auto pick_var = [&](const Sym<D>& P) { return comp == 0 ? P.a[0] : comp == 1 ? P.a[2] : comp == 2 ? P.a[5] : P.a[9]; };      // the diagonal of the packed lower triangle
 
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
     if (valid) {
         if (want_m) { CGP_UNROLL for (int i = 0; i < D; i++) mss[(T - 1) * D + i] = mfs[(T - 1) * D + i]; }
         if (want_P) { CGP_UNROLL for (int i = 0; i < D * D; i++) Pss[(T - 1) * D * D + i] = Pfs[(T - 1) * D * D + i]; }
-        if constexpr (SEL) sel_write(io.sel, trial * T + T - 1, pick_mean(ms), pick_var(Ps));
+        if constexpr (SEL) sel_write(io.sel, ghrule, trial * T + T - 1, pick_mean(ms), pick_var(Ps));
     }
     // one row outside the whole quads: inputs and outputs straight from / to this lane's rows (a handful per record)
     auto edge = [&](int64_t t) __attribute__((always_inline)) {
@@ -405,13 +411,14 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
         if (valid) {
             if (want_m) store_vec<D>(mss + t * D, ms);
             if (want_P) store_sym_full<D>(Pss + t * D * D, Ps);
-            if constexpr (SEL) sel_write(io.sel, trial * T + t, pick_mean(ms), pick_var(Ps));
+            if constexpr (SEL) sel_write(io.sel, ghrule, trial * T + t, pick_mean(ms), pick_var(Ps));
         }
     };
     // rows [a_lo, a_lo + 4 nq) are whole lines of four means for every trial of this wavefront (wave-uniform: period * T is a multiple of 4);
     // SEL: whole lines of SIXTEEN doubles of a [B][T] array (period * T a multiple of 16), and a whole number of them
-    const int a_lo = SEL ? (int)((16 - ((block_first * T) & 15)) & 15) : (int)((4 - ((block_first * T) & 3)) & 3);
-    const int64_t nq = (T - 1 > a_lo) ? ((T - 1 - a_lo) / 4) & (SEL ? ~(int64_t)3 : ~(int64_t)0) : 0;
+    constexpr int kLine = SEL ? SELN : 4;                                // steps per aligned block: a line of means, or SELN selected values
+    const int a_lo = (int)((kLine - ((block_first * T) & (kLine - 1))) & (kLine - 1));
+    const int64_t nq = (T - 1 > a_lo) ? ((T - 1 - a_lo) / 4) & ~(int64_t)(kLine / 4 - 1) : 0;
     for (int64_t t = T - 2; t >= (nq > 0 ? a_lo + 4 * nq : 0); t--) edge(t);     // (no whole quad: every row goes this way)
     if (nq > 0) {
         // output windows over this wavefront's trials, per-lane offsets of (trial 8 i + sub, piece pc), as in the filter
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
             wSe.init(sel_e ? io.sel.expect + block_first * T : nullptr, span * T * 8);
         }
         const unsigned rowS = (unsigned)(T * period) * 8u;
-        const int nflush = SEL ? 8 * ((sel_m ? 1 : 0) + (sel_v ? 1 : 0) + (sel_e ? 1 : 0)) : 0;      // store instructions of one flush
+        const int nflush = SEL ? LS::LPT * ((sel_m ? 1 : 0) + (sel_v ? 1 : 0) + (sel_e ? 1 : 0)) : 0;      // store instructions of one flush
         int pending = 0;                                                 // ... issued since the last DMA request (SEL without full outputs)
         const int sub = lane >> 3, pc = lane & 7;
         const unsigned rowP = (unsigned)(T * period) * 128u, rowM = (unsigned)(T * period) * 32u;
@@ -465,9 +472,12 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                 if constexpr (SEL) {
                     // counted only where nothing but a flush was stored since the request (the selected outputs alone: the fast case)
                     if (first || want_P || want_m || pending == 0) lane4_wait_vm<0>();
+                    else if (pending == 4) lane4_wait_vm<4>();
                     else if (pending == 8) lane4_wait_vm<8>();
+                    else if (pending == 12) lane4_wait_vm<12>();
                     else if (pending == 16) lane4_wait_vm<16>();
-                    else lane4_wait_vm<24>();
+                    else if (pending == 24) lane4_wait_vm<24>();
+                    else lane4_wait_vm<0>();
                     pending = 0;
                 } else {
                     if (first) lane4_wait_vm<0>();
@@ -495,20 +505,21 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                 }
                 step.step(lane, lds, mf, Pf, ms, Ps);
                 if constexpr (SEL) {
-                    const int slot = (int)((t - a_lo) & 15);
+                    const int slot = (int)((t - a_lo) & (SELN - 1));
                     const double m_k = pick_mean(ms), v_k = pick_var(Ps);
-                    if (sel_m) selM[slot * Lane4Sel::PITCH + lane] = m_k;
-                    if (sel_v) selV[slot * Lane4Sel::PITCH + lane] = v_k;
-                    if (sel_e) selE[slot * Lane4Sel::PITCH + lane] = gh_expectation(io.sel.func, m_k, sqrt(v_k), io.sel.xi, io.sel.w, io.sel.order);
+                    if (sel_m) selM[slot * LS::PITCH + lane] = m_k;
+                    if (sel_v) selV[slot * LS::PITCH + lane] = v_k;
+                    if (sel_e) selE[slot * LS::PITCH + lane] = gh_expectation(io.sel.func, m_k, sqrt(v_k), ghrule, ghrule + kGhMaxOrder, io.sel.order);
                     if (slot == 0) {
-                        // sixteen steps of 64 trials: lane (sub, pc) writes the steps 2 pc, 2 pc + 1 of the trials 8 i + sub -- whole 128-byte lines
+                        // SELN steps of 64 trials: lane (tsub, piece) writes the steps 2 piece, 2 piece + 1 of the trials TPI i + tsub
                         wave_lds_fence();
-                        const unsigned off0 = (unsigned)sub * rowS + (unsigned)t * 8u + (unsigned)pc * 16u;
-                        const int at = (2 * pc) * Lane4Sel::PITCH + sub;
-                        CGP_UNROLL for (int i = 0; i < 8; i++) {
-                            if (sel_m) wSm.store2(selM[at + 8 * i], selM[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
-                            if (sel_v) wSv.store2(selV[at + 8 * i], selV[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
-                            if (sel_e) wSe.store2(selE[at + 8 * i], selE[at + Lane4Sel::PITCH + 8 * i], off0 + (unsigned)i * 8u * rowS);
+                        const int tsub = lane / LS::LPT, piece = lane % LS::LPT;
+                        const unsigned off0 = (unsigned)tsub * rowS + (unsigned)t * 8u + (unsigned)piece * 16u;
+                        const int at = (2 * piece) * LS::PITCH + tsub;
+                        CGP_UNROLL for (int i = 0; i < LS::LPT; i++) {
+                            if (sel_m) wSm.store2(selM[at + LS::TPI * i], selM[at + LS::PITCH + LS::TPI * i], off0 + (unsigned)(i * LS::TPI) * rowS);
+                            if (sel_v) wSv.store2(selV[at + LS::TPI * i], selV[at + LS::PITCH + LS::TPI * i], off0 + (unsigned)(i * LS::TPI) * rowS);
+                            if (sel_e) wSe.store2(selE[at + LS::TPI * i], selE[at + LS::PITCH + LS::TPI * i], off0 + (unsigned)(i * LS::TPI) * rowS);
                         }
                         wave_lds_fence();
                         pending = nflush;
@@ -562,11 +573,16 @@ template <class Step>
 inline hipError_t launch_lane4_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
     if (io.sel.comp >= 0) {
-        // selected outputs: trials grouped by the phase of their [B][T] rows against the 128-byte lines (the filter's period)
-        const int period = lane4_period(io.T);
-        const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+        // selected outputs: trials grouped by the phase of their [B][T] rows against the flushed blocks (16 or 8 doubles)
         const int nsel = (io.sel.mean ? 1 : 0) + (io.sel.var ? 1 : 0) + (io.sel.expect ? 1 : 0);
-        hipLaunchKernelGGL((lane4_smoother_kernel<Step, true>), dim3((unsigned)(groups * period)), dim3(64), sizeof(double) * Lane4Sel::DOUBLES * nsel, stream, io, ma, period);
+        const int seln = nsel == 1 ? 16 : 8;
+        int period = 1;
+        while ((period * io.T) % seln != 0) period *= 2;
+        if (io.T * period * 128 * 64 > kOobMaxBytes) period = 1;
+        const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+        const size_t dyn = sizeof(double) * 65 * seln * nsel;
+        if (seln == 16) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 16>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
+        else hipLaunchKernelGGL((lane4_smoother_kernel<Step, 8>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
         return hipGetLastError();
     }
     const int period = lane4_smoother_period(io.T);

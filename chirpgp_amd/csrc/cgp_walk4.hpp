@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     static_assert(!(SEL && MODE == kWalkCompose), "pass 1 of the time-split form writes nothing");
     __shared__ double recs[64 * kWalkRec];
     __shared__ double selbuf[SEL ? 128 : 1];
+    __shared__ double ghrule[SEL ? 2 * kGhMaxOrder : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
     const int64_t trial = (MODE == kWalkWhole) ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / (unsigned)io.segs);
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
 
     Elem elem;
     elem.setup(ma, trial);
+    if constexpr (SEL) { sel_stage_rule(io.sel, ghrule, lane); wave_lds_fence(); }
     if constexpr (Elem::USES_SIGMA) elem.sg.stage(dyn_lds(), lane, 64, 4);
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * 4;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
     if (MODE != kWalkCompose && seg == 0) {
         if (lane < 16 && (!SEL || io.Pss)) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];
         if (lane < 4 && (!SEL || io.mss)) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
-        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, trial * T + T - 1, mfs[(T - 1) * 4 + io.sel.comp], Pfs[(T - 1) * 16 + io.sel.comp * 5]); }
+        if constexpr (SEL) { if (lane == 0) sel_write(io.sel, ghrule, trial * T + T - 1, mfs[(T - 1) * 4 + io.sel.comp], Pfs[(T - 1) * 16 + io.sel.comp * 5]); }
     }
     const bool sel_var_lane = SEL && r == io.sel.comp && q == io.sel.comp, sel_mean_lane = SEL && r == io.sel.comp && q == 0;
     if constexpr (MODE == kWalkApply) {
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             wave_lds_fence();
             walk(base);
             wave_lds_fence();
-            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
+            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, ghrule, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) elem.map(mf, Pf, G, c, C);
             write_record(base - 64 + lane >= 0, G, c, C);
             wave_lds_fence();
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(64) walk4_smoother_kernel(SmootherIO io, Model
             wave_lds_fence();
             walk(base);
             wave_lds_fence();
-            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
+            if constexpr (SEL) { if (base + lane >= 0) sel_write(io.sel, ghrule, trial * T + base + lane, selbuf[lane], selbuf[64 + lane]); }
         }
     }
     if constexpr (MODE == kWalkCompose) {

@@ -49,35 +49,38 @@ def _family_setup(method, family, num_harmonics, dt, init):
     return build, (init_default if init is None else init), build_kw
 
 
-def _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, ys):
-    """Filter + smoother + E[g(V)] at given model parameters; `params` and `ys` may both carry a leading record axis."""
+def _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, ys, keep_rows=True):
+    """Filter + smoother + E[g(V)] at given model parameters; `params` and `ys` may both carry a leading record axis.
+    The estimate E[g(V)] of the frequency marginal (demos/ekfs_mle.py:69-77: gaussian_expectation on mss[:, 2], sqrt(Pss[:, 2, 2])) is
+    written by the smoother launch itself (`select`: include/chirpgp_hip.h, cgp_smoother_select); with ``keep_rows=False`` the full
+    smoothing rows are not written at all (None in their place) -- what a caller that only wants the RMSE needs."""
     if method == 'kpt':      # tetralith/jobs/kpt_mle.py:54-76: ekf_for_kpt, then the LINEAR smoother; frequency = g(x_0) fs / 2 pi
         F, Sigma, m0, P0, h = build(params, **build_kw)
         mfs, Pfs, _ = fs.ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys)
-        mss, Pss = fs.rts(F, Sigma, mfs, Pfs)
-        scale = 1. / dt / 2 / math.pi
-        ms, sd = mss[..., 0] * scale, np.sqrt(Pss[..., 0, 0]) * scale
-    else:
-        drift, dispersion, m_and_cov, m0, P0, H = build(params, **build_kw)
-        if method == 'ekfs':
-            mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
-            mss, Pss = fs.eks(m_and_cov, mfs, Pfs, dt)
-        elif method == 'ghfs':
-            mfs, Pfs, _ = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
-            mss, Pss = fs.sgp_smoother(m_and_cov, sgps, mfs, Pfs, dt)
-        elif method == 'cd_ekfs':
-            mfs, Pfs, _ = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
-            mss, Pss = fs.cd_eks(drift, dispersion, mfs, Pfs, dt)
-        else:   # the reference passes the dispersion MATRIX: dispersion(jnp.eye(4)) (demos/cd_ghfs_mle.py:48)
-            mfs, Pfs, _ = fs.cd_sgp_filter(drift, dispersion(None), sgps, H, Xi, m0, P0, dt, ys)
-            mss, Pss = fs.cd_sgp_smoother(drift, dispersion(None), sgps, mfs, Pfs, dt)
-        # the frequency state is the last-but-one component (index 2 of the chirp model, -2 of the harmonic one)
-        ms, sd = mss[..., -2], np.sqrt(Pss[..., -2, -2])
-    est = gaussian_expectation(ms=ms.reshape(-1), chol_Ps=sd.reshape(-1), func=g, force_shape=True)[:, 0].reshape(ms.shape)
-    return mss, Pss, est
+        mss, Pss, sel = fs.rts(F, Sigma, mfs, Pfs, want=(keep_rows, keep_rows), select=dict(comp=0, mean=True, var=True))
+        scale = 1. / dt / 2 / math.pi          # (the marginal is rescaled before the expectation: that one stays on the host)
+        ms, sd = sel['mean'] * scale, np.sqrt(sel['var']) * scale
+        est = gaussian_expectation(ms=ms.reshape(-1), chol_Ps=sd.reshape(-1), func=g, force_shape=True)[:, 0].reshape(ms.shape)
+        return mss, Pss, est
+    drift, dispersion, m_and_cov, m0, P0, H = build(params, **build_kw)
+    # the frequency state is the last-but-one component (index 2 of the chirp model, -2 of the harmonic one)
+    kw = dict(want=(keep_rows, keep_rows), select=dict(comp=-2, expect='softplus'))
+    if method == 'ekfs':
+        mfs, Pfs, _ = fs.ekf(m_and_cov, H, Xi, m0, P0, dt, ys)
+        mss, Pss, sel = fs.eks(m_and_cov, mfs, Pfs, dt, **kw)
+    elif method == 'ghfs':
+        mfs, Pfs, _ = fs.sgp_filter(m_and_cov, sgps, H, Xi, m0, P0, dt, ys)
+        mss, Pss, sel = fs.sgp_smoother(m_and_cov, sgps, mfs, Pfs, dt, **kw)
+    elif method == 'cd_ekfs':
+        mfs, Pfs, _ = fs.cd_ekf(drift, dispersion, H, Xi, m0, P0, dt, ys)
+        mss, Pss, sel = fs.cd_eks(drift, dispersion, mfs, Pfs, dt, **kw)
+    else:   # the reference passes the dispersion MATRIX: dispersion(jnp.eye(4)) (demos/cd_ghfs_mle.py:48)
+        mfs, Pfs, _ = fs.cd_sgp_filter(drift, dispersion(None), sgps, H, Xi, m0, P0, dt, ys)
+        mss, Pss, sel = fs.cd_sgp_smoother(drift, dispersion(None), sgps, mfs, Pfs, dt, **kw)
+    return mss, Pss, sel['expect']
 
 
-def run_records(method, yss, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
+def run_records(method, yss, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None, keep_rows=True):
     """The pipeline for R records in LOCK STEP: one maximum-likelihood fit for all of them (chirpgp_amd.mle.fit_many: every
     line-search probe of every record in one kernel launch), then ONE batched filter and ONE batched smoother launch with a
     parameter vector per record -- R records for about the wall time of one (the reference's jobs loop over them,
@@ -89,11 +92,11 @@ def run_records(method, yss, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, in
     theta0 = np.tile(np.log(np.expm1(np.asarray(init, dtype=np.float64))), (R, 1))
     nll0 = mle.batched_nll(filt, build, theta0, yss, Xi, dt, sgps, **build_kw)
     params, info = mle.fit_many(filt, build, init, yss, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
-    mss, Pss, est = _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, yss)
+    mss, Pss, est = _filter_and_smooth(method, build, build_kw, params, sgps, Xi, dt, yss, keep_rows)
     return dict(opt_params=params, fun=info['fun'], nll0=nll0, mss=mss, Pss=Pss, est_freq=est, nit=info['nit'], launches=info['launches'])
 
 
-def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None):
+def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init=None, family=None, keep_rows=True):
     """MLE -> filter -> smoother -> E[g(V)] on one measurement record.
     method: 'ekfs' | 'ghfs' | 'cd_ekfs' | 'cd_ghfs' | 'kpt';  family: 'chirp' | 'harmonic' | 'lascala' | 'kpt'
     (default: 'kpt' for method 'kpt', else 'harmonic' when num_harmonics > 0, else 'chirp').
@@ -102,7 +105,7 @@ def run_record(method, ys, Xi, dt, sgps=None, num_harmonics=0, maxiter=200, init
     filt = FILTER_OF[method]
     nll0 = float(mle.batched_nll(filt, build, np.log(np.expm1(np.asarray(init, dtype=np.float64))), ys, Xi, dt, sgps, **build_kw)[0])
     opt_params, res = mle.fit(filt, build, init, ys, Xi, dt, sgps=sgps, maxiter=maxiter, **build_kw)
-    mss, Pss, est = _filter_and_smooth(method, build, build_kw, opt_params, sgps, Xi, dt, ys)
+    mss, Pss, est = _filter_and_smooth(method, build, build_kw, opt_params, sgps, Xi, dt, ys, keep_rows)
     return dict(opt_params=opt_params, res=res, nll0=nll0, mss=mss, Pss=Pss, est_freq=est)
 
 
@@ -132,7 +135,7 @@ def demo(method, sgps=None, num_harmonics=0, T=3141, seed=555, Xi=0.1, dt=0.001,
     out = []
     for k, name, ys in records_of_run(seed, T, dt, Xi, sig_h, mags):
         t0 = time.time()
-        r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter, family=family)
+        r = run_record(method, ys, Xi, dt, sgps=sgps, num_harmonics=num_harmonics, maxiter=maxiter, family=family, keep_rows=bool(save_dir))
         err = float(rmse(true_freq_func(ts), r['est_freq'])) if r['res'].success or np.isfinite(r['res'].fun) else float('nan')
         if save_dir:       # tetralith/jobs/ekfs_mle.py:75-81: NaN results for a diverged run
             results.save_result(save_dir, result_name or method, name, k if mc is None else mc, r['mss'], r['Pss'], err)

@@ -252,7 +252,7 @@ typedef struct cgp_smooth_out {
     double*       expect;      /* [B][T]: E[f(V)], or NULL                                                       */
     const double* xi;          /* [order] nodes (DEVICE), the reference's scaling: sqrt(2) x the Hermite roots   */
     const double* w;           /* [order] weights (DEVICE), normalised                                           */
-    int32_t       order;
+    int32_t       order;       /* 1 .. 32 (the reference's default: 10)                                          */
 } cgp_smooth_out;
 int cgp_smoother_select(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
                         double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,

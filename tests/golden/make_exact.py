@@ -1,9 +1,9 @@
-"""Generates tests/golden/exact_*.npz: the path's formulas evaluated in 60-digit arithmetic (mpmath), rounded to float64 at the end.
+"""Generates tests/golden/exact_*.npz: the path's formulas evaluated in 100-digit arithmetic (mpmath), rounded to float64 at the end.
 
 Why.  The reference cannot run in this pipeline (no JAX: SURVEY.md 8c), so the float64 oracles (oracle/np_filters.py, oracle/c/port.c)
 are pinned by the reference's property tests only.  What separates ANY float64 evaluation of the reference's formulas -- XLA's, NumPy's,
 the C port's, the HIP kernels' -- from each other is rounding: operation order, fused multiply-adds, the libm behind exp / log / sin /
-cos.  This script evaluates the same recursions with a unit roundoff of 1e-60, i.e. their exact values for float64 inputs, so that the
+cos.  This script evaluates the same recursions with a unit roundoff of 1e-100, i.e. their exact values for float64 inputs, so that the
 distance of every float64 implementation from that common reference can be measured in units of 2^-53 (tests/test_exact.py): the
 "amplification" of the recursion.  XLA's result is an evaluation of the same kind and sits within the same distance of the exact value --
 that bounds what the unrunnable reference could differ by, against the north star's 1e-5 gate.  (Parity stays "partial" by the rules.)
