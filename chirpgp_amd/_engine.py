@@ -57,7 +57,7 @@ class CgpSmoothOut(C.Structure):
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
            'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
-           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select')
+           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select', 'cgp_ekf_nll_grad')
 
 _lib = None
 _lock = threading.Lock()
@@ -96,6 +96,9 @@ def load_library():
         lib.cgp_smoother_select.restype = C.c_int
         lib.cgp_smoother_select.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                             _vp, _vp, C.c_int64, C.c_int64, C.POINTER(CgpSmoothOut), C.c_uint32, _vp]
+        lib.cgp_ekf_nll_grad.restype = C.c_int
+        lib.cgp_ekf_nll_grad.argtypes = [_vp, C.POINTER(CgpModel), C.POINTER(CgpInit), C.c_double, _vp, C.c_int64, C.c_int64, _vp,
+                                         C.c_int64, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_gaussian_expectation_fn.restype = C.c_int
@@ -437,6 +440,47 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         _per_thread.junction_error = junction
         res = tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
         return res + (junction,) if return_junction_error else res
+
+
+DIR_DOUBLES = 24        # include/chirpgp_hip.h: CGP_DIR_DOUBLES
+
+
+def run_ekf_nll_grad(spec, H, Xi, m0, P0, dt, ys, dirs, trials_per_record=None, record_index=None):
+    """cgp_ekf_nll_grad: the EKF's final NLL and its derivative along `dirs` (B, n_dir, 24) -- forward tangents through the scan, one
+    launch.  ys (T,) or (R, T) with the shared-record addressing of run_filter.  Returns (nll (B,), grad (B, n_dir)) as device tensors."""
+    torch = _torch()
+    ys_d = dev(ys)
+    if ys_d.ndim == 1:
+        ys_d = ys_d[None, :]
+    R, T = int(ys_d.shape[0]), int(ys_d.shape[1])
+    rep = 1 if trials_per_record is None else int(trials_per_record)
+    idx_h = None
+    if record_index is not None:
+        idx_h = np.ascontiguousarray(np.asarray(record_index, dtype=np.int64).reshape(-1))
+        if idx_h.size and (idx_h.min() < 0 or idx_h.max() >= R):
+            raise ValueError(f'record_index outside 0..{R - 1}')
+    B = (R if idx_h is None else int(idx_h.size)) * rep
+    d = _check_dimension(spec)
+    dirs_h = np.ascontiguousarray(np.asarray(dirs, dtype=np.float64))
+    if dirs_h.ndim != 3 or dirs_h.shape[0] != B or dirs_h.shape[2] != DIR_DOUBLES:
+        raise ValueError(f'dirs must be ({B}, n_dir, {DIR_DOUBLES}); got {dirs_h.shape}')
+    n_dir = int(dirs_h.shape[1])
+    with torch.cuda.device(ys_d.device):
+        ctx = context(ys_d.device.index)
+        keep = [ys_d]
+        idx_d = None
+        if idx_h is not None:
+            idx_d = _index_const(idx_h.astype(np.int32))
+            keep.append(idx_d)
+        model = _model_struct(spec, None, B, keep)
+        init = _init_struct(H, Xi, m0, P0, d, B, keep)
+        dirs_d = dev(dirs_h, ys_d.device.index)
+        opts = dict(dtype=torch.float64, device=ys_d.device)
+        nll, grad = torch.empty((B,), **opts), torch.empty((B, n_dir), **opts)
+        rc = _timed('filter', lambda: load_library().cgp_ekf_nll_grad(ctx, C.byref(model), C.byref(init), float(dt), _ptr(ys_d), T, rep, _ptr(idx_d),
+                                                                      B, T, _ptr(dirs_d), n_dir, _ptr(nll), _ptr(grad), 0, _stream()))
+        _check(ctx, rc, 'cgp_ekf_nll_grad')
+        return nll, grad
 
 
 E_UNSUPPORTED = -2

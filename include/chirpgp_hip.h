@@ -208,6 +208,21 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
                           int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags,
                           int64_t segments, int64_t burn_in, double* junction_err, void* stream);
 
+/* The EKF's final negative log-likelihood AND its exact gradient in one launch: forward tangents of (m, P, nll) carried through the
+ * scan -- the reference differentiates its objective through the scan (demos/ekfs_mle.py:43-51: value_and_grad of
+ * ekf(build_model(g(theta)), ys)[-1][-1]).  d = 4 chirp / La Scala LCD models (CGP_M_HARMONIC_LCD with n_harm = 1, CGP_M_LASCALA_LCD).
+ * A direction is CGP_DIR_DOUBLES doubles: the derivative, along one coordinate of the caller's parametrisation, of the model's constants
+ *     log rho (rho = exp(-lam dt)) | q (chirp noise variance, models.py:302-308) | M32_F (2 x 2, row-major) | M32_Sigma (00, 01, 11) | Xi |
+ *     m0 (4) | P0 (packed lower triangle: 00 10 11 20 21 22 30 31 32 33)
+ * computed by the caller from its model builder (chirpgp_amd/mle.py does it by complex step); the derivative through the state-
+ * dependent part of the model (softplus frequency, rotation, Jacobian) is taken by the kernel.  dirs: [B][n_dir][CGP_DIR_DOUBLES]
+ * (device), nll: [B], grad: [B][n_dir] = d nll[b] / d direction.  Records are addressed as in cgp_filter.  One lane per
+ * (trial, direction). */
+#define CGP_DIR_DOUBLES 24
+int cgp_ekf_nll_grad(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init, double dt,
+                     const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index, int64_t B, int64_t T,
+                     const double* dirs, int32_t n_dir, double* nll, double* grad, uint32_t flags, void* stream);
+
 /* Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers) lives in
  * ONE buffer per (context, stream), grown on demand and freed by cgp_destroy; the library allocates nothing else per call.  Growing
  * waits for the stream -- illegal while the stream is being captured into a graph -- so a caller that captures its launches sizes the

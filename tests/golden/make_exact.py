@@ -18,6 +18,7 @@ and one at Xi = 1 on a 5.5 Hz chirp started at frequency state 7 (the estimate s
 headline kernel's speculative step; "exact_lost": the filter starts 1.5 Hz off and is ten times noisier).
 
     python -m tests.golden.make_exact          (about two minutes)
+    python -m tests.golden.make_exact --grad   (exact_grad.npz: the MLE objective's exact gradient on the same records; about five minutes)
 """
 import math
 import os
@@ -128,7 +129,7 @@ def m32_solution(ell, sigma, dt):                                        # model
 
 def build_chirp_model(params):
     """models.py:437-459 with 76-119 and 264-311: (drift, b, cond_m_cov, m0, P0, H); params = lam, b, delta, ell, sigma, m0_v (float64 -> exact)"""
-    lam, b, delta, ell, sigma, m0_v = (mpf(float(p)) for p in params)
+    lam, b, delta, ell, sigma, m0_v = (p if isinstance(p, mpf) else mpf(float(p)) for p in params)
     gam = mp.sqrt(3) / ell
 
     def drift(u):
@@ -299,6 +300,34 @@ def pipelines(params, Xi, dt, ys, cd_T):
     return res
 
 
+def ekf_final_nll(params, Xi, dt, ys):
+    """ekf(...)[2][-1] (filters_smoothers.py:222-264) for mpf parameters: the MLE objective of demos/ekfs_mle.py:42-47"""
+    drift, b, cond, m0, P0, H = build_chirp_model(params)
+
+    def step(mf, Pf, y):
+        J = jacobian(lambda u: cond(u, dt)[0], mf)
+        mp_, Sig = cond(mf, dt)
+        return linear_update(mp_, madd(matmul(matmul(J, Pf), tr(J)), Sig), H, Xi, y)
+    return run_filter(step, m0, P0, ys)[-1][2]
+
+
+def exact_gradient(params, Xi, dt, ys, h=mpf(10) ** -30):
+    """d ekf_final_nll(g(theta)) / d theta at theta = g_inv(params): central differences with a step of 1e-30 in 100-digit arithmetic
+    (truncation 1e-60 relative) -- the exact derivative the reference takes with jax.value_and_grad."""
+    theta = [mp.log(mp.exp(mpf(float(p))) - 1) for p in params]
+    Xi, dt = mpf(float(Xi)), mpf(float(dt))
+    ys = [mpf(float(y)) for y in ys]
+    f0 = ekf_final_nll([g(t) for t in theta], Xi, dt, ys)
+    grad = []
+    for k in range(len(theta)):
+        tp, tm = list(theta), list(theta)
+        tp[k] += h
+        tm[k] -= h
+        grad.append((ekf_final_nll([g(t) for t in tp], Xi, dt, ys) - ekf_final_nll([g(t) for t in tm], Xi, dt, ys)) / (2 * h))
+        print(f'  d nll / d theta[{k}] done', flush=True)
+    return np.array([float(t) for t in theta]), float(f0), np.array([float(v) for v in grad])
+
+
 def to_f64(res):
     flat = {}
     for name, rows in res.items():
@@ -320,7 +349,19 @@ def records():
     return (('exact_track', p, 0.1, dt, track), ('exact_lost', p, 1.0, dt, lost))
 
 
+def main_gradient():
+    """tests/golden/exact_grad.npz: value and exact gradient of the MLE objective on the two records (T = 500)"""
+    out = {}
+    for name, p, Xi, dt, ys in records():
+        print(name, 'gradient', flush=True)
+        theta, f0, grad = exact_gradient(p, Xi, dt, ys)
+        out.update({f'{name}.theta': theta, f'{name}.nll': f0, f'{name}.grad': grad, f'{name}.ys': ys, f'{name}.Xi': Xi, f'{name}.dt': dt, f'{name}.params': p})
+    np.savez_compressed(os.path.join(OUT, 'exact_grad.npz'), digits=mp.dps, **out)
+
+
 def main():
+    if '--grad' in sys.argv:
+        return main_gradient()
     for name, p, Xi, dt, ys in records():
         print(name, flush=True)
         res = pipelines(p, Xi, dt, ys, cd_T=300)

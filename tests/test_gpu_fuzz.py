@@ -1,0 +1,138 @@
+"""Randomised records through the regime state machine of the d = 4 EKF kernels.
+
+The headline filter (cgp_mfma4.hpp: ekf4_mfma_kernel) runs 64-step chunks speculatively on lean polynomials chosen by the frequency
+state's range -- HIGH (>= 5), common (>= 1.5), LOW (<= -1.5), MID (|x| < 2), the branch-free WIDE step, the checked step -- and repeats a
+chunk that left its regime; five counters and thresholds tuned on 45 benchmark sets decide what is tried next.  Hand-built crossing
+records test it in test_gpu_parity.py; here 240 seeded random record sets do: frequency-state tracks anywhere in -2 .. 40 (0.1 to 40 Hz)
+that cross the boundaries at random places and rates, measurement noise 1e-3 .. 3, dt 1e-3 or 1e-2, T 65 .. 3000, per-trial model
+parameters and noise levels, NaN and inf measurements -- through the one-trial-per-wavefront kernel, the four-trials-per-wavefront
+kernel and the one-lane-per-trial kernel, each against the C port, NaN and inf positions identical, and the regime counters of the
+one-trial kernel accounting for every chunk.
+
+Tolerance: 1e-9 -- or, for a record set on which the recursion itself is ill-conditioned, 300 x the amount by which the PORT's own results
+move when every measurement is perturbed by 1e-15 of itself (measured per set, two runs of the port).  Of the 240 sets 228 sit below
+1e-10 on all three kernels; the worst (seed 29: dt = 1e-2, the filter 25 units of frequency state away from the signal) moves the port by
+1.8e-4 under that perturbation and the kernels by 2.3e-4 .. 5.9e-4 -- the full-accuracy lane kernel as much as the lean-polynomial ones:
+it is the recursion that amplifies, not the tiers (ratios to the port's own response: <= 150 over the whole fuzz)."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import cases as cs
+
+pytestmark = pytest.mark.gpu
+
+ONE, FOUR, LANE = 0x2 | 0x400, 0x2 | 0x200, 0x4
+N_SETS = 240
+
+
+def _softplus(v):
+    return np.logaddexp(0.0, v)
+
+
+def make_set(seed):
+    """One random record set: (B, T, dt, Xi (B,), params (B, 6), ys (B, T), tracks (B, T))."""
+    rng = np.random.default_rng(90000 + seed)
+    B = int(rng.integers(3, 9))
+    T = int(rng.integers(65, 3001))
+    dt = 1e-3 if rng.random() < 0.6 else 1e-2
+    Xi = 10 ** rng.uniform(-3, math.log10(3.0), size=B)
+    if rng.random() < 0.5:
+        Xi[:] = Xi[0]
+    ts = dt * np.arange(1, T + 1)
+    vmax = 40.0 if dt == 1e-3 else 25.0                       # stay well below Nyquist at dt = 1e-2
+    params, ys, tracks = np.empty((B, 6)), np.empty((B, T)), np.empty((B, T))
+    for b in range(B):
+        kind = rng.integers(0, 4)
+        if kind == 0:                                         # anywhere to anywhere
+            v0, v1 = rng.uniform(-2, vmax, size=2)
+        elif kind == 1:                                       # around the common / MID / LOW boundaries
+            v0, v1 = rng.uniform(-2.5, 3.0, size=2)
+        elif kind == 2:                                       # around the HIGH boundary
+            v0, v1 = rng.uniform(3.5, 7.0, size=2)
+        else:                                                 # flat
+            v0 = rng.uniform(-2, vmax)
+            v1 = v0 + rng.uniform(-0.3, 0.3)
+        cyc = rng.uniform(0.3, 2.5)
+        v = v0 + (v1 - v0) * 0.5 * (1 - np.cos(2 * math.pi * cyc * np.arange(T) / T))
+        tracks[b] = v
+        phase = np.cumsum(_softplus(v)) * dt
+        amp = rng.uniform(0.5, 2.0)
+        ys[b] = amp * np.sin(2 * math.pi * phase + rng.uniform(0, 2 * math.pi)) + math.sqrt(Xi[b]) * rng.standard_normal(T)
+        params[b] = np.array([0.1, rng.uniform(0.05, 0.6), 0.1, rng.uniform(0.3, 1.2), rng.uniform(0.8, 3.0), v0]) * np.r_[rng.uniform(0.7, 1.3, 5), 1.0]
+        if rng.random() < 0.1:
+            params[b, 0] = 0.0                                # the lam = 0 branch of models.py:302-308
+    if rng.random() < 0.15:
+        ys[rng.integers(0, B), rng.integers(0, T)] = np.nan
+    if rng.random() < 0.08:
+        ys[rng.integers(0, B), rng.integers(0, T)] = np.inf
+    return B, T, dt, Xi, params, ys, tracks
+
+
+def distance(g, w, n):
+    """Largest error of an output array, component by component, each against ITS scale: the frequency state runs up to 40, the chirp's
+    amplitude is ~1 -- one denominator for the whole vector would hide the small components, and an element-wise floor of 1e-3 of the global
+    scale would gate them at 1e-12 of theirs.  Non-finite entries (compared separately) count as 0."""
+    bad = ~(np.isfinite(w) & np.isfinite(g))
+    gf, wf = np.where(bad, 0.0, g), np.where(bad, 0.0, w)
+    if n == 'mfs':
+        return max(cs.max_rel_err(gf[..., c], wf[..., c]) for c in range(4))
+    if n == 'Pfs':
+        sd = np.sqrt(np.maximum(np.abs(wf[..., np.arange(4), np.arange(4)]).reshape(-1, 4).max(axis=0), 1e-300))
+        return max(float(np.abs(gf[..., i, j] - wf[..., i, j]).max() / (sd[i] * sd[j])) for i in range(4) for j in range(4))
+    return cs.max_rel_err(gf, wf)
+
+
+def test_random_records_through_the_regime_state_machine():
+    from chirpgp_amd import filters_smoothers as fs, models as pm, _engine
+    from oracle import port
+    totals = dict.fromkeys(_engine.REGIME_COUNTERS, 0)
+    worst = {ONE: 0.0, FOUR: 0.0, LANE: 0.0}
+    ill = 0
+    failures = []
+    below = arrays = 0
+    for seed in range(N_SETS):
+        B, T, dt, Xi, params, ys, tracks = make_set(seed)
+        drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+        want = port.filter(port.F_EKF, disc, None, H, Xi, m0, P0, dt, ys)
+        # the recursion's own conditioning on this set: how far the port moves when every measurement moves by 1e-15 of itself
+        moved = port.filter(port.F_EKF, disc, None, H, Xi, m0, P0, dt, ys * (1 + 1e-15 * np.random.default_rng(seed).choice([-1., 1.], size=ys.shape)))
+        delta = {n: distance(np.asarray(b_), np.asarray(a), n) for a, b_, n in zip(want, moved, ('mfs', 'Pfs', 'nll'))}
+        tols = {n: max(1e-9, 300.0 * d) for n, d in delta.items()}
+        ill += max(tols.values()) > 1e-9
+        for flags in (ONE, FOUR, LANE):
+            if flags == ONE:
+                _engine.debug_set(_engine.DBG_COUNT_REGIMES, 1)
+                _engine.debug_counters(reset=True)
+            got = fs.ekf(disc, H, Xi, m0, P0, dt, ys, flags=flags)
+            if flags == ONE:
+                rg = _engine.debug_counters(reset=True)
+                _engine.debug_set(_engine.DBG_COUNT_REGIMES, 0)
+                chunks = B * ((T + 63) // 64)
+                kept = rg['high'] + rg['common'] + rg['low'] + rg['mid'] + rg['redone'] + rg['wide'] + rg['checked']
+                if kept != chunks:
+                    failures.append((seed, 'counters', kept, chunks, rg))
+                for k in totals:
+                    totals[k] += rg[k]
+            for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+                g, w = np.asarray(g), np.asarray(w)
+                # non-finite entries (an inf measurement gives inf, then NaN) must be the SAME non-finite values; the rest is compared
+                bad = ~np.isfinite(w)
+                if not (np.array_equal(bad, ~np.isfinite(g)) and np.array_equal(np.isnan(w), np.isnan(g)) and np.array_equal(np.sign(w[bad & ~np.isnan(w)]), np.sign(g[bad & ~np.isnan(w)]))):
+                    failures.append((seed, flags, n, 'non-finite entries differ', dict(B=B, T=T, dt=dt)))
+                    continue
+                e, tol = distance(g, w, n), tols[n]
+                if not e <= tol:
+                    failures.append((seed, flags, n, f'{e:.3e} > {tol:.1e}', dict(B=B, T=T, dt=dt, delta=delta[n])))
+                worst[flags] = max(worst[flags], e)
+                below += e < 1e-10
+                arrays += 1
+                if e > 1e-9:
+                    print(f'  seed {seed} flags {flags:#x} {n}: {e:.2e}  (B {B} T {T} dt {dt}; the port under a 1e-15 perturbation: {delta[n]:.2e})')
+    print(f'{N_SETS} sets ({ill} ill-conditioned: tolerance above 1e-9); {below} of {arrays} output arrays below 1e-10; worst relative error one-trial {worst[ONE]:.2e}, four-trials {worst[FOUR]:.2e}, lane {worst[LANE]:.2e}')
+    print('chunks by regime over the fuzz:', totals)
+    assert not failures, failures[:6]
+    # the fuzz reached every tier of the state machine
+    for k in ('high', 'common', 'low', 'mid', 'wide', 'redone'):
+        assert totals[k] > 0, (k, totals)
