@@ -57,7 +57,8 @@ class CgpSmoothOut(C.Structure):
 EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_filter', 'cgp_smoother',
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
            'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
-           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select', 'cgp_ekf_nll_grad')
+           'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select', 'cgp_ekf_nll_grad', 'cgp_model_from_source', 'cgp_custom_model_destroy',
+           'cgp_filter_custom', 'cgp_smoother_custom')
 
 _lib = None
 _lock = threading.Lock()
@@ -99,6 +100,15 @@ def load_library():
         lib.cgp_ekf_nll_grad.restype = C.c_int
         lib.cgp_ekf_nll_grad.argtypes = [_vp, C.POINTER(CgpModel), C.POINTER(CgpInit), C.c_double, _vp, C.c_int64, C.c_int64, _vp,
                                          C.c_int64, C.c_int64, _vp, C.c_int32, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_model_from_source.restype = C.c_int
+        lib.cgp_model_from_source.argtypes = [_vp, C.c_int, C.c_int32, C.c_char_p, C.c_char_p, C.POINTER(_vp)]
+        lib.cgp_custom_model_destroy.restype = None
+        lib.cgp_custom_model_destroy.argtypes = [_vp]
+        lib.cgp_filter_custom.restype = C.c_int
+        lib.cgp_filter_custom.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(CgpInit), C.c_double, _vp, C.c_int64, C.c_int64, _vp,
+                                          C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_smoother_custom.restype = C.c_int
+        lib.cgp_smoother_custom.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_double, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_gaussian_expectation_fn.restype = C.c_int
@@ -440,6 +450,94 @@ def run_filter(method, spec, sgps, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=
         _per_thread.junction_error = junction
         res = tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
         return res + (junction,) if return_junction_error else res
+
+
+# ---- models compiled at run time (include/chirpgp_hip.h: cgp_model_from_source) ----------------------------------------------------
+_custom_cache = {}
+
+
+def custom_model(spec, device_index=None):
+    """The compiled form of a models.CustomDiscrete / CustomDrift on a device: built by hiprtc on first use (about a second), then cached by
+    (device, kind, d, source).  A source that does not compile raises RuntimeError with the compiler's messages."""
+    torch = _torch()
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    key = (device_index, int(spec.kind), int(spec.d), spec.source)
+    h = _custom_cache.get(key)
+    if h is None:
+        ctx = context(device_index)
+        h = _vp()
+        rc = load_library().cgp_model_from_source(ctx, int(spec.kind), int(spec.d), spec.source.encode(), os.path.join(_HERE, 'csrc').encode(), C.byref(h))
+        _check(ctx, rc, 'cgp_model_from_source')
+        _custom_cache[key] = h
+    return h
+
+
+def _custom_params(spec, gamma, B, keep):
+    params = dev_const(spec.params)
+    if params.ndim == 2 and params.shape[0] != B:
+        raise ValueError(f'model parameters have batch {params.shape[0]} but the data has batch {B}')
+    keep.append(params)
+    g = gs = None
+    if gamma is not None:
+        g, gs = _batched_operand(gamma, 2, B, 'dispersion')
+        if tuple(g.shape[-2:]) != (spec.d, spec.d):
+            raise ValueError(f'b b^T must be {spec.d} x {spec.d}, got {tuple(g.shape)}')
+        keep.append(g)
+    return params, (int(params.shape[-1]) if params.ndim == 2 else 0), g, (gs or 0)
+
+
+def run_filter_custom(spec, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, want=(True, True, True), flags=0):
+    """ekf / cd_ekf on a model compiled at run time (cgp_filter_custom): the generic one-lane-per-trial kernel instantiated on the
+    caller's source.  ys (T,) or (B, T)."""
+    torch = _torch()
+    like_numpy = not _is_torch(ys)
+    ys_d = dev(ys)
+    squeeze = ys_d.ndim == 1
+    if squeeze:
+        ys_d = ys_d[None, :]
+    B, T = int(ys_d.shape[0]), int(ys_d.shape[1])
+    d = int(spec.d)
+    with torch.cuda.device(ys_d.device):
+        ctx = context(ys_d.device.index)
+        handle = custom_model(spec, ys_d.device.index)
+        keep = [ys_d]
+        params, pstride, g, gstride = _custom_params(spec, gamma, B, keep)
+        init = _init_struct(H, Xi, m0, P0, d, B, keep)
+        opts = dict(dtype=torch.float64, device=ys_d.device)
+        mfs = torch.empty((B, T, d), **opts) if want[0] else None
+        Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
+        nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
+        fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
+        rc = _timed('filter', lambda: load_library().cgp_filter_custom(ctx, handle, _ptr(params), pstride, _ptr(g), gstride, C.byref(init), float(dt),
+                                                                       _ptr(ys_d), T, 1, None, B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, _stream()))
+        _check(ctx, rc, 'cgp_filter_custom')
+        return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
+
+
+def run_smoother_custom(spec, gamma, dt, mfs, Pfs, flags=0):
+    """eks / cd_eks on a model compiled at run time (cgp_smoother_custom)."""
+    torch = _torch()
+    like_numpy = not _is_torch(mfs)
+    m, P = dev(mfs), dev(Pfs)
+    squeeze = m.ndim == 2
+    if squeeze:
+        m, P = m[None], P[None]
+    if m.ndim != 3 or P.ndim != 4 or P.shape[:2] != m.shape[:2] or P.shape[2] != m.shape[2] or P.shape[3] != m.shape[2]:
+        raise ValueError(f'mfs / Pfs must be (B, T, d) / (B, T, d, d); got {tuple(m.shape)} / {tuple(P.shape)}')
+    B, T, d = (int(v) for v in m.shape)
+    if d != int(spec.d):
+        raise ValueError(f'model dimension {spec.d} != data dimension {d}')
+    with torch.cuda.device(m.device):
+        ctx = context(m.device.index)
+        handle = custom_model(spec, m.device.index)
+        keep = [m, P]
+        params, pstride, g, gstride = _custom_params(spec, gamma, B, keep)
+        mss, Pss = torch.empty_like(m), torch.empty_like(P)
+        rc = _timed('smoother', lambda: load_library().cgp_smoother_custom(ctx, handle, _ptr(params), pstride, _ptr(g), gstride, float(dt), _ptr(m), _ptr(P),
+                                                                           B, T, _ptr(mss), _ptr(Pss), int(flags), _stream()))
+        _check(ctx, rc, 'cgp_smoother_custom')
+        return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)
 
 
 DIR_DOUBLES = 24        # include/chirpgp_hip.h: CGP_DIR_DOUBLES

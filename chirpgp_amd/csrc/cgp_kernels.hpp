@@ -9,7 +9,11 @@
 //   WAVE  = false : grid = ceil(B / 64).  One lane per trial (large batches).
 #pragma once
 #include "cgp_steps.hpp"
+#ifndef __HIPCC_RTC__          // the context is host code
 #include "cgp_ctx.hpp"
+#else
+struct cgp_ctx;
+#endif
 #include "../../include/chirpgp_hip.h"
 
 namespace cgp {
@@ -634,6 +638,7 @@ __global__ void __launch_bounds__(64) tp_smoother_kernel(SmootherIO io, ModelArg
 // Steps per lane of the time-parallel smoother: bounded by the VGPR budget (K affine maps of D^2 + D + D(D+1)/2 doubles).
 template <int D> struct TpStepsPerLane { static constexpr int value = D <= 4 ? 4 : 1; };
 
+#ifndef __HIPCC_RTC__          // ---- host side: launchers and the dispatch entry points of the translation units
 template <class Elem>
 inline hipError_t launch_tp_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
@@ -712,5 +717,6 @@ int dispatch_smoother_sde_linear(int method, int key, bool wave, const SmootherI
 int dispatch_smoother_sde_harm(int method, int key, bool wave, const SmootherIO&, const ModelArgs&, hipStream_t);
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? CGP_OK : CGP_E_HIP; }
+#endif                         // __HIPCC_RTC__
 
 }  // namespace cgp

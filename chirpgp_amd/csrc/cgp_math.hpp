@@ -4,8 +4,13 @@
 // compiler keeps it in registers (runtime-indexed arrays go to scratch: cdna_hip_programming.md rule 20).
 // Symmetric matrices are stored packed (lower triangle, D(D+1)/2 doubles): d = 4 -> 10, d = 8 -> 36 doubles.
 #pragma once
+#ifndef __HIPCC_RTC__          // (a runtime compilation -- cgp_rtc.hip, custom models -- has the device runtime built in and no host headers)
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#else                          // the fixed-width types of <cstdint> as this platform's host compiler defines them (LP64)
+typedef long int64_t; typedef unsigned long uint64_t; typedef int int32_t; typedef unsigned int uint32_t;
+typedef unsigned long uintptr_t; typedef unsigned long size_t;
+#endif
 
 #define CGP_DEV __device__ __forceinline__
 #define CGP_UNROLL _Pragma("unroll")

@@ -20,16 +20,16 @@ __all__ = ['kf', 'rts', 'ekf', 'ekf_for_kpt', 'eks', 'cd_ekf', 'cd_eks',
 
 
 def _discrete(cond_m_cov, dt=None):
-    if isinstance(cond_m_cov, M.DiscreteModel):
+    if isinstance(cond_m_cov, (M.DiscreteModel, M.CustomDiscrete)):
         return cond_m_cov
     if hasattr(cond_m_cov, 'at') and dt is not None:          # dt-dependent linear descriptors (disc_m32)
         return cond_m_cov.at(dt)
-    raise TypeError('cond_m_cov must be a chirpgp_amd.models descriptor (e.g. disc_chirp_lcd(...), '
-                    'linear_cond_m_cov(F, Sigma)); arbitrary Python callables cannot run inside the HIP kernels')
+    raise TypeError('cond_m_cov must be a chirpgp_amd.models descriptor (e.g. disc_chirp_lcd(...), linear_cond_m_cov(F, Sigma), or '
+                    'custom_cond_m_cov(source, ...) for a model of your own); arbitrary Python callables cannot run inside the HIP kernels')
 
 
 def _drift(a):
-    if isinstance(a, M.DriftModel):
+    if isinstance(a, (M.DriftModel, M.CustomDrift)):
         return a
     raise TypeError('the drift must be a chirpgp_amd.models descriptor (e.g. model_chirp(...)[0], linear_sde(A, B)[0])')
 
@@ -67,6 +67,9 @@ def rts(F, Sigma, mfs, Pfs, **kw):
 
 def ekf(cond_m_cov, H, Xi, m0, P0, dt, ys, **kw):
     """Extended Kalman filter (filters_smoothers.py:222-264)."""
+    spec = _discrete(cond_m_cov, dt)
+    if isinstance(spec, M.CustomDiscrete):            # a model compiled at run time: the generic kernel on the caller's source
+        return E.run_filter_custom(spec, None, H, Xi, m0, P0, dt, ys, **_custom_kw(kw))
     return E.run_filter(E.F_EKF, _discrete(cond_m_cov, dt), None, None, H, Xi, m0, P0, dt, ys, **kw)
 
 
@@ -83,41 +86,63 @@ def ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw):
 
 def eks(cond_m_cov, mfs, Pfs, dt, **kw):
     """Extended Kalman smoother (filters_smoothers.py:317-349)."""
+    spec = _discrete(cond_m_cov, dt)
+    if isinstance(spec, M.CustomDiscrete):
+        return E.run_smoother_custom(spec, None, dt, mfs, Pfs, **_custom_kw(kw, ('flags',)))
     return E.run_smoother(E.S_EKS, _discrete(cond_m_cov, dt), None, None, dt, mfs, Pfs, **kw)
 
 
 def cd_ekf(a, b, H, Xi, m0, P0, dt, ys, **kw):
     """Continuous-discrete EKF with RK4 moment integration (filters_smoothers.py:352-397)."""
+    if isinstance(a, M.CustomDrift):
+        return E.run_filter_custom(a, _gamma_from_callable(b), H, Xi, m0, P0, dt, ys, **_custom_kw(kw))
     return E.run_filter(E.F_CD_EKF, _drift(a), None, _gamma_from_callable(b), H, Xi, m0, P0, dt, ys, **kw)
 
 
 def cd_eks(a, b, mfs, Pfs, dt, **kw):
     """Continuous-discrete EKS (filters_smoothers.py:400-443)."""
+    if isinstance(a, M.CustomDrift):
+        return E.run_smoother_custom(a, _gamma_from_callable(b), dt, mfs, Pfs, **_custom_kw(kw, ('flags',)))
     return E.run_smoother(E.S_CD_EKS, _drift(a), None, _gamma_from_callable(b), dt, mfs, Pfs, **kw)
 
 
 def sgp_filter(cond_m_cov, sgps, H, Xi, m0, P0, dt, ys, **kw):
     """Sigma-point (Gauss-Hermite / cubature) filter on a discretised model (filters_smoothers.py:446-490)."""
-    spec = _discrete(cond_m_cov, dt)
+    spec = _enumerated(_discrete(cond_m_cov, dt), 'sgp_filter')
     return E.run_filter(E.F_SGP, spec, _sgps(sgps, spec.d), None, H, Xi, m0, P0, dt, ys, **kw)
 
 
 def sgp_smoother(cond_m_cov, sgps, mfs, Pfs, dt, **kw):
     """Sigma-point smoother (filters_smoothers.py:493-531)."""
-    spec = _discrete(cond_m_cov, dt)
+    spec = _enumerated(_discrete(cond_m_cov, dt), 'sgp_smoother')
     return E.run_smoother(E.S_SGP, spec, _sgps(sgps, spec.d), None, dt, mfs, Pfs, **kw)
 
 
 def cd_sgp_filter(a, b, sgps, H, Xi, m0, P0, dt, ys, **kw):
     """Continuous-discrete sigma-point filter; b is the constant (d, dw) dispersion matrix (filters_smoothers.py:534-582)."""
-    spec = _drift(a)
+    spec = _enumerated(_drift(a), 'cd_sgp_filter')
     return E.run_filter(E.F_CD_SGP, spec, _sgps(sgps, spec.d), _gamma_from_matrix(b), H, Xi, m0, P0, dt, ys, **kw)
 
 
 def cd_sgp_smoother(a, b, sgps, mfs, Pfs, dt, **kw):
     """Continuous-discrete sigma-point smoother (filters_smoothers.py:585-632)."""
-    spec = _drift(a)
+    spec = _enumerated(_drift(a), 'cd_sgp_smoother')
     return E.run_smoother(E.S_CD_SGP, spec, _sgps(sgps, spec.d), _gamma_from_matrix(b), dt, mfs, Pfs, **kw)
+
+
+def _custom_kw(kw, allowed=('nll_final_only', 'want', 'flags')):
+    """Keywords a runtime-compiled model understands (one launch shape, dense records); anything else is refused by name."""
+    extra = set(kw) - set(allowed)
+    if extra:
+        raise TypeError(f'custom models take {" / ".join(allowed)} only, not {sorted(extra)}')
+    return kw
+
+
+def _enumerated(spec, what):
+    if isinstance(spec, (M.CustomDiscrete, M.CustomDrift)):
+        raise NotImplementedError(f'{what}: models compiled at run time run the EKF-type methods (ekf, eks, cd_ekf, cd_eks); the sigma-point '
+                                  f'kernels take the enumerated models')
+    return spec
 
 
 def _np(x):

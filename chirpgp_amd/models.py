@@ -12,7 +12,8 @@ batch axis (one parameter vector per trial: parameter sweeps / MLE grids).
 import math
 import numpy as np
 
-__all__ = ['g', 'g_inv', 'DiscreteModel', 'DriftModel', 'Dispersion', 'MeasurementKPT',
+__all__ = ['g', 'g_inv', 'DiscreteModel', 'DriftModel', 'Dispersion', 'MeasurementKPT', 'CustomDiscrete', 'CustomDrift',
+           'custom_cond_m_cov', 'custom_sde',
            'linear_cond_m_cov', 'linear_sde',
            'model_chirp', 'model_harmonic_chirp', 'model_lascala',
            'disc_chirp_lcd', 'disc_harmonic_chirp_lcd', 'disc_model_lascala_lcd', 'disc_m32',
@@ -152,6 +153,69 @@ class MeasurementKPT:
         x = np.asarray(x)
         ks = np.arange(1, self.n_harm + 1)
         return np.dot(x[1:-1], np.sin(g(x[0] + x[-1]) * ks))
+
+
+# --------------------------------------------------------------------------- models compiled at run time
+M_CUSTOM = -1
+CUSTOM_DISCRETE, CUSTOM_SDE = 0, 1          # include/chirpgp_hip.h
+
+
+class _CustomSpec(_Spec):
+    """A model handed over as DEVICE SOURCE (include/chirpgp_hip.h: cgp_model_from_source; csrc/cgp_custom.hpp): compiled by ROCm's
+    runtime compiler into the generic kernels on first use, Jacobian by forward-mode dual numbers in the kernel."""
+    model_id = M_CUSTOM
+    kind = None
+
+    def __init__(self, source, d, params, host=None):
+        super().__init__(d, 0, params)
+        self.source = str(source)
+        self.host = host
+
+    def __repr__(self):
+        return f'{type(self).__name__}(d={self.d}, params{self.params.shape}, {len(self.source)} characters of source)'
+
+
+class CustomDiscrete(_CustomSpec):
+    """cond_m_cov(u, dt) -> (mean, cov) as source: `cond_mean<T>` and `cond_cov` (see custom_cond_m_cov)."""
+    kind = CUSTOM_DISCRETE
+
+    def __call__(self, u, dt):
+        if self.host is None:
+            raise TypeError('this custom model has no host callable (pass host= to custom_cond_m_cov to evaluate it with NumPy)')
+        return self.host(u, dt)
+
+
+class CustomDrift(_CustomSpec):
+    """SDE drift a(u) as source: `drift<T>` (see custom_sde)."""
+    kind = CUSTOM_SDE
+
+    def __call__(self, u):
+        if self.host is None:
+            raise TypeError('this custom drift has no host callable (pass host= to custom_sde to evaluate it with NumPy)')
+        return self.host(u)
+
+
+def custom_cond_m_cov(source, d, params, host=None):
+    """Descriptor of a discrete model the library does not enumerate -- what the reference takes as any traceable ``cond_m_cov(u, dt)``
+    (filters_smoothers.py:222-264, 317-349): usable with ``ekf`` and ``eks``.  ``source`` is HIP device code defining, for a generic scalar
+    type T (double, or the dual numbers the kernel differentiates with: sin, cos, exp, log, sqrt, tanh, pow(x, const) and softplus are
+    overloaded),
+
+        template <class T> __device__ void cond_mean(const T* u, const double* p, double dt, T* mean);
+        __device__ void cond_cov(const double* u, const double* p, double dt, double* cov);      // cov: [d][d] row-major, symmetric
+
+    ``params`` (n,) or (B, n) is the vector ``p`` the source reads (one per trial if batched); ``host`` an optional NumPy callable
+    ``(u, dt) -> (mean, cov)`` of the same model for host-side use (simulation, checking).  d <= 8."""
+    return CustomDiscrete(source, d, params, host)
+
+
+def custom_sde(source, d, params, dispersion, host=None):
+    """(drift, dispersion) descriptors of an SDE model as source -- ``cd_ekf`` / ``cd_eks`` (filters_smoothers.py:352-443):
+
+        template <class T> __device__ void drift(const T* u, const double* p, T* a);
+
+    ``dispersion`` is the constant (d, dw) matrix b (the kernels take b b^T)."""
+    return CustomDrift(source, d, params, host), Dispersion(dispersion)
 
 
 # --------------------------------------------------------------------------- generic linear descriptors

@@ -38,8 +38,10 @@
 #ifndef CHIRPGP_HIP_H
 #define CHIRPGP_HIP_H
 
+#ifndef __HIPCC_RTC__       /* (hiprtc, compiling a custom model against the library's own headers, has these types built in) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -222,6 +224,33 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
 int cgp_ekf_nll_grad(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init, double dt,
                      const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index, int64_t B, int64_t T,
                      const double* dirs, int32_t n_dir, double* nll, double* grad, uint32_t flags, void* stream);
+
+/* ---- models compiled at run time ------------------------------------------------------------------------------------------
+ * The reference's filters take any JAX-traceable callable (filters_smoothers.py:255, 304, 382, 425); the enumerated models above are the
+ * reference's own builders.  A model outside that set is handed over as device source and compiled by ROCm's runtime compiler (hiprtc)
+ * into the generic one-lane-per-trial kernels -- ekf / eks for a discrete model, cd_ekf / cd_eks for an SDE -- with its Jacobian taken
+ * by forward-mode dual numbers in the kernel (the counterpart of jax.jacfwd; csrc/cgp_custom.hpp).  `body` defines, for a generic scalar
+ * type T (double or a dual number; sin, cos, exp, log, sqrt, tanh, pow(x, const), softplus are overloaded for it),
+ *     CGP_CUSTOM_DISCRETE:   template <class T> __device__ void cond_mean(const T* u, const double* p, double dt, T* mean);
+ *                            __device__ void cond_cov(const double* u, const double* p, double dt, double* cov);      cov [d][d] row-major
+ *     CGP_CUSTOM_SDE:        template <class T> __device__ void drift(const T* u, const double* p, T* a);              (b b^T is `gamma`)
+ * p = the trial's parameter vector (`params` + trial * param_stride at launch; any length the body agrees on with its caller).
+ * include_dir = the directory of this library's kernel headers (chirpgp_amd/csrc in the source tree; include/ is found beside it).
+ * A body that does not compile gives CGP_E_ARG with the compiler's messages in cgp_last_error.  d <= 8. */
+typedef struct cgp_custom_model cgp_custom_model;
+#define CGP_CUSTOM_DISCRETE 0
+#define CGP_CUSTOM_SDE      1
+int  cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, const char* include_dir, cgp_custom_model** out);
+void cgp_custom_model_destroy(cgp_custom_model* model);
+/* ekf (filters_smoothers.py:222-264) / cd_ekf (:352-397) on a compiled model; arguments as cgp_filter */
+int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* model, const double* params, int64_t param_stride,
+                      const double* gamma, int64_t gamma_stride, const cgp_init* init, double dt,
+                      const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index, int64_t B, int64_t T,
+                      double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
+/* eks (:317-349) / cd_eks (:400-443) on a compiled model; arguments as cgp_smoother */
+int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* model, const double* params, int64_t param_stride,
+                        const double* gamma, int64_t gamma_stride, double dt, const double* mfs, const double* Pfs,
+                        int64_t B, int64_t T, double* mss, double* Pss, uint32_t flags, void* stream);
 
 /* Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers) lives in
  * ONE buffer per (context, stream), grown on demand and freed by cgp_destroy; the library allocates nothing else per call.  Growing
