@@ -16,6 +16,11 @@
  *   cgp_smoother (method = CGP_S_SGP)                                  sgp_smoother    filters_smoothers.py:493-531
  *   cgp_smoother (method = CGP_S_CD_EKS)                               cd_eks      filters_smoothers.py:400-443
  *   cgp_smoother (method = CGP_S_CD_SGP)                               cd_sgp_smoother filters_smoothers.py:585-632
+ *   cgp_smoother_select                                                the smoothers above + the marginal step behind them in every driver
+ *                                                                      (demos/ekfs_mle.py:69-77: mss[:, k], Pss[:, k, k], gaussian_expectation), fused
+ *   cgp_ekf_nll_grad                                                   value_and_grad of ekf(...)[-1][-1] through the scan, demos/ekfs_mle.py:43-51
+ *   cgp_model_from_source, cgp_filter_custom, cgp_smoother_custom      ekf / eks / cd_ekf / cd_eks on ANY model (the reference traces any callable:
+ *                                                                      filters_smoothers.py:255, 342, 382, 425; test/test_ekfs.py:11-62), compiled at run time
  *   cgp_gaussian_expectation                                           gaussian_expectation quadratures.py:234-274
  *   cgp_simulate                                                       simulate_sde tools.py:119-170 and the
  *                                                                      state + measurement simulation of
@@ -47,7 +52,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 140          /* 0.1.4: cgp_release_workspace, cgp_source_hash, pinned reserved workspaces, per-call launch lock; 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
+#define CGP_VERSION 150          /* 0.1.5: cgp_smoother_select, cgp_ekf_nll_grad, cgp_model_from_source / cgp_filter_custom / cgp_smoother_custom; 0.1.4: cgp_release_workspace, cgp_source_hash, pinned reserved workspaces, per-call launch lock; 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;

@@ -412,6 +412,26 @@ def test_large_sigma_sets_fall_back_to_one_lane_per_trial():
         bk.compare(got, want, RTOL, f'gh3 d={2 * nh + 2}')
 
 
+def test_d4_sigma_sets_in_the_window_between_the_lane_and_the_wave_stage():
+    """the large-batch lane kernel of the sigma-point filter has 28.7 KB of static LDS in front of the staged set, so a set of
+    34 .. 44 KB (about 880 .. 1120 points at d = 4) fits the wave kernels' stage but not the lane kernel's 64 KB launch -- it must take the
+    generic lane kernel (set read from global memory), not fail.  881 points (Gauss-Hermite orders 5 and 4 at half weight each), a smaller
+    one (order 5: 625 points) on the lane kernel proper, and a larger one (order 6: 1296) past both stages; every launch shape."""
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    fs = _fs()
+    c = cs.chirp_case(T=40, seed=52)
+    ys = c.ys[None, :] + 0.05 * np.random.default_rng(1).standard_normal((70, c.ys.size))
+    g5, g4, g6 = SigmaPoints.gauss_hermite(4, 5), SigmaPoints.gauss_hermite(4, 4), SigmaPoints.gauss_hermite(4, 6)
+    mixed = SigmaPoints(4, g5.n_points + g4.n_points, np.concatenate([0.5 * g5.w, 0.5 * g4.w]), None, np.concatenate([g5.xi, g4.xi]))
+    for sg, tag in ((mixed, '881 points'), (g5, '625 points'), (g6, '1296 points')):
+        want = port.filter(port.F_SGP, c.disc, sg, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        for kw in (THREAD, WAVE, {}):
+            got = fs.sgp_filter(c.disc, sg, c.H, c.Xi, c.m0, c.P0, c.dt, ys, **kw)
+            for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+                cs.assert_close(g, w, RTOL, f'{tag} {kw} {n}')
+
+
 def test_sigma_point_sweep_nll_only():
     """Config C5's sweep: 3-harmonic model, cubature, one parameter vector per trial, NLL-only, both launch shapes."""
     from chirpgp_amd import models as pm

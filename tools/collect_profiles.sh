@@ -10,13 +10,17 @@ for W in ekf sgp harmonic harmonic_ekf cd_ekf cd_sgp; do
     [ -d $D ] || continue
     cp $D/kernel_stats.csv profiles/${TAG}_${W}_kernel_stats.csv
     cp $D/bench.json profiles/${TAG}_${W}_bench.json
+    [ -f $D/bench_details.json ] && cp $D/bench_details.json profiles/${TAG}_${W}_bench_details.json
     cp $D/pmc.json profiles/${TAG}_${W}_pmc.json
 done
 [ -f gpurun_out/${TAG}_issue_table.json ] && cp gpurun_out/${TAG}_issue_table.json profiles/${TAG}_issue_table.json
-for D in gpurun_out/crlb_$TAG/*/; do
-    N=$(basename $D)
-    cp $D/kernel_stats.csv profiles/${TAG}_${N}_kernel_stats.csv
-    cp $D/pmc.json profiles/${TAG}_${N}_pmc.json
+for D in gpurun_out/crlb_$TAG/*/ gpurun_out/select_$TAG/*/; do
+    [ -d "$D" ] || continue                      # (the glob stays literal where the profile script has not been run: ADVICE r5)
+    N=$(basename "$D")
+    case "$D" in *select_*) N=select_$N;; esac
+    cp "$D/kernel_stats.csv" profiles/${TAG}_${N}_kernel_stats.csv
+    cp "$D/pmc.json" profiles/${TAG}_${N}_pmc.json
+    [ -f "$D/time.txt" ] && cp "$D/time.txt" profiles/${TAG}_${N}_time.txt
 done
 if [ -d gpurun_out/kpt_$TAG ]; then
     cp gpurun_out/kpt_$TAG/kernel_stats.csv profiles/${TAG}_kpt_kernel_stats.csv

@@ -15,6 +15,7 @@ cd "$ROOT"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench.json" 2> "$OUT/bench.log"
+[ -f bench_details.json ] && cp bench_details.json "$OUT/bench_details.json"
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
