@@ -36,10 +36,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # rocprofv3 --pmc passes of the default command (tools/profile.sh), committed; bench.py quotes its traffic / issue figures
-PMC_PROFILE = 'profiles/r05_ekf_pmc.json'
-ISSUE_TABLE = 'profiles/r05_issue_table.json'
-CRLB_PROFILES = {'ekf_full': 'profiles/r05_ekf_large_full_pmc.json', 'ekf_means': 'profiles/r05_ekf_large_means_pmc.json',
-                 'ghf_means': 'profiles/r05_ghf_large_means_pmc.json'}
+PMC_PROFILE = 'profiles/r06_ekf_pmc.json'
+ISSUE_TABLE = 'profiles/r06_issue_table.json'
+CRLB_PROFILES = {'ekf_full': 'profiles/r06_ekf_large_full_pmc.json', 'ekf_means': 'profiles/r06_ekf_large_means_pmc.json',
+                 'ghf_means': 'profiles/r06_ghf_large_means_pmc.json'}
 _SHA = {}
 
 
