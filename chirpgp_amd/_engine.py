@@ -105,10 +105,10 @@ def load_library():
         lib.cgp_custom_model_destroy.restype = None
         lib.cgp_custom_model_destroy.argtypes = [_vp]
         lib.cgp_filter_custom.restype = C.c_int
-        lib.cgp_filter_custom.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(CgpInit), C.c_double, _vp, C.c_int64, C.c_int64, _vp,
+        lib.cgp_filter_custom.argtypes = [_vp, _vp, C.POINTER(CgpSigma), _vp, C.c_int64, _vp, C.c_int64, C.POINTER(CgpInit), C.c_double, _vp, C.c_int64, C.c_int64, _vp,
                                           C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_smoother_custom.restype = C.c_int
-        lib.cgp_smoother_custom.argtypes = [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_double, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_smoother_custom.argtypes = [_vp, _vp, C.POINTER(CgpSigma), _vp, C.c_int64, _vp, C.c_int64, C.c_double, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
         lib.cgp_gaussian_expectation.restype = C.c_int
         lib.cgp_gaussian_expectation.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]
         lib.cgp_gaussian_expectation_fn.restype = C.c_int
@@ -487,9 +487,9 @@ def _custom_params(spec, gamma, B, keep):
     return params, (int(params.shape[-1]) if params.ndim == 2 else 0), g, (gs or 0)
 
 
-def run_filter_custom(spec, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, want=(True, True, True), flags=0):
-    """ekf / cd_ekf on a model compiled at run time (cgp_filter_custom): the generic one-lane-per-trial kernel instantiated on the
-    caller's source.  ys (T,) or (B, T)."""
+def run_filter_custom(spec, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, want=(True, True, True), flags=0, sgps=None):
+    """ekf / cd_ekf -- with `sgps`: sgp_filter / cd_sgp_filter -- on a model compiled at run time (cgp_filter_custom): the generic
+    one-lane-per-trial kernel instantiated on the caller's source.  ys (T,) or (B, T)."""
     torch = _torch()
     like_numpy = not _is_torch(ys)
     ys_d = dev(ys)
@@ -503,20 +503,21 @@ def run_filter_custom(spec, gamma, H, Xi, m0, P0, dt, ys, nll_final_only=False, 
         handle = custom_model(spec, ys_d.device.index)
         keep = [ys_d]
         params, pstride, g, gstride = _custom_params(spec, gamma, B, keep)
+        sig = _sigma_struct(sgps, d, keep, None)
         init = _init_struct(H, Xi, m0, P0, d, B, keep)
         opts = dict(dtype=torch.float64, device=ys_d.device)
         mfs = torch.empty((B, T, d), **opts) if want[0] else None
         Pfs = torch.empty((B, T, d, d), **opts) if want[1] else None
         nll = (torch.empty((B,) if nll_final_only else (B, T), **opts)) if want[2] else None
         fl = int(flags) | (NLL_FINAL_ONLY if nll_final_only else 0)
-        rc = _timed('filter', lambda: load_library().cgp_filter_custom(ctx, handle, _ptr(params), pstride, _ptr(g), gstride, C.byref(init), float(dt),
+        rc = _timed('filter', lambda: load_library().cgp_filter_custom(ctx, handle, C.byref(sig) if sig is not None else None, _ptr(params), pstride, _ptr(g), gstride, C.byref(init), float(dt),
                                                                        _ptr(ys_d), T, 1, None, B, T, _ptr(mfs), _ptr(Pfs), _ptr(nll), fl, _stream()))
         _check(ctx, rc, 'cgp_filter_custom')
         return tuple(None if t is None else _out(t, like_numpy, squeeze) for t in (mfs, Pfs, nll))
 
 
-def run_smoother_custom(spec, gamma, dt, mfs, Pfs, flags=0):
-    """eks / cd_eks on a model compiled at run time (cgp_smoother_custom)."""
+def run_smoother_custom(spec, gamma, dt, mfs, Pfs, flags=0, sgps=None):
+    """eks / cd_eks -- with `sgps`: sgp_smoother / cd_sgp_smoother -- on a model compiled at run time (cgp_smoother_custom)."""
     torch = _torch()
     like_numpy = not _is_torch(mfs)
     m, P = dev(mfs), dev(Pfs)
@@ -533,8 +534,9 @@ def run_smoother_custom(spec, gamma, dt, mfs, Pfs, flags=0):
         handle = custom_model(spec, m.device.index)
         keep = [m, P]
         params, pstride, g, gstride = _custom_params(spec, gamma, B, keep)
+        sig = _sigma_struct(sgps, d, keep, None)
         mss, Pss = torch.empty_like(m), torch.empty_like(P)
-        rc = _timed('smoother', lambda: load_library().cgp_smoother_custom(ctx, handle, _ptr(params), pstride, _ptr(g), gstride, float(dt), _ptr(m), _ptr(P),
+        rc = _timed('smoother', lambda: load_library().cgp_smoother_custom(ctx, handle, C.byref(sig) if sig is not None else None, _ptr(params), pstride, _ptr(g), gstride, float(dt), _ptr(m), _ptr(P),
                                                                            B, T, _ptr(mss), _ptr(Pss), int(flags), _stream()))
         _check(ctx, rc, 'cgp_smoother_custom')
         return _out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze)

@@ -11,7 +11,9 @@
 // the in-kernel counterpart of jacfwd -- for the Jacobian, exact to rounding.  CustomDisc / CustomSDE adapt it to the interface the
 // generic lane-per-trial kernels of cgp_kernels.hpp expect of a model (LinearDisc / LinearSDE), and the runtime-compiled program
 // instantiates filter_kernel<EkfPredict<..>>, smoother_kernel<EksStep<..>>, filter_kernel<CdEkfPredict<..>>, smoother_kernel<CdEksStep<..>>
-// on them: ekf, eks, cd_ekf, cd_eks for any model of dimension <= 8, same arithmetic as the compiled-in models.
+// on them -- ekf, eks, cd_ekf, cd_eks for any model of dimension <= 8, same arithmetic as the compiled-in models -- and the sigma-point
+// methods: sgp_filter / sgp_smoother through a literal fan (SgpPredictCustom: the covariance evaluated at every point), cd_sgp_filter /
+// cd_sgp_smoother through the generic CdSgpPredict / CdSgpsStep.
 #pragma once
 #include "cgp_kernels.hpp"
 
@@ -72,6 +74,7 @@ template <int D_, class U> struct CustomDisc {
     bool uniform = false, wide = false, large_batch = false;
     CGP_DEV void setup(const double* __restrict__ params, double dt_, int /*model_id*/) { p = params; dt = dt_; }
     CGP_DEV void mean(const Vec<D>& u, Vec<D>& f) const { U::template mean<double>(u.v, p, dt, f.v); }
+    CGP_DEV void mean_and_cov(const Vec<D>& u, Vec<D>& f, double (&cov)[D_ * D_]) const { U::template mean<double>(u.v, p, dt, f.v); U::cov(u.v, p, dt, cov); }
     // f = mean(u), T = J P with J = d mean / d u by dual numbers (jacfwd, filters_smoothers.py:255), Pp = T J^T + cov(u)
     CGP_DEV void propagate(const Vec<D>& u, const Sym<D>& P, Vec<D>& f, Mat<D>& T, Sym<D>& Pp) const {
         ad::Dual<D> x[D], y[D];
@@ -88,6 +91,60 @@ template <int D_, class U> struct CustomDisc {
     }
 };
 
+// Sigma-point prediction of a custom discrete model, filters_smoothers.py:88-121 as written -- one lane walks the whole point set
+// (read from global memory), the model's covariance is evaluated AT EVERY POINT (the enumerated models' is constant; a
+// caller's need not be) -- plus (CROSS) the smoother's D^T of :525.
+template <class DM, bool CROSS>
+CGP_DEV void sgp_prediction_literal(const DM& model, const SigmaSet& sg, const Vec<DM::D>& mf, const Sym<DM::D>& Pf,
+                                    Vec<DM::D>& mp, Sym<DM::D>& Pp, Mat<DM::D>& DT) {
+    constexpr int D = DM::D;
+    Sym<D> L; Vec<D> inv;
+    cholesky<D>(Pf, L, inv);
+    CGP_UNROLL for (int i = 0; i < D; i++) mp.v[i] = 0.0;
+    CGP_UNROLL for (int i = 0; i < Sym<D>::N; i++) Pp.a[i] = 0.0;
+    Mat<D> X;
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) X.a[i][j] = 0.0;
+    for (int p = 0; p < sg.s; p++) {
+        Vec<D> chi, f;
+        sigma_point<D, false>(mf, L, sg, p, chi);
+        double cov[D * D];
+        model.mean_and_cov(chi, f, cov);
+        const double w = sg.template weight<false>(p);
+        CGP_UNROLL for (int i = 0; i < D; i++) {
+            const double wf = w * f.v[i];
+            mp.v[i] += wf;
+            CGP_UNROLL for (int j = 0; j <= i; j++) Pp(i, j) = fma(wf, f.v[j], fma(w, cov[i * D + j], Pp(i, j)));
+            if (CROSS) { CGP_UNROLL for (int k = 0; k < D; k++) X.a[k][i] = fma(chi.v[k], wf, X.a[k][i]); }
+        }
+    }
+    CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j <= i; j++) Pp(i, j) -= mp.v[i] * mp.v[j];
+    if (CROSS) { CGP_UNROLL for (int i = 0; i < D; i++) CGP_UNROLL for (int j = 0; j < D; j++) DT.a[j][i] = X.a[i][j] - mf.v[i] * mp.v[j]; }
+}
+// sgp_filter (filters_smoothers.py:446-490) / sgp_smoother (:493-531) on a custom model, one lane per trial
+template <class DM> struct SgpPredictCustom {
+    static constexpr bool USES_SIGMA = true;
+    static constexpr bool LANE_TWO_WAVES = false;
+    static constexpr int D = DM::D; static constexpr bool WAVE = false; static constexpr bool USES_LDS = false;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void predict(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& mp, Sym<D>& Pp) const {
+        Mat<D> unused;
+        sgp_prediction_literal<DM, false>(model, sg, mf, Pf, mp, Pp, unused);
+    }
+};
+template <class DM> struct SgpsStepCustom {
+    static constexpr bool USES_SIGMA = true;
+    static constexpr int D = DM::D; static constexpr bool WAVE = false; static constexpr bool USES_LDS = false;
+    DM model; SigmaSet sg;
+    CGP_DEV void setup(const ModelArgs& a, int64_t trial) { model.setup(a.params + trial * a.param_stride, a.dt, a.model_id); sg = a.sg; }
+    CGP_DEV void step(int, double*, const Vec<D>& mf, const Sym<D>& Pf, Vec<D>& ms, Sym<D>& Ps) const {
+        Vec<D> mp; Sym<D> Pp; Mat<D> DT, G;
+        sgp_prediction_literal<DM, true>(model, sg, mf, Pf, mp, Pp, DT);
+        smoother_gain<D>(DT, Pp, G);
+        smoother_apply<D>(G, mf, Pf, mp, Pp, ms, Ps);
+    }
+};
+
 // SDE drift a(u) supplied as U::drift<T>: the interface of LinearSDE (cgp_models.hpp)
 template <int D_, class U> struct CustomSDE {
     static constexpr int D = D_;
@@ -95,6 +152,11 @@ template <int D_, class U> struct CustomSDE {
     bool uniform = false, wide = false;
     CGP_DEV void setup(const double* __restrict__ params, int /*model_id*/) { p = params; }
     CGP_DEV void drift(const Vec<D>& u, Vec<D>& a) const { U::template drift<double>(u.v, p, a.v); }
+    // sigma-point interface (cd_sgp_common, cgp_steps.hpp): nothing to share between the points of a group
+    static constexpr int IVC = 0;
+    struct Pre {};
+    CGP_DEV void precompute(double, Pre&) const {}
+    CGP_DEV void drift_pre(const Vec<D>& u, const Pre&, Vec<D>& a) const { drift(u, a); }
     CGP_DEV void drift_jac(const Vec<D>& u, Vec<D>& a, Mat<D>& J) const {
         ad::Dual<D> x[D], y[D];
         CGP_UNROLL for (int i = 0; i < D; i++) { x[i] = ad::Dual<D>(u.v[i]); x[i].d[i] = 1.0; }

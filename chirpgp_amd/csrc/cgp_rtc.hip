@@ -12,7 +12,7 @@ struct cgp_custom_model {
     int kind = 0, d = 0;
     int device = 0;
     hipModule_t module = nullptr;
-    hipFunction_t filter = nullptr, smoother = nullptr;
+    hipFunction_t filter = nullptr, smoother = nullptr, sgp_filter = nullptr, sgp_smoother = nullptr;
 };
 
 namespace {
@@ -56,11 +56,12 @@ Rtc& rtc() {
     return r;
 }
 
-ModelArgs custom_args(const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride, double dt) {
+// (the sigma-point set as a plain point list read from global memory: no groups, no LDS stage, no closed forms)
+ModelArgs custom_args(const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride, double dt, const cgp_sigma* sg) {
     ModelArgs ma;
     ma.params = params; ma.param_stride = param_stride; ma.gamma = gamma; ma.gamma_stride = gamma_stride;
     ma.model_id = -1; ma.dt = dt;
-    ma.sg.xi = nullptr; ma.sg.w = nullptr; ma.sg.s = 0; ma.sg.group_start = nullptr; ma.sg.n_groups = 0;
+    ma.sg.xi = sg ? sg->xi : nullptr; ma.sg.w = sg ? sg->w : nullptr; ma.sg.s = sg ? sg->s : 0; ma.sg.group_start = nullptr; ma.sg.n_groups = 0;
     ma.sg.lds_xi = 0; ma.sg.lds_w = 0; ma.sg.lds_gs = 0; ma.sg.lds_tab = 0; ma.sg.flags = 0u;
     return ma;
 }
@@ -86,23 +87,28 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
     std::string src = "#include \"cgp_custom.hpp\"\nnamespace cgp_user {\nusing namespace cgp::ad;\n#line 1 \"model\"\n";
     src += body;
     src += "\n}\nstruct CgpUserModel {\n";
-    std::string f_name, s_name;
+    std::string f_name, s_name, sf_name, ss_name;
     if (kind == CGP_CUSTOM_DISCRETE) {
         src += "    template <class T> __device__ static void mean(const T* u, const double* p, double dt, T* m) { cgp_user::cond_mean(u, p, dt, m); }\n"
                "    __device__ static void cov(const double* u, const double* p, double dt, double* c) { cgp_user::cond_cov(u, p, dt, c); }\n};\n"
                "using CgpUserM = cgp::CustomDisc<" + D + ", CgpUserModel>;\n";
         f_name = "cgp::filter_kernel<cgp::EkfPredict<CgpUserM, false>, cgp::LinearMeasurement<" + D + ">>";
         s_name = "cgp::smoother_kernel<cgp::EksStep<CgpUserM, false>>";
+        sf_name = "cgp::filter_kernel<cgp::SgpPredictCustom<CgpUserM>, cgp::LinearMeasurement<" + D + ">>";
+        ss_name = "cgp::smoother_kernel<cgp::SgpsStepCustom<CgpUserM>>";
     } else {
         src += "    template <class T> __device__ static void drift(const T* u, const double* p, T* a) { cgp_user::drift(u, p, a); }\n};\n"
                "using CgpUserM = cgp::CustomSDE<" + D + ", CgpUserModel>;\n";
         f_name = "cgp::filter_kernel<cgp::CdEkfPredict<CgpUserM, false>, cgp::LinearMeasurement<" + D + ">>";
         s_name = "cgp::smoother_kernel<cgp::CdEksStep<CgpUserM, false>>";
+        sf_name = "cgp::filter_kernel<cgp::CdSgpPredict<CgpUserM, false>, cgp::LinearMeasurement<" + D + ">>";
+        ss_name = "cgp::smoother_kernel<cgp::CdSgpsStep<CgpUserM, false>>";
     }
     void* prog = nullptr;
     if (R.CreateProgram(&prog, src.c_str(), "cgp_custom_model.hip", 0, nullptr, nullptr) != 0) return fail(ctx, CGP_E_HIP, "hiprtcCreateProgram failed");
     auto done = [&](int code, const std::string& msg) { R.DestroyProgram(&prog); return fail(ctx, code, msg); };
-    if (R.AddNameExpression(prog, f_name.c_str()) != 0 || R.AddNameExpression(prog, s_name.c_str()) != 0) return done(CGP_E_HIP, "hiprtcAddNameExpression failed");
+    if (R.AddNameExpression(prog, f_name.c_str()) != 0 || R.AddNameExpression(prog, s_name.c_str()) != 0 ||
+        R.AddNameExpression(prog, sf_name.c_str()) != 0 || R.AddNameExpression(prog, ss_name.c_str()) != 0) return done(CGP_E_HIP, "hiprtcAddNameExpression failed");
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
     const std::string inc1 = std::string("-I") + include_dir, inc2 = std::string("-I") + include_dir + "/../../include";
     const char* opts[] = {arch.c_str(), "-std=c++17", "-O3", "-fno-fast-math", inc1.c_str(), inc2.c_str()};
@@ -114,16 +120,18 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
         if (log.size() > 6000) log.resize(6000);
         return done(CGP_E_ARG, "the model source does not compile:\n" + log);
     }
-    const char *f_low = nullptr, *s_low = nullptr;
+    const char *f_low = nullptr, *s_low = nullptr, *sf_low = nullptr, *ss_low = nullptr;
     size_t size = 0;
-    if (R.GetLoweredName(prog, f_name.c_str(), &f_low) != 0 || R.GetLoweredName(prog, s_name.c_str(), &s_low) != 0 || R.GetCodeSize(prog, &size) != 0)
+    if (R.GetLoweredName(prog, f_name.c_str(), &f_low) != 0 || R.GetLoweredName(prog, s_name.c_str(), &s_low) != 0 ||
+        R.GetLoweredName(prog, sf_name.c_str(), &sf_low) != 0 || R.GetLoweredName(prog, ss_name.c_str(), &ss_low) != 0 || R.GetCodeSize(prog, &size) != 0)
         return done(CGP_E_HIP, "hiprtc: no lowered names / code");
     std::vector<char> code(size);
     if (R.GetCode(prog, code.data()) != 0) return done(CGP_E_HIP, "hiprtcGetCode failed");
     cgp_custom_model* m = new cgp_custom_model;
     m->kind = kind; m->d = d; m->device = ctx->device;
     if (hipModuleLoadData(&m->module, code.data()) != hipSuccess || hipModuleGetFunction(&m->filter, m->module, f_low) != hipSuccess ||
-        hipModuleGetFunction(&m->smoother, m->module, s_low) != hipSuccess) {
+        hipModuleGetFunction(&m->smoother, m->module, s_low) != hipSuccess || hipModuleGetFunction(&m->sgp_filter, m->module, sf_low) != hipSuccess ||
+        hipModuleGetFunction(&m->sgp_smoother, m->module, ss_low) != hipSuccess) {
         const std::string why = hipGetErrorString(hipGetLastError());
         if (m->module) (void)hipModuleUnload(m->module);
         delete m;
@@ -143,7 +151,7 @@ void cgp_custom_model_destroy(cgp_custom_model* m) {
     delete m;
 }
 
-int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* m, const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride,
+int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* m, const cgp_sigma* sigma, const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride,
                       const cgp_init* init, double dt, const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index,
                       int64_t B, int64_t T, double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream) {
     if (!ctx) return CGP_E_ARG;
@@ -163,14 +171,15 @@ int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* m, const double* par
     io.m0 = init->m0; io.m0_stride = init->m0_stride; io.P0 = init->P0; io.P0_stride = init->P0_stride;
     io.ys = ys; io.ys_stride = ys_stride; io.ys_repeat = ys_repeat; io.ys_index = ys_index; io.B = B; io.T = T;
     io.mfs = mfs; io.Pfs = Pfs; io.nll = nll; io.flags = flags & CGP_NLL_FINAL_ONLY;
-    ModelArgs ma = custom_args(params, param_stride, gamma, gamma_stride, dt);
+    if (sigma && (!sigma->xi || !sigma->w || sigma->s < 1 || sigma->d != m->d)) return fail(ctx, CGP_E_ARG, "cgp_sigma needs xi, w, s >= 1 and d = the model's");
+    ModelArgs ma = custom_args(params, param_stride, gamma, gamma_stride, dt, sigma);
     void* args[] = {&io, &ma};
-    if (hipModuleLaunchKernel(m->filter, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
+    if (hipModuleLaunchKernel(sigma ? m->sgp_filter : m->filter, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
         return fail(ctx, CGP_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return CGP_OK;
 }
 
-int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* m, const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride,
+int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* m, const cgp_sigma* sigma, const double* params, int64_t param_stride, const double* gamma, int64_t gamma_stride,
                         double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T, double* mss, double* Pss, uint32_t flags, void* stream) {
     if (!ctx) return CGP_E_ARG;
     if (!m) return fail(ctx, CGP_E_ARG, "model is NULL");
@@ -184,9 +193,10 @@ int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* m, const double* p
     std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
-    ModelArgs ma = custom_args(params, param_stride, gamma, gamma_stride, dt);
+    if (sigma && (!sigma->xi || !sigma->w || sigma->s < 1 || sigma->d != m->d)) return fail(ctx, CGP_E_ARG, "cgp_sigma needs xi, w, s >= 1 and d = the model's");
+    ModelArgs ma = custom_args(params, param_stride, gamma, gamma_stride, dt, sigma);
     void* args[] = {&io, &ma};
-    if (hipModuleLaunchKernel(m->smoother, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
+    if (hipModuleLaunchKernel(sigma ? m->sgp_smoother : m->smoother, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
         return fail(ctx, CGP_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return CGP_OK;
 }

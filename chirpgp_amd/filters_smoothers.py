@@ -108,25 +108,33 @@ def cd_eks(a, b, mfs, Pfs, dt, **kw):
 
 def sgp_filter(cond_m_cov, sgps, H, Xi, m0, P0, dt, ys, **kw):
     """Sigma-point (Gauss-Hermite / cubature) filter on a discretised model (filters_smoothers.py:446-490)."""
-    spec = _enumerated(_discrete(cond_m_cov, dt), 'sgp_filter')
+    spec = _discrete(cond_m_cov, dt)
+    if isinstance(spec, M.CustomDiscrete):            # a model compiled at run time: the literal fan, covariance at every point
+        return E.run_filter_custom(spec, None, H, Xi, m0, P0, dt, ys, sgps=_sgps(sgps, spec.d), **_custom_kw(kw))
     return E.run_filter(E.F_SGP, spec, _sgps(sgps, spec.d), None, H, Xi, m0, P0, dt, ys, **kw)
 
 
 def sgp_smoother(cond_m_cov, sgps, mfs, Pfs, dt, **kw):
     """Sigma-point smoother (filters_smoothers.py:493-531)."""
-    spec = _enumerated(_discrete(cond_m_cov, dt), 'sgp_smoother')
+    spec = _discrete(cond_m_cov, dt)
+    if isinstance(spec, M.CustomDiscrete):
+        return E.run_smoother_custom(spec, None, dt, mfs, Pfs, sgps=_sgps(sgps, spec.d), **_custom_kw(kw, ('flags',)))
     return E.run_smoother(E.S_SGP, spec, _sgps(sgps, spec.d), None, dt, mfs, Pfs, **kw)
 
 
 def cd_sgp_filter(a, b, sgps, H, Xi, m0, P0, dt, ys, **kw):
     """Continuous-discrete sigma-point filter; b is the constant (d, dw) dispersion matrix (filters_smoothers.py:534-582)."""
-    spec = _enumerated(_drift(a), 'cd_sgp_filter')
+    spec = _drift(a)
+    if isinstance(spec, M.CustomDrift):
+        return E.run_filter_custom(spec, _gamma_from_matrix(b), H, Xi, m0, P0, dt, ys, sgps=_sgps(sgps, spec.d), **_custom_kw(kw))
     return E.run_filter(E.F_CD_SGP, spec, _sgps(sgps, spec.d), _gamma_from_matrix(b), H, Xi, m0, P0, dt, ys, **kw)
 
 
 def cd_sgp_smoother(a, b, sgps, mfs, Pfs, dt, **kw):
     """Continuous-discrete sigma-point smoother (filters_smoothers.py:585-632)."""
-    spec = _enumerated(_drift(a), 'cd_sgp_smoother')
+    spec = _drift(a)
+    if isinstance(spec, M.CustomDrift):
+        return E.run_smoother_custom(spec, _gamma_from_matrix(b), dt, mfs, Pfs, sgps=_sgps(sgps, spec.d), **_custom_kw(kw, ('flags',)))
     return E.run_smoother(E.S_CD_SGP, spec, _sgps(sgps, spec.d), _gamma_from_matrix(b), dt, mfs, Pfs, **kw)
 
 
@@ -136,13 +144,6 @@ def _custom_kw(kw, allowed=('nll_final_only', 'want', 'flags')):
     if extra:
         raise TypeError(f'custom models take {" / ".join(allowed)} only, not {sorted(extra)}')
     return kw
-
-
-def _enumerated(spec, what):
-    if isinstance(spec, (M.CustomDiscrete, M.CustomDrift)):
-        raise NotImplementedError(f'{what}: models compiled at run time run the EKF-type methods (ekf, eks, cd_ekf, cd_eks); the sigma-point '
-                                  f'kernels take the enumerated models')
-    return spec
 
 
 def _np(x):

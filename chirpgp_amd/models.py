@@ -197,7 +197,8 @@ class CustomDrift(_CustomSpec):
 
 def custom_cond_m_cov(source, d, params, host=None):
     """Descriptor of a discrete model the library does not enumerate -- what the reference takes as any traceable ``cond_m_cov(u, dt)``
-    (filters_smoothers.py:222-264, 317-349): usable with ``ekf`` and ``eks``.  ``source`` is HIP device code defining, for a generic scalar
+    (filters_smoothers.py:222-264, 317-349, 446-531): usable with ``ekf``, ``eks``, ``sgp_filter`` and ``sgp_smoother`` (the covariance is
+    evaluated at every sigma point, as the reference's ``_sgp_prediction`` does).  ``source`` is HIP device code defining, for a generic scalar
     type T (double, or the dual numbers the kernel differentiates with: sin, cos, exp, log, sqrt, tanh, pow(x, const) and softplus are
     overloaded),
 
@@ -210,7 +211,8 @@ def custom_cond_m_cov(source, d, params, host=None):
 
 
 def custom_sde(source, d, params, dispersion, host=None):
-    """(drift, dispersion) descriptors of an SDE model as source -- ``cd_ekf`` / ``cd_eks`` (filters_smoothers.py:352-443):
+    """(drift, dispersion) descriptors of an SDE model as source -- ``cd_ekf`` / ``cd_eks`` / ``cd_sgp_filter`` / ``cd_sgp_smoother``
+    (filters_smoothers.py:352-443, 534-632):
 
         template <class T> __device__ void drift(const T* u, const double* p, T* a);
 

@@ -233,7 +233,8 @@ int cgp_ekf_nll_grad(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init,
 /* ---- models compiled at run time ------------------------------------------------------------------------------------------
  * The reference's filters take any JAX-traceable callable (filters_smoothers.py:255, 304, 382, 425); the enumerated models above are the
  * reference's own builders.  A model outside that set is handed over as device source and compiled by ROCm's runtime compiler (hiprtc)
- * into the generic one-lane-per-trial kernels -- ekf / eks for a discrete model, cd_ekf / cd_eks for an SDE -- with its Jacobian taken
+ * into the generic one-lane-per-trial kernels -- ekf / eks / sgp_filter / sgp_smoother for a discrete model, cd_ekf / cd_eks /
+ * cd_sgp_filter / cd_sgp_smoother for an SDE: every filter and smoother of the reference that takes a callable -- with its Jacobian taken
  * by forward-mode dual numbers in the kernel (the counterpart of jax.jacfwd; csrc/cgp_custom.hpp).  `body` defines, for a generic scalar
  * type T (double or a dual number; sin, cos, exp, log, sqrt, tanh, pow(x, const), softplus are overloaded for it),
  *     CGP_CUSTOM_DISCRETE:   template <class T> __device__ void cond_mean(const T* u, const double* p, double dt, T* mean);
@@ -247,13 +248,15 @@ typedef struct cgp_custom_model cgp_custom_model;
 #define CGP_CUSTOM_SDE      1
 int  cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, const char* include_dir, cgp_custom_model** out);
 void cgp_custom_model_destroy(cgp_custom_model* model);
-/* ekf (filters_smoothers.py:222-264) / cd_ekf (:352-397) on a compiled model; arguments as cgp_filter */
-int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* model, const double* params, int64_t param_stride,
+/* ekf (filters_smoothers.py:222-264) / cd_ekf (:352-397) on a compiled model -- or, with a sigma-point set (a plain point list: xi, w, s, d;
+ * groups and flags are not read), sgp_filter (:446-490) / cd_sgp_filter (:534-582); the other arguments as cgp_filter.  The discrete
+ * model's covariance is evaluated at every sigma point (filters_smoothers.py:118-120 as written). */
+int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* model, const cgp_sigma* sigma, const double* params, int64_t param_stride,
                       const double* gamma, int64_t gamma_stride, const cgp_init* init, double dt,
                       const double* ys, int64_t ys_stride, int64_t ys_repeat, const int32_t* ys_index, int64_t B, int64_t T,
                       double* mfs, double* Pfs, double* nll, uint32_t flags, void* stream);
-/* eks (:317-349) / cd_eks (:400-443) on a compiled model; arguments as cgp_smoother */
-int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* model, const double* params, int64_t param_stride,
+/* eks (:317-349) / cd_eks (:400-443) -- with a sigma-point set sgp_smoother (:493-531) / cd_sgp_smoother (:585-632) -- on a compiled model */
+int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* model, const cgp_sigma* sigma, const double* params, int64_t param_stride,
                         const double* gamma, int64_t gamma_stride, double dt, const double* mfs, const double* Pfs,
                         int64_t B, int64_t T, double* mss, double* Pss, uint32_t flags, void* stream);
 

@@ -107,6 +107,41 @@ def test_lorenz63_of_the_references_own_test_on_the_hip_path():
     assert disc(np.ones(3), dt)[0].shape == (3,)            # the host callable rides along
 
 
+def test_sigma_point_methods_on_custom_models():
+    """sgp_filter / sgp_smoother / cd_sgp_filter / cd_sgp_smoother on Lorenz-63 as source (cubature and Gauss-Hermite order 3), against the
+    NumPy oracle on the same callables -- a discretisation whose COVARIANCE depends on the state, so the fan has to evaluate it at every
+    point (filters_smoothers.py:118-120), which the enumerated models never exercise."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import np_filters as nf
+    drift, m_and_cov = lorenz_host()
+    dt, T, Xi = 1e-3, 600, 2.
+    H, m0, P0 = np.array([1., 0., 0.]), np.zeros(3), np.eye(3)
+    ys = np.stack([lorenz_data(T, dt, Xi, seed=700 + i) for i in range(3)])
+    p = np.array([KAPPA, LAM, MU, 25.])
+    disc = pm.custom_cond_m_cov(LORENZ, 3, p, host=m_and_cov)
+    sde, disp = pm.custom_sde(LORENZ, 3, p, 5. * np.eye(3), host=drift)
+    b = 5. * np.eye(3)
+    for sg in (SigmaPoints.cubature(3), SigmaPoints.gauss_hermite(3, 3)):
+        osg = cs.osig(sg)
+        f = fs.sgp_filter(disc, sg, H, Xi, m0, P0, dt, ys)
+        cf = fs.cd_sgp_filter(sde, b, sg, H, Xi, m0, P0, dt, ys)
+        for i in range(3):
+            wf = nf.sgp_filter(m_and_cov, osg, H, Xi, m0, P0, dt, ys[i])
+            wcf = nf.cd_sgp_filter(drift, b, osg, H, Xi, m0, P0, dt, ys[i])
+            for g, w, n in zip(f, wf, ('m', 'P', 'nll')):
+                cs.assert_close(g[i], w, 1e-9, f'sgp_filter {sg.n_points} points {n}')
+            for g, w, n in zip(cf, wcf, ('m', 'P', 'nll')):
+                cs.assert_close(g[i], w, 1e-9, f'cd_sgp_filter {sg.n_points} points {n}')
+            if i == 0:
+                ws = nf.sgp_smoother(m_and_cov, osg, wf[0], wf[1], dt)
+                wcs = nf.cd_sgp_smoother(drift, b, osg, wcf[0], wcf[1], dt)
+                for g, w, n in zip(fs.sgp_smoother(disc, sg, wf[0], wf[1], dt), ws, ('m', 'P')):
+                    cs.assert_close(g, w, 1e-9, f'sgp_smoother {sg.n_points} points {n}')
+                for g, w, n in zip(fs.cd_sgp_smoother(sde, b, sg, wcf[0], wcf[1], dt), wcs, ('m', 'P')):
+                    cs.assert_close(g, w, 1e-9, f'cd_sgp_smoother {sg.n_points} points {n}')
+
+
 CHIRP = r'''
 // the chirp LCD model of models.py:264-311 written as a custom model: p = [lam, b, ell, sigma]
 template <class T> __device__ void cond_mean(const T* u, const double* p, double dt, T* m) {
@@ -165,8 +200,8 @@ def test_errors_are_named():
     with pytest.raises(RuntimeError, match='undefined_symbol'):
         fs.ekf(bad, np.array([0., 1., 0., 0.]), 0.1, np.zeros(4), np.eye(4), 1e-3, np.zeros(10))
     ok = pm.custom_cond_m_cov(CHIRP, 4, np.array([0.1, 0.1, 1., 1.]))
-    with pytest.raises(NotImplementedError, match='EKF-type'):
-        fs.sgp_filter(ok, SigmaPoints.cubature(4), np.array([0., 1., 0., 0.]), 0.1, np.zeros(4), np.eye(4), 1e-3, np.zeros(10))
+    with pytest.raises(ValueError, match='sigma points are for d'):
+        fs.sgp_filter(ok, SigmaPoints.cubature(3), np.array([0., 1., 0., 0.]), 0.1, np.zeros(4), np.eye(4), 1e-3, np.zeros(10))
     with pytest.raises(TypeError, match='time_split'):
         fs.ekf(ok, np.array([0., 1., 0., 0.]), 0.1, np.zeros(4), np.eye(4), 1e-3, np.zeros(10), time_split=(2, 64))
     with pytest.raises(RuntimeError, match='dimension'):
