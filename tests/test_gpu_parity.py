@@ -552,7 +552,7 @@ def test_lockstep_mle_matches_per_record_fits():
     for r in range(R):
         single, res = mle.fit('ekf', pm.build_chirp_model, init, recs[r], 0.1, 1e-3, maxiter=120)
         assert info['fun'][r] <= res.fun + 1e-3 * abs(res.fun), (r, info['fun'][r], res.fun)
-        assert abs(info['fun'][r] - res.fun) <= 2e-2 * abs(res.fun)
+        assert abs(info['fun'][r] - res.fun) <= 1e-6 * abs(res.fun)      # (measured 4e-10 .. 2e-8; the gate was 2e-2 up to round 5)
 
 
 def test_four_trials_per_wave_dense_variant_at_large_batch():
