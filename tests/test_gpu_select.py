@@ -253,3 +253,22 @@ def test_raw_c_abi():
     rc = lib.cgp_smoother_select(ctx, E.S_EKS, C.byref(model), None, c.dt, m.data_ptr(), P.data_ptr(), 6, 300, C.byref(o), GENERIC | WAVE, st)
     assert rc == -2 and b'mss and Pss' in lib.cgp_last_error(ctx)
     assert lib.cgp_smoother_select(ctx, E.S_EKS, C.byref(model), None, c.dt, m.data_ptr(), P.data_ptr(), 6, 300, None, 0, st) == -1
+
+
+def test_one_step_records_and_empty_batches():
+    """T = 1: the smoother returns the filtering row (filters_smoothers.py:140-142) and the selection is that row's marginal, in every
+    launch shape; an empty batch returns empty selections."""
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    c = cs.chirp_case(T=1, seed=3)
+    for B in (1, 3, 70):
+        ys = np.zeros((B, 1)) + c.ys[None, :]
+        f = port.filter(port.F_EKF, c.disc, None, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+        for flags in (WAVE, LANE, WAVE | TIME_SPLIT):
+            mss, Pss, sel = fs.eks(c.disc, f[0], f[1], c.dt, flags=flags, select=dict(comp=2, **ALL))
+            np.testing.assert_array_equal(mss, f[0])
+            np.testing.assert_array_equal(sel['mean'], f[0][..., 2])
+            np.testing.assert_array_equal(sel['var'], f[1][..., 2, 2])
+            cs.assert_close(sel['expect'], _oracle_expect(f[0][..., 2], f[1][..., 2, 2]), 1e-12, 'T = 1 expect')
+    e = fs.eks(c.disc, np.zeros((0, 5, 4)), np.zeros((0, 5, 4, 4)), c.dt, want=(False, False), select=dict(comp=2, mean=True))
+    assert e[0] is None and e[2]['mean'].shape == (0, 5)
