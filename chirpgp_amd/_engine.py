@@ -800,7 +800,7 @@ def debug_philox(ctr, key):
     return out.cpu().numpy().view(np.uint32)
 
 
-DBG_WALK_SEGMENTS, DBG_COUNT_REGIMES = 1, 2
+DBG_WALK_SEGMENTS, DBG_COUNT_REGIMES, DBG_LANE_BUFFERS = 1, 2, 3
 REGIME_COUNTERS = ('high', 'common', 'redone', 'checked', 'high_left', 'wide', 'low', 'mid')
 
 

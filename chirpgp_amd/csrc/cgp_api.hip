@@ -292,6 +292,10 @@ int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value) {
         if (value < 0 || value > 4096) return fail(ctx, CGP_E_ARG, "CGP_DBG_WALK_SEGMENTS outside 0..4096");
         ctx->walk_segments = (int)value;
         return CGP_OK;
+    case CGP_DBG_LANE_BUFFERS:
+        if (value != 0 && value != 2 && value != 3) return fail(ctx, CGP_E_ARG, "CGP_DBG_LANE_BUFFERS: 0 (default), 2 or 3");
+        ctx->lane_buffers = (int)value;
+        return CGP_OK;
     case CGP_DBG_COUNT_REGIMES: {
         if (value != 0 && !ctx->counters_mem) {
             DeviceScope on_device(ctx->device);
@@ -505,6 +509,7 @@ static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const
     SmootherIO io;
     io.mfs = mfs; io.Pfs = Pfs; io.B = B; io.T = T; io.mss = mss; io.Pss = Pss; io.flags = flags;
     io.host_ctx = ctx;
+    io.lane_buffers = ctx->lane_buffers;
     // Time-split form of the discrete wave-per-trial smoothers: when the batch leaves two thirds of the SIMDs idle (or on
     // request).  cgp_debug_set(CGP_DBG_WALK_SEGMENTS) caps the number of segments of this context (tuning aid).
     io.num_cus = ctx->num_cus;

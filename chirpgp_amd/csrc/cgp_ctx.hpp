@@ -9,6 +9,7 @@ struct cgp_ctx {
     int device;
     int num_cus;
     int walk_segments = 0;                       // cgp_debug_set(CGP_DBG_WALK_SEGMENTS): 0 = choose, 1 = off, n = cap
+    int lane_buffers = 0;                        // cgp_debug_set(CGP_DBG_LANE_BUFFERS): 0 / 2 = default (rows requested one step ahead), 3 = two where the LDS allows
     unsigned long long* counters = nullptr;      // cgp_debug_set(CGP_DBG_COUNT_REGIMES): eight device counters, NULL = off
     unsigned long long* counters_mem = nullptr;  // the allocation (kept while counting is switched off)
     // Scratch of the time-split launches (segment records of cgp_filter_time_split, composed maps of the time-split smoothers):

@@ -187,6 +187,7 @@ struct SmootherIO {
     double* __restrict__ ws = nullptr;
     cgp_ctx* host_ctx = nullptr;  // host side only: the context whose per-stream workspace (cgp::ctx_workspace) serves `ws`
     SmoothSel sel;                // cgp_smoother_select: selected outputs (mss / Pss may then be NULL); comp < 0: off
+    int lane_buffers = 0;         // host side: cgp_debug_set(CGP_DBG_LANE_BUFFERS) -- 3 = the large-batch smoothers request their rows two steps ahead, else one
 };
 
 // Dynamic LDS (sized by the launch): the staged sigma-point set.  The static LDS in front of it (the 17 152-byte

@@ -53,6 +53,16 @@ CGP_DEV void lane4_dma_y(unsigned lds_base, const double* __restrict__ rec, int6
 }
 // Wait until all but the N youngest vector-memory operations of this wavefront are done (N a compile-time constant).
 template <int N> CGP_DEV void lane4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+// ... N a wave-uniform run-time multiple of four up to 40 (anything else: wait for everything)
+CGP_DEV void lane4_wait_vm_n(int n) {
+    switch (n) {
+    case 4: lane4_wait_vm<4>(); break;    case 8: lane4_wait_vm<8>(); break;    case 12: lane4_wait_vm<12>(); break;
+    case 16: lane4_wait_vm<16>(); break;  case 20: lane4_wait_vm<20>(); break;  case 24: lane4_wait_vm<24>(); break;
+    case 28: lane4_wait_vm<28>(); break;  case 32: lane4_wait_vm<32>(); break;  case 36: lane4_wait_vm<36>(); break;
+    case 40: lane4_wait_vm<40>(); break;
+    default: lane4_wait_vm<0>();
+    }
+}
 
 // WHOLE LINES ONLY.  tools/ubench/store_pattern.hip, same bytes: 4.7 ms when every store instruction fills 128-byte lines, 6.1 - 6.3 ms
 // when the 8-byte NLL stream alone leaves in aligned 64-byte halves or in 128-byte chunks that straddle two lines (a record of T = 500
@@ -355,15 +365,19 @@ CGP_DEV unsigned lane4_row_piece(int lane, int p) {
 // SELN = steps per flush: 16 (whole lines) for ONE selected output; 8 (aligned half lines, written 8 steps apart by the same wavefront) for
 // two or three -- their 16-step buffers would take the workgroup past 40 KB of LDS, three workgroups a CU instead of four.
 template <int SELN> struct Lane4Sel { static constexpr int PITCH = 65, DOUBLES = SELN * 65, LPT = SELN / 2, TPI = 64 / LPT; };
-template <class Step, int SELN = 0>
+// NBUF (round 6): covariance-row buffers -- rows are requested NBUF - 1 steps ahead.  Two (one step ahead) is what launches use; three
+// (where the LDS allows a third buffer beside four workgroups a CU) is kept behind CGP_DBG_LANE_BUFFERS as a measured negative result.
+// FULL: the kernel may write full rows (the 3 KB transpose tile exists); a launch with the selected outputs alone runs the variant without.
+template <class Step, int SELN = 0, int NBUF = 2, bool FULL = true>
 __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, ModelArgs ma, int period) {
     constexpr bool SEL = SELN > 0;
+    static_assert(FULL || SEL, "a launch without full rows selects something");
     using LS = Lane4Sel<SEL ? SELN : 16>;
     static_assert(Step::D == 4 && !Step::WAVE && !Step::USES_SIGMA, "one lane per trial, d = 4, no sigma-point set");
     constexpr int D = 4;
-    __shared__ __attribute__((aligned(16))) double pin[2 * Lane4S::ROWS];
+    __shared__ __attribute__((aligned(16))) double pin[NBUF * Lane4S::ROWS];
     __shared__ __attribute__((aligned(16))) double min_[Lane4S::ROWS];
-    __shared__ __attribute__((aligned(16))) double tile[Lane4::TILE];
+    __shared__ __attribute__((aligned(16))) double tile[FULL ? Lane4::TILE : 2];
     __shared__ double lds[Step::USES_LDS ? kFanLdsDoubles : 1];
     __shared__ double ghrule[SEL ? 2 * kGhMaxOrder : 1];
     const int lane = threadIdx.x;
@@ -381,7 +395,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
     const int64_t T = io.T;
     const double* __restrict__ mfs = io.mfs + trial * T * D;
     const double* __restrict__ Pfs = io.Pfs + trial * T * D * D;
-    const bool want_m = !SEL || io.mss != nullptr, want_P = !SEL || io.Pss != nullptr;      // (wave-uniform)
+    const bool want_m = FULL && (!SEL || io.mss != nullptr), want_P = FULL && (!SEL || io.Pss != nullptr);      // (wave-uniform)
     double* __restrict__ mss = want_m ? io.mss + trial * T * D : nullptr;
     double* __restrict__ Pss = want_P ? io.Pss + trial * T * D * D : nullptr;
     // the selected outputs: `nsel` arrays parked in the dynamic LDS in the order mean, variance, expectation
@@ -434,7 +448,6 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
         }
         const unsigned rowS = (unsigned)(T * period) * 8u;
         const int nflush = SEL ? LS::LPT * ((sel_m ? 1 : 0) + (sel_v ? 1 : 0) + (sel_e ? 1 : 0)) : 0;      // store instructions of one flush
-        int pending = 0;                                                 // ... issued since the last DMA request (SEL without full outputs)
         const int sub = lane >> 3, pc = lane & 7;
         const unsigned rowP = (unsigned)(T * period) * 128u, rowM = (unsigned)(T * period) * 32u;
         const int64_t t_hi = a_lo + 4 * nq - 1;                          // the first row of the quads (processed downwards)
@@ -458,40 +471,33 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
         unsigned rd[8];                                                  // this lane's row pieces in a DMA-ed set
         CGP_UNROLL for (int p = 0; p < 8; p++) rd[p] = lane4_row_piece(lane, p);
 
+        constexpr int AHEAD = NBUF - 1;                                  // steps between a row's request and its use
         lane4_dma_rows(mbase, gM + (t_hi - 3) * 4, tr_step * 4, sub, nvalid, lastM + (t_hi - 3) * 4);
-        lane4_dma_rows(pbase, gP + t_hi * 16, tr_step * 16, sub, nvalid, lastP + t_hi * 16);
+        CGP_UNROLL for (int j = 0; j < AHEAD; j++)
+            if (t_hi - j >= a_lo) lane4_dma_rows(pbase + (unsigned)j * (Lane4S::ROWS * 8u), gP + (t_hi - j) * 16, tr_step * 16, sub, nvalid, lastP + (t_hi - j) * 16);
         int cur = 0;
-        bool first = true;
+        // What was issued behind the request of the row about to be used, and may stay in flight across the wait (in-order completion):
+        // the requests of the AHEAD - 1 rows after it, and the previous step's line of means and stores.
+        int younger = 0;                                                 // ... of the previous step: its DMA of means + its stores
         for (int64_t k = nq - 1; k >= 0; k--) {
             const int64_t a = a_lo + 4 * k;
             double mq[16], mh[16];
             CGP_UNROLL for (int s4 = 3; s4 >= 0; s4--) {
                 const int64_t t = a + s4;
-                // this row's covariances were requested a step ago: wait for them, not for the stores issued since (8 covariance stores;
-                // behind the last row of a quad also 8 stores of means)
-                if constexpr (SEL) {
-                    // counted only where nothing but a flush was stored since the request (the selected outputs alone: the fast case)
-                    if (first || want_P || want_m || pending == 0) lane4_wait_vm<0>();
-                    else if (pending == 4) lane4_wait_vm<4>();
-                    else if (pending == 8) lane4_wait_vm<8>();
-                    else if (pending == 12) lane4_wait_vm<12>();
-                    else if (pending == 16) lane4_wait_vm<16>();
-                    else if (pending == 24) lane4_wait_vm<24>();
-                    else lane4_wait_vm<0>();
-                    pending = 0;
-                } else {
-                    if (first) lane4_wait_vm<0>();
-                    else if (s4 == 3) lane4_wait_vm<16>();
-                    else lane4_wait_vm<8>();
+                {
+                    int rows_behind = 0;                                 // row requests younger than this row's: rows t - 1 .. t - AHEAD + 1
+                    CGP_UNROLL for (int j = 1; j < AHEAD; j++) rows_behind += (t - j >= a_lo) ? 8 : 0;
+                    lane4_wait_vm_n(rows_behind + younger);
+                    younger = 0;
                 }
-                first = false;
-                if (t > a_lo) lane4_dma_rows(pbase + (unsigned)(cur ^ 1) * (Lane4S::ROWS * 8u), gP + (t - 1) * 16, tr_step * 16, sub, nvalid, lastP + (t - 1) * 16);
+                if (t - AHEAD >= a_lo)
+                    lane4_dma_rows(pbase + (unsigned)((cur + AHEAD) % NBUF) * (Lane4S::ROWS * 8u), gP + (t - AHEAD) * 16, tr_step * 16, sub, nvalid, lastP + (t - AHEAD) * 16);
                 if (s4 == 3) {
                     CGP_UNROLL for (int p = 0; p < 8; p++) {
                         const double2 v = *reinterpret_cast<const double2*>(min_b + rd[p]);
                         mq[2 * p] = v.x; mq[2 * p + 1] = v.y;
                     }
-                    if (k > 0) lane4_dma_rows(mbase, gM + (a - 4) * 4, tr_step * 4, sub, nvalid, lastM + (a - 4) * 4);
+                    if (k > 0) { lane4_dma_rows(mbase, gM + (a - 4) * 4, tr_step * 4, sub, nvalid, lastM + (a - 4) * 4); younger += 8; }
                 }
                 Vec<D> mf; Sym<D> Pf;
                 CGP_UNROLL for (int i = 0; i < D; i++) mf.v[i] = mq[4 * s4 + i];
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                             if (sel_e) wSe.store2(selE[at + LS::TPI * i], selE[at + LS::PITCH + LS::TPI * i], off0 + (unsigned)(i * LS::TPI) * rowS);
                         }
                         wave_lds_fence();
-                        pending = nflush;
+                        younger += nflush;
                     }
                 }
                 if (want_P) {
@@ -536,10 +542,11 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                             wP.store2(tPa[i * 8 * Lane4::PITCH_P], tPb[i * 8 * Lane4::PITCH_P], voffP + (unsigned)(4 * h + i) * 8u * rowP);
                         wave_lds_fence();
                     }
+                    younger += 8;
                 }
                 voffP -= 128u;
                 CGP_UNROLL for (int i = 0; i < D; i++) mh[4 * s4 + i] = ms.v[i];
-                cur ^= 1;
+                cur = (cur + 1) % NBUF;
             }
             if (want_m) {
                 // (the passes are NOT pipelined as in the filter: at one wavefront per SIMD with all 256 registers taken, the reads held back
@@ -556,6 +563,7 @@ __global__ void __launch_bounds__(64) lane4_smoother_kernel(SmootherIO io, Model
                     }
                     wave_lds_fence();
                 }
+                younger += 8;
             }
             voffM -= 128u;
         }
@@ -572,22 +580,34 @@ inline int lane4_smoother_period(int64_t T) {
 template <class Step>
 inline hipError_t launch_lane4_smoother(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return hipSuccess;
+    // covariance rows requested one step ahead (default) or, cgp_debug_set(CGP_DBG_LANE_BUFFERS, 3), two: measured at 262 144 x 500 on MI355X, no
+    // gain -- full rows 8.2 -> 8.2 ms, the marginal alone 4.91 -> 4.86, E[g] alone 8.95 -> 8.85: the prefetch depth is not what limits the kernel
+    const bool three = io.lane_buffers == 3;
     if (io.sel.comp >= 0) {
         // selected outputs: trials grouped by the phase of their [B][T] rows against the flushed blocks (16 or 8 doubles)
         const int nsel = (io.sel.mean ? 1 : 0) + (io.sel.var ? 1 : 0) + (io.sel.expect ? 1 : 0);
-        const int seln = nsel == 1 ? 16 : 8;
+        const bool full = io.mss || io.Pss;
+        // LDS per workgroup must stay within 40 KB (four workgroups a CU): a third row buffer fits beside ONE 8-step output buffer and no tile
+        const bool nb3 = three && !full && nsel == 1;
+        const int seln = (nsel == 1 && !nb3) ? 16 : 8;
         int period = 1;
         while ((period * io.T) % seln != 0) period *= 2;
         if (io.T * period * 128 * 64 > kOobMaxBytes) period = 1;
         const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
+        const unsigned grid = (unsigned)(groups * period);
         const size_t dyn = sizeof(double) * 65 * seln * nsel;
-        if (seln == 16) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 16>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
-        else hipLaunchKernelGGL((lane4_smoother_kernel<Step, 8>), dim3((unsigned)(groups * period)), dim3(64), dyn, stream, io, ma, period);
+        if (full) {
+            if (seln == 16) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 16, 2, true>), dim3(grid), dim3(64), dyn, stream, io, ma, period);
+            else hipLaunchKernelGGL((lane4_smoother_kernel<Step, 8, 2, true>), dim3(grid), dim3(64), dyn, stream, io, ma, period);
+        } else if (nb3) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 8, 3, false>), dim3(grid), dim3(64), dyn, stream, io, ma, period);
+        else if (seln == 16) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 16, 2, false>), dim3(grid), dim3(64), dyn, stream, io, ma, period);
+        else hipLaunchKernelGGL((lane4_smoother_kernel<Step, 8, 2, false>), dim3(grid), dim3(64), dyn, stream, io, ma, period);
         return hipGetLastError();
     }
     const int period = lane4_smoother_period(io.T);
     const int64_t groups = (io.B + 64 * period - 1) / (64 * period);
-    hipLaunchKernelGGL((lane4_smoother_kernel<Step>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
+    if (three) hipLaunchKernelGGL((lane4_smoother_kernel<Step, 0, 3, true>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
+    else hipLaunchKernelGGL((lane4_smoother_kernel<Step, 0, 2, true>), dim3((unsigned)(groups * period)), dim3(64), 0, stream, io, ma, period);
     return hipGetLastError();
 }
 

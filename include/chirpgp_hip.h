@@ -369,6 +369,8 @@ int cgp_debug_math(cgp_ctx* ctx, int op, const double* x, int64_t n, double* out
  *                           it ran in each regime of its speculative step to the context's counters; 0 (default): it does not */
 #define CGP_DBG_WALK_SEGMENTS  1
 #define CGP_DBG_COUNT_REGIMES  2
+#define CGP_DBG_LANE_BUFFERS   3   /* A/B aid: 3 = the large-batch smoothers (one lane per trial) request their covariance rows TWO steps ahead where the
+                                      LDS allows a third buffer beside four workgroups a CU; 0 / 2 (default): one step ahead (measured: no difference) */
 int cgp_debug_set(cgp_ctx* ctx, int key, int64_t value);
 /* Waits for `stream`, copies the context's eight counters to the HOST array `out` and, with reset != 0, zeroes them.
  *   out[0] chunks kept from the HIGH regime (frequency state >= 5 throughout)      out[1] chunks kept from the common regime (>= 1.5)

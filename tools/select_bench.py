@@ -29,7 +29,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--buffers', type=int, default=0, help='CGP_DBG_LANE_BUFFERS: 0 / 2 = covariance rows one step ahead (default), 3 = two where the LDS allows')
     a = ap.parse_args()
+    _engine.debug_set(_engine.DBG_LANE_BUFFERS, a.buffers)
     variants = (('full rows', dict()),
                 ('full + E[g]', dict(select=dict(comp=-2, expect='softplus'))),
                 ('E[g] only', dict(want=(False, False), select=dict(comp=-2, expect='softplus'))),
