@@ -95,3 +95,28 @@ def test_print_time_and_bats_shape_scripts():
     assert 0.0 < print_time.main(['--T', '1200', '--maxiter', '30']) < 5.0
     elapsed, err = bats_shape.main(['--T', '3000'])
     assert 0.0 < elapsed < 5.0 and err < 1500.0
+
+
+def test_lorenz_demo_on_runtime_compiled_models(capsys):
+    """demos/lorenz_custom.py: the four filter / smoother pairs on Lorenz-63 handed over as source; smoothed states near the simulated ones."""
+    import lorenz_custom
+    old = sys.argv
+    sys.argv = ['lorenz_custom.py', '--T', '500', '--batch', '4']
+    try:
+        lorenz_custom.main()
+    finally:
+        sys.argv = old
+    out = capsys.readouterr().out
+    assert out.count('RMSE of the smoothed state') == 4 and 'nan' not in out
+
+
+def test_ekfs_demo_with_exact_gradients(capsys):
+    import ekfs_mle
+    old = sys.argv
+    sys.argv = ['ekfs_mle.py', '--T', '800', '--exact']
+    try:
+        ekfs_mle.main()
+    finally:
+        sys.argv = old
+    out = capsys.readouterr().out
+    assert out.count('RMSE') == 3 and 'nan' not in out
