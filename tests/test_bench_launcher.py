@@ -114,6 +114,11 @@ def test_contract_line_is_compact_strict_json():
     cb = line['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] == full['cpu_baseline']['cores'] and cb['value'] > 0 and len(cb['sample']) <= 160
     assert line['config']['workload'].startswith('C2') and 'model' not in line['config']
+    # a pathological record still yields a line: the last-resort form
+    full['config']['workload'] = 'C2 ' + 'z' * 9000
+    text = bench.contract_line(full, '/somewhere/bench_details.json')
+    line = json.loads(text, parse_constant=no_constants)
+    assert len(text) < 4096 and line['value'] == pytest.approx(full['value'], rel=1e-5) and line['roofline']['frac'] > 0 and line['cpu_baseline']['cores'] > 0
     # the details file is strict JSON too
     import tempfile
     assert json.loads(json.dumps(bench._finite(full), allow_nan=False))['steps'] == full['steps']
