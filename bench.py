@@ -278,7 +278,10 @@ def write_details(result):
     strings) as ONE strict-JSON file next to bench.py -- or in the temp directory when the tree is read-only -- and never on stdout.
     Returns the path (None if it could not be written anywhere)."""
     import tempfile
-    text = json.dumps(_finite(result), allow_nan=False, indent=1)
+    try:
+        text = json.dumps(_finite(result), allow_nan=False, indent=1, default=lambda o: o.item() if hasattr(o, 'item') else str(o))
+    except (TypeError, ValueError) as exc:                # never lose the contract line over the side file
+        text = json.dumps({"error": f"details not serialisable: {exc}"})
     for folder in (ROOT, os.path.join(ROOT, 'gpurun_out'), tempfile.gettempdir()):
         try:
             path = os.path.join(folder, DETAILS_NAME)
