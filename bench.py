@@ -335,6 +335,10 @@ def contract_line(result, details_path=None):
         for tag in ("C1", "C2_low_freq", "C3", "C4", "C5"):
             if tag in oc:
                 summ[tag] = {"value": oc[tag].get("value"), "filter_ms": oc[tag].get("filter_ms"), "smoother_ms": oc[tag].get("smoother_ms")}
+        ts = oc.get("time_split_filters") or {}
+        if "C4_per_gpu" in ts and "C4_per_gpu_smoother" in ts:      # C4's pass with BOTH launches time-split with burn-in (explicit calls; approximate to the junctions' mismatch)
+            summ["C4_time_split"] = {"filter_ms": ts["C4_per_gpu"].get("time_split_filter_ms"), "smoother_ms": ts["C4_per_gpu_smoother"].get("time_split_smoother_ms"),
+                                     "junction_mismatch": max(ts["C4_per_gpu"].get("junction_mismatch") or 0.0, ts["C4_per_gpu_smoother"].get("junction_mismatch") or 0.0)}
         sp = oc.get("C2_spread")
         if sp:
             summ["C2_spread"] = {x: sp.get(x) for x in ("combinations", "value_min", "value_median", "value_max")}
@@ -663,6 +667,26 @@ def main():
                         "sequential_filter_ms": res["sequential"][1], "time_split_filter_ms": res["time_split"][1],
                         "speedup": res["sequential"][1] / res["time_split"][1], "junction_mismatch": err, "worst_output_difference": worst,
                         "accepted_at_1e-5": bool(err <= 1e-5)}
+            if kind == 'cd_sgp':
+                # ... and the smoother's counterpart (cgp_smoother_time_split, round 6) on the sequential filter's rows
+                fm, fP = res["sequential"][0][0], res["sequential"][0][1]
+                sres = {}
+                for name, kw in (("sequential", {}), ("time_split", dict(time_split=(segs, burn)))):
+                    sr = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], fm, fP, wl['dt'], **kw)
+                    sync()
+                    events = _engine.kernel_events = []
+                    for _ in range(steps):
+                        sr = fs.cd_sgp_smoother(wl['drift'], wl['disp'](None), wl['sgps'], fm, fP, wl['dt'], **kw)
+                    sync()
+                    _engine.kernel_events = None
+                    sres[name] = (sr, float(np.mean([x.elapsed_time(y) for n, x, y in events if n == 'smoother'])))
+                serr = float(_engine.last_junction_error.max())
+                sworst = max(float((g - s).abs().max() / s.abs().max()) for g, s in zip(sres["time_split"][0], sres["sequential"][0]))
+                out[tag + "_smoother"] = {"workload": "cd_sgp_smoother (cgp_smoother_time_split)", "batch_per_gpu": B, "T": T, "segments": segs, "burn_in": burn,
+                                          "sequential_smoother_ms": sres["sequential"][1], "time_split_smoother_ms": sres["time_split"][1],
+                                          "speedup": sres["sequential"][1] / sres["time_split"][1], "junction_mismatch": serr,
+                                          "worst_output_difference": sworst, "accepted_at_1e-5": bool(serr <= 1e-5)}
+                del sres, sr
             del res, r, ys_dev
             torch.cuda.empty_cache()
         return out

@@ -58,7 +58,7 @@ EXPORTS = ('cgp_version', 'cgp_create', 'cgp_destroy', 'cgp_last_error', 'cgp_fi
            'cgp_gaussian_expectation', 'cgp_debug_math', 'cgp_simulate', 'cgp_add_noise', 'cgp_debug_philox',
            'cgp_debug_set', 'cgp_debug_counters', 'cgp_gaussian_expectation_fn', 'cgp_filter_time_split', 'cgp_squared_error_sums',
            'cgp_reserve_workspace', 'cgp_release_workspace', 'cgp_source_hash', 'cgp_smoother_select', 'cgp_ekf_nll_grad', 'cgp_model_from_source', 'cgp_custom_model_destroy',
-           'cgp_filter_custom', 'cgp_smoother_custom')
+           'cgp_filter_custom', 'cgp_smoother_custom', 'cgp_smoother_time_split')
 
 _lib = None
 _lock = threading.Lock()
@@ -94,6 +94,9 @@ def load_library():
         lib.cgp_smoother.restype = C.c_int
         lib.cgp_smoother.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                      _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_uint32, _vp]
+        lib.cgp_smoother_time_split.restype = C.c_int
+        lib.cgp_smoother_time_split.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double, _vp, _vp, C.c_int64, C.c_int64,
+                                                _vp, _vp, C.c_uint32, C.c_int64, C.c_int64, _vp, _vp]
         lib.cgp_smoother_select.restype = C.c_int
         lib.cgp_smoother_select.argtypes = [_vp, C.c_int, C.POINTER(CgpModel), C.POINTER(CgpSigma), C.c_double,
                                             _vp, _vp, C.c_int64, C.c_int64, C.POINTER(CgpSmoothOut), C.c_uint32, _vp]
@@ -602,7 +605,8 @@ class SmootherSelection(dict):
     __getattr__ = dict.get
 
 
-def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0, want=(True, True), select=None):
+def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0, want=(True, True), select=None, time_split=None, split_tol=None,
+                 return_junction_error=False):
     """cgp_smoother / cgp_smoother_select with NumPy / torch marshalling.  (T, d) / (T, d, d) or with a leading batch axis.
 
     ``select = dict(comp=k, mean=True, var=True, expect='softplus' | 'exp' | 'identity' | 'square' | None, order=10)`` asks the launch
@@ -631,6 +635,26 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0, want=(True, T
         sig = _sigma_struct(sgps, d, keep, _nonlinear_coord(spec))
         lib, st = load_library(), _stream()
         sig_ref = C.byref(sig) if sig is not None else None
+        if time_split is not None:
+            # cgp_smoother_time_split (cd_sgp_smoother): several wavefronts per trial, each starting `burn_in` steps later than its piece from the
+            # filtering row there; the launch reports the mismatch at its junctions (with split_tol: fall back to the sequential smoother)
+            if select is not None:
+                raise ValueError('time_split writes full rows only')
+            segments, burn_in = (int(v) for v in time_split)
+            mss, Pss = torch.empty_like(m), torch.empty_like(P)
+            err = torch.empty((B,), dtype=torch.float64, device=m.device)
+            rc = _timed('smoother', lambda: lib.cgp_smoother_time_split(ctx, int(method), C.byref(model), sig_ref, float(dt), _ptr(m), _ptr(P), B, T,
+                                                                        _ptr(mss), _ptr(Pss), int(flags), segments, burn_in, _ptr(err), st))
+            _check(ctx, rc, 'cgp_smoother_time_split')
+            junction = err
+            if split_tol is not None and not bool((err <= float(split_tol)).all()):
+                rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), sig_ref, float(dt), _ptr(m), _ptr(P), B, T,
+                                                                 _ptr(mss), _ptr(Pss), int(flags), st))
+                _check(ctx, rc, 'cgp_smoother')
+                junction = None
+            _per_thread.junction_error = junction
+            res = (_out(mss, like_numpy, squeeze), _out(Pss, like_numpy, squeeze))
+            return res + (junction,) if return_junction_error else res
         if select is None:
             mss, Pss = torch.empty_like(m), torch.empty_like(P)
             rc = _timed('smoother', lambda: lib.cgp_smoother(ctx, int(method), C.byref(model), sig_ref,

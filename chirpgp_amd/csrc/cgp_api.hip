@@ -481,7 +481,7 @@ int cgp_filter_time_split(cgp_ctx* ctx, int method, const cgp_model* model, cons
 
 static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
                          const double* mfs, const double* Pfs, int64_t B, int64_t T, const cgp_smooth_out* out,
-                         uint32_t flags, void* stream) {
+                         uint32_t flags, void* stream, int64_t segments = 1, int64_t burn_in = 0, double* junction_err = nullptr) {
     if (!ctx) return CGP_E_ARG;
     if (B < 0 || T < 0) return fail(ctx, CGP_E_ARG, "negative B or T");
     if (B == 0 || T == 0) return CGP_OK;
@@ -586,6 +586,25 @@ static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const
         } else if (!mss || !Pss)
             return fail(ctx, CGP_E_UNSUPPORTED, "this (method, model, launch shape) writes selected outputs from its full rows only: pass mss and Pss as well");
     }
+    // ---- time-split with burn-in (cgp_smoother_time_split): the continuous-discrete sigma-point smoother on the d = 4 matrix-core kernel
+    if (segments > 1) {
+        if (burn_in < 0) return fail(ctx, CGP_E_ARG, "burn_in must be >= 0");
+        if (!junction_err) return fail(ctx, CGP_E_ARG, "junction_err must be set: a time-split smoother is only as good as its junctions");
+        if (want_sel) return fail(ctx, CGP_E_UNSUPPORTED, "cgp_smoother_time_split writes full rows only");
+        if (route != kCoop4CdSgp || (flags & CGP_DPP_KERNEL) || !sigma_mfma_taken(flags, T, ma))
+            return fail(ctx, CGP_E_UNSUPPORTED, "time-split smoothers with burn-in are built for cd_sgp_smoother on the d = 4 chirp / La Scala SDE (matrix-core kernel, "
+                                                "standard sigma set); the discrete smoothers split exactly (CGP_TIME_SPLIT)");
+        const int64_t chunks = (T - 1 + 63) / 64;
+        if (chunks >= 2) {
+            const int64_t cps = (chunks + segments - 1) / segments;
+            const int64_t segs = (chunks + cps - 1) / cps;
+            if (segs > 1) {
+                io.bsegs = (int)segs; io.chunks_per_bseg = (int)cps; io.burn_chunks = (int)((burn_in + 63) / 64);
+                io.junction = (double*)ctx_workspace(ctx, st, sizeof(double) * 20 * (size_t)B * (size_t)segs);
+                if (!io.junction) return fail(ctx, CGP_E_HIP, "no workspace for the junction states (allocation failed, or the buffer would grow inside a graph capture: cgp_reserve_workspace first)");
+            }
+        }
+    }
     switch (route) {
     case kCoop8Linear: rc = dispatch_smoother_coop8_linear(method, model->d, io, ma, st); break;
     case kWalk4Linear: rc = dispatch_smoother_walk4_linear(method, io, ma, st); break;
@@ -599,6 +618,10 @@ static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const
     case kCoop4CdEks:  rc = dispatch_smoother_coop4_cdeks(io, ma, st); break;
     case kSdeHarm:     rc = dispatch_smoother_sde_harm(method, model->n_harm, wave, io, ma, st); break;
     default: rc = CGP_E_ARG;
+    }
+    if (rc == CGP_OK && junction_err) {
+        if (io.bsegs > 1) rc = dispatch_smoother_split_fixup(io, junction_err, st);
+        else if (hipMemsetAsync(junction_err, 0, sizeof(double) * (size_t)B, st) != hipSuccess) rc = CGP_E_HIP;      // nothing was split: no junction, no mismatch
     }
     if (rc == CGP_OK && want_sel && !sel_native) {
         SmoothSel sel;
@@ -620,6 +643,17 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
     memset(&out, 0, sizeof(out));
     out.mss = mss; out.Pss = Pss; out.comp = -1;
     return smoother_impl(ctx, method, model, sigma, dt, mfs, Pfs, B, T, &out, flags, stream);
+}
+
+int cgp_smoother_time_split(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,
+                            const double* mfs, const double* Pfs, int64_t B, int64_t T, double* mss, double* Pss,
+                            uint32_t flags, int64_t segments, int64_t burn_in, double* junction_err, void* stream) {
+    if (ctx && segments < 1) return fail(ctx, CGP_E_ARG, "segments must be >= 1");
+    if (ctx && !junction_err) return fail(ctx, CGP_E_ARG, "junction_err must be set");
+    cgp_smooth_out out;
+    memset(&out, 0, sizeof(out));
+    out.mss = mss; out.Pss = Pss; out.comp = -1;
+    return smoother_impl(ctx, method, model, sigma, dt, mfs, Pfs, B, T, &out, flags, stream, segments, burn_in, junction_err);
 }
 
 int cgp_smoother_select(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma, double dt,

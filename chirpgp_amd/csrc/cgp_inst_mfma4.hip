@@ -8,6 +8,7 @@
 namespace cgp {
 // (the two sigma-point FILTERS are instantiated in cgp_inst_mfma4_sgpf.hip)
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdsgps4_mfma<HarmonicSDE<1>>(io, ma, st); }
+int dispatch_smoother_split_fixup(const SmootherIO& io, double* junction_err, hipStream_t st) { return launch_smoother_split_fixup(io, junction_err, st); }
 int dispatch_filter_mfma4_cdekf(const FilterIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdekf4_mfma(io, ma, st); }
 int dispatch_smoother_mfma4_cdeks(const SmootherIO& io, const ModelArgs& ma, hipStream_t st) { return launch_cdeks4_mfma(io, ma, st); }
 }  // namespace cgp

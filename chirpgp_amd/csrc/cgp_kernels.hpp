@@ -186,6 +186,13 @@ struct SmootherIO {
     int tiles_per_seg = 0;
     double* __restrict__ ws = nullptr;
     cgp_ctx* host_ctx = nullptr;  // host side only: the context whose per-stream workspace (cgp::ctx_workspace) serves `ws`
+    // Time-split with burn-in of the continuous-discrete smoothers (cgp_smoother_time_split; round 6): their backward ODE is not affine in the
+    // carry, so a segment cannot be composed exactly -- but the recursion FORGETS its terminal condition like the filters forget their initial
+    // one: segment s (0 = the last in time) starts `burn_chunks` 64-step chunks LATER than its piece from the filtering row there, writes
+    // nothing until its piece begins, and leaves its state at the junction in junction[(trial * bsegs + s) * 20] (m 4 | P 16) for the
+    // fix-up pass to compare with the row the segment before it wrote.  bsegs <= 1: off.
+    int bsegs = 1, chunks_per_bseg = 0, burn_chunks = 0;
+    double* __restrict__ junction = nullptr;
     SmoothSel sel;                // cgp_smoother_select: selected outputs (mss / Pss may then be NULL); comp < 0: off
     int lane_buffers = 0;         // host side: cgp_debug_set(CGP_DBG_LANE_BUFFERS) -- 3 = the large-batch smoothers request their rows two steps ahead, else one
 };
@@ -679,6 +686,7 @@ int dispatch_filter_mfma4(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_mfma4_sgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_filter_mfma4_cdsgp(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_mfma4_cdsgp(const SmootherIO&, const ModelArgs&, hipStream_t);
+int dispatch_smoother_split_fixup(const SmootherIO&, double* junction_err, hipStream_t);
 int dispatch_filter_mfma4_cdekf(const FilterIO&, const ModelArgs&, hipStream_t);
 int dispatch_smoother_mfma4_cdeks(const SmootherIO&, const ModelArgs&, hipStream_t);
 // the matrix-core EKF addresses a trial's outputs through 2 GiB buffer windows (cgp_mfma4.hpp)

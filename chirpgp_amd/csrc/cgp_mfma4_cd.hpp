@@ -217,13 +217,17 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
 // Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
 // G is constant over the four stages and computed a chunk of 64 steps at a time, lane-parallel (cgp_coop4_sigma.hpp:
 // coop4_chunk_gains); the walk reads it back from LDS one entry per lane, and mf in column form.
-template <class SM, bool TWO>
+// SPLIT (round 6; cgp_smoother_time_split): one wavefront per (trial, segment) -- see SmootherIO::bsegs.  Chunk j covers the rows
+// T - 2 - 64 j - 63 .. T - 2 - 64 j; segment s owns the chunks [s cps, (s + 1) cps) and starts burn_chunks chunks earlier in its walk
+// (later in time) from the FILTERING row there; the burn-in chunks store through a zero-byte window.
+template <class SM, bool TWO, bool SPLIT = false>
 __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelArgs ma) {
     static_assert(SM::D == 4, "d = 4 kernel");
     __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    const int64_t trial = SPLIT ? (int64_t)(blockIdx.x / (unsigned)io.bsegs) : (int64_t)blockIdx.x;
+    const int seg = SPLIT ? (int)(blockIdx.x % (unsigned)io.bsegs) : 0;
     if (trial >= io.B) return;
 
     SM model;
@@ -246,18 +250,42 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
     const double* __restrict__ Pfs = io.Pfs + trial * T * 16;
     double* __restrict__ mss = io.mss + trial * T * 4;
     double* __restrict__ Pss = io.Pss + trial * T * 16;
-    OobWindow wP, wm;
+    OobWindow wP, wm, wPnull, wmnull;
     wP.init(Pss, T * 128);
     wm.init(mss, T * 32);
+    wPnull.init(nullptr, 0); wmnull.init(nullptr, 0);                    // the burn-in chunks of a segment store through these
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
     const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
 
-    double ms = mfs[(T - 1) * 4 + q];                                    // the mean in column form
-    double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, r, q);
-    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
-    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    // this wavefront's chunks: [j_first, j_last], of which [j_own, j_last] are its own (stored)
+    const int64_t n_chunks = (T - 1 + 63) / 64;
+    int64_t j_own = 0, j_first = 0, j_last = n_chunks - 1;
+    if constexpr (SPLIT) {
+        j_own = (int64_t)seg * io.chunks_per_bseg;
+        j_last = j_own + io.chunks_per_bseg - 1 < n_chunks - 1 ? j_own + io.chunks_per_bseg - 1 : n_chunks - 1;
+        j_first = j_own - io.burn_chunks > 0 ? j_own - io.burn_chunks : 0;
+        if (j_own >= n_chunks) return;                                   // (more segments than chunks: nothing to do)
+    }
+    const int64_t t_start = T - 1 - 64 * j_first;                        // the row the carry starts from: the last filtering row, or a later segment's territory
+    double ms = mfs[t_start * 4 + q];                                    // the mean in column form
+    double Ps = coop4_load_sym_entry(Pfs + t_start * 16, r, q);
+    if (j_first == 0 && j_own == 0) {
+        if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
+        if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    }
 
-    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+    for (int64_t j = j_first; j <= j_last; j++) {
+        const int64_t t_hi = T - 2 - 64 * j;
+        const bool own = j >= j_own;
+        if constexpr (SPLIT) {
+            if (j == j_own && seg > 0 && io.junction) {                  // the state this segment's burn-in arrived at, at row t_hi + 1
+                double* __restrict__ jn = io.junction + (trial * io.bsegs + seg) * 20;
+                if (r == 0 && b == 0) jn[q] = ms;
+                if (b == 0) jn[4 + 4 * r + q] = Ps;
+            }
+        }
+        const OobWindow& oP = own ? wP : wPnull;
+        const OobWindow& om = own ? wm : wmnull;
         const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
         coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);
         for (int slot = 0; slot < nsteps; slot++) {
@@ -282,11 +310,38 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
             }
             ms = ms + (dt * am) * kSixth;
             Ps = Ps + (dt * aP) * kSixth;
-            wP.store(Ps, t * 128u + offP);
-            wm.store(ms, t * 32u + offm);
+            oP.store(Ps, t * 128u + offP);
+            om.store(ms, t * 32u + offm);
         }
         wave_lds_fence();
     }
+}
+
+// Fix-up pass of a time-split smoother launch (one wavefront per trial): junction_err[b] = the largest relative mismatch, over the junctions of
+// trial b, between the state a segment's burn-in arrived at and the row the segment before it (later in time) wrote there -- max |difference| /
+// max |reference| over the mean and, separately, the covariance; inf if a NaN sits at a junction.  A heuristic like the filters' (include/chirpgp_hip.h).
+template <int UNIT = 0>      // (a template: the header is included by more than one translation unit)
+__global__ void __launch_bounds__(64) smoother_split_fixup_kernel(SmootherIO io, double* __restrict__ junction_err) {
+    const int64_t trial = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int64_t T = io.T;
+    double worst = 0.0;
+    for (int s = 1; s < io.bsegs; s++) {
+        const int64_t j_own = (int64_t)s * io.chunks_per_bseg;
+        if (j_own >= (T - 1 + 63) / 64) break;
+        const int64_t row = T - 1 - 64 * j_own;                          // the row both sides hold: segment s - 1 wrote it, segment s arrived at it
+        const double* __restrict__ jn = io.junction + (trial * io.bsegs + s) * 20;
+        const double* __restrict__ mr = io.mss + (trial * T + row) * 4;
+        const double* __restrict__ Pr = io.Pss + (trial * T + row) * 16;
+        double dm = 0.0, rm = 0.0, dp = 0.0, rp = 0.0;
+        bool nan = false;
+        for (int i = 0; i < 4; i++) { const double e = fabs(jn[i] - mr[i]); nan = nan || !(e == e); dm = fmax(dm, e); rm = fmax(rm, fabs(mr[i])); }
+        for (int i = 0; i < 16; i++) { const double e = fabs(jn[4 + i] - Pr[i]); nan = nan || !(e == e); dp = fmax(dp, e); rp = fmax(rp, fabs(Pr[i])); }
+        double err = fmax(rm > 0.0 ? dm / rm : dm, rp > 0.0 ? dp / rp : dp);
+        if (nan) err = __builtin_inf();
+        worst = fmax(worst, err);
+    }
+    junction_err[trial] = worst;
 }
 
 // ------------------------------------------------------------------------------------------------ cd_ekf / cd_eks, d = 4
@@ -488,8 +543,19 @@ template <class SM>
 inline int launch_cdsgps4_mfma(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (!collapsed_ok(ma) || io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
+    if (io.bsegs > 1) {                                                             // time-split with burn-in: one wavefront per (trial, segment)
+        const unsigned grid = (unsigned)(io.B * io.bsegs);
+        if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, true, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+        else hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, false, true>), dim3(grid), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+        return hip_rc(hipGetLastError());
+    }
     if (ma.sg.n_groups > 16) hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, true>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
     else hipLaunchKernelGGL((cdsgps4_mfma_kernel<SM, false>), dim3((unsigned)io.B), dim3(64), sigma_lds_bytes(ma, 4), stream, io, ma);
+    return hip_rc(hipGetLastError());
+}
+// (the fix-up pass of a split launch: instantiated with the kernel, called by cgp_smoother_time_split)
+inline int launch_smoother_split_fixup(const SmootherIO& io, double* junction_err, hipStream_t stream) {
+    hipLaunchKernelGGL((smoother_split_fixup_kernel<0>), dim3((unsigned)io.B), dim3(64), 0, stream, io, junction_err);
     return hip_rc(hipGetLastError());
 }
 

@@ -286,6 +286,20 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
                  double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
                  double* mss, double* Pss, uint32_t flags, void* stream);
 
+/* Time-split smoother with burn-in (round 6) -- the counterpart of cgp_filter_time_split for the continuous-discrete sigma-point smoother
+ * (cd_sgp_smoother, filters_smoothers.py:585-632), whose backward moment ODE is not affine in its carry and so cannot be composed exactly like
+ * the discrete smoothers (CGP_TIME_SPLIT).  It FORGETS its terminal condition instead: the record is cut into `segments` pieces of whole
+ * 64-step chunks, and the wavefront of a piece starts `burn_in` steps LATER in time than its piece ends, from the FILTERING row there, writes
+ * nothing until its piece begins, and carries on like the sequential smoother.  junction_err[b] (DEVICE, [B], required): the largest relative
+ * mismatch, over trial b's junctions, between the state a burn-in arrived at and the row the piece later in time wrote there (max |difference| /
+ * max |reference|, mean and covariance separately; inf for a NaN) -- a heuristic like the filters' (see there), checked by the caller against
+ * its own tolerance.  Built for CGP_S_CD_SGP on the d = 4 chirp / La Scala SDE (matrix-core kernel, standard sigma set); CGP_E_UNSUPPORTED
+ * otherwise.  segments = 1: cgp_smoother (junction_err = 0).  Scratch: 8 * 20 * B * segments bytes of the stream's workspace. */
+int cgp_smoother_time_split(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
+                            double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
+                            double* mss, double* Pss, uint32_t flags, int64_t segments, int64_t burn_in,
+                            double* junction_err, void* stream);
+
 /* Smoothers with selected outputs -- the step right behind the smoother in every driver of the reference, fused into it
  * (demos/ekfs_mle.py:69-77: gaussian_expectation(ms = mss[:, 2], chol_Ps = sqrt(Pss[:, 2, 2]), func = g), then rmse; quadratures.py:234-274).
  * Besides (or instead of) the full rows a launch writes, per trial and step, the smoothed mean and variance of ONE state component and

@@ -116,6 +116,9 @@ def test_default_line_carries_the_other_baseline_configs():
         assert ts[k]['accepted_at_1e-5'] and ts[k]['junction_mismatch'] < 1e-5 and ts[k]['worst_output_difference'] <= 5 * ts[k]['junction_mismatch']
         assert ts[k]['speedup'] > 1.4, (k, ts[k])
     assert not ts['C5_shard']['accepted_at_1e-5']                         # the 3-harmonic filter does not, and its junctions say so
+    sm = ts['C4_per_gpu_smoother']                                        # round 6: the smoother's counterpart (cgp_smoother_time_split)
+    assert sm['accepted_at_1e-5'] and sm['junction_mismatch'] < 1e-7 and sm['worst_output_difference'] <= max(1e-12, 5 * sm['junction_mismatch'])
+    assert sm['speedup'] > 1.4, sm
     assert (oc['C1']['batch_per_gpu'], oc['C1']['T'], oc['C1']['d']) == (1, 1000, 4)
     assert (oc['C3']['batch_per_gpu'], oc['C3']['T']) == (1000, 10000) and oc['C3']['scaling'] == 'strong'
     assert (oc['C4']['batch_per_gpu'], oc['C4']['T']) == (512, 50000)

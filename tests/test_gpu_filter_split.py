@@ -178,3 +178,75 @@ def test_the_other_kernels_that_know_segments(method):
     last = run(time_split=(4, 3008), nll_final_only=True, want=(False, False, True))[2]
     seq_last = run(nll_final_only=True, want=(False, False, True))[2]
     assert _rel(last, seq_last) <= 5 * err + 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ the smoother's counterpart (round 6)
+def _cd_filtered(c, B, T, seed):
+    """Filtering rows of B noisy copies of the case's record from the C port (the smoothers are compared on identical inputs)."""
+    import copy
+    from oracle import port
+    dg = copy.copy(c.drift)
+    dg.gamma = c.disp.outer()
+    ys = c.ys[None, :T] + 0.05 * np.random.default_rng(seed).standard_normal((B, T))
+    return dg, port.filter(port.F_CD_SGP, dg, c.sgps, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+
+
+@pytest.mark.parametrize('T,segments,burn_in', [(3000, 3, 640), (3000, 2, 1280), (1000, 4, 0), (130, 2, 64), (65, 5, 64)])
+def test_cd_sgp_smoother_time_split_against_its_sequential_launch(T, segments, burn_in):
+    """cgp_smoother_time_split (cd_sgp_smoother on the d = 4 matrix-core kernel): every output within 5 x the junction mismatch the launch
+    reports of the sequential launch's, the segment that is last in time bit-identical, ragged T (a record shorter than the segments asked
+    for), no burn-in at all (the junctions then report what that costs)."""
+    from chirpgp_amd import filters_smoothers as fs
+    c = cs.chirp_case(T=T, seed=91)
+    dg, f = _cd_filtered(c, 5, T, 1)
+    b = c.disp(None)
+    seq = fs.cd_sgp_smoother(c.drift, b, c.sgps, f[0], f[1], c.dt)
+    got = fs.cd_sgp_smoother(c.drift, b, c.sgps, f[0], f[1], c.dt, time_split=(segments, burn_in), return_junction_error=True)
+    err = got[2].cpu().numpy() if hasattr(got[2], 'cpu') else np.asarray(got[2])
+    assert err.shape == (5,) and np.isfinite(err).all()
+    chunks = (T - 1 + 63) // 64
+    cps = -(-chunks // segments)
+    own = 64 * cps                                                    # rows of the segment that is last in time: no junction in front of it
+    for g, s_, n in zip(got[:2], seq, ('mss', 'Pss')):
+        np.testing.assert_array_equal(g[:, T - 1 - min(own, T - 1):], s_[:, T - 1 - min(own, T - 1):])
+        worst = np.abs(g - s_).reshape(5, -1).max(axis=1) / np.abs(s_).max()
+        assert (worst <= np.maximum(1e-12, 5 * err)).all(), (n, worst, err)
+    if burn_in == 0 and chunks > cps:
+        assert err.max() > 1e-3                                       # a segment that starts from the FILTERING row is far from the smoothed one
+    print(f'T {T} segments {segments} burn-in {burn_in}: junction mismatch {err.max():.1e}')
+
+
+def test_cd_sgp_smoother_time_split_against_the_oracle_and_refusals():
+    """C4's shape in small (T = 12 000, two segments, 2048 steps of burn-in) against the C port's sequential smoother on identical filtering
+    rows: within max(1e-7, 5 x junction); split_tol sends a launch with a NaN junction back to the sequential smoother; other methods
+    and kernel variants are refused by name."""
+    from chirpgp_amd import filters_smoothers as fs, _engine
+    from oracle import port
+    T = 12000
+    c = cs.chirp_case(T=T, seed=92)
+    dg, f = _cd_filtered(c, 4, T, 2)
+    b = c.disp(None)
+    want = port.smoother(port.S_CD_SGP, dg, c.sgps, c.dt, f[0], f[1])
+    got = fs.cd_sgp_smoother(c.drift, b, c.sgps, f[0], f[1], c.dt, time_split=(2, 2048), return_junction_error=True)
+    err = np.asarray(got[2].cpu())
+    assert 0 < err.max() < 1e-6
+    for g, w, n in zip(got[:2], want, ('mss', 'Pss')):
+        worst = np.abs(g - w).reshape(4, -1).max(axis=1) / np.abs(w).max()
+        assert (worst <= np.maximum(1e-7, 5 * err)).all(), (n, worst, err)
+    print(f'cd_sgp_smoother 4 x {T} (2, 2048): junction mismatch {err.max():.1e}')
+    # a NaN in the filtering rows just behind a junction: inf, and split_tol returns the sequential result
+    f2 = (f[0].copy(), f[1].copy())
+    chunks = (T - 1 + 63) // 64
+    row = T - 1 - 64 * (-(-chunks // 2))                              # the junction row of segment 1
+    f2[1][1, row + 100, 2, 2] = np.nan                                # inside segment 1's burn-in stretch
+    seq = fs.cd_sgp_smoother(c.drift, b, c.sgps, f2[0], f2[1], c.dt)
+    fs.cd_sgp_smoother(c.drift, b, c.sgps, f2[0], f2[1], c.dt, time_split=(2, 2048))
+    e2 = _engine.last_junction_error.cpu().numpy()
+    assert np.isinf(e2[1]) and np.isfinite(e2[[0, 2, 3]]).all()
+    safe = fs.cd_sgp_smoother(c.drift, b, c.sgps, f2[0], f2[1], c.dt, time_split=(2, 2048), split_tol=1e-3)
+    for a_, b_ in zip(safe, seq):
+        assert np.array_equal(np.isnan(a_), np.isnan(b_)) and np.array_equal(a_[~np.isnan(a_)], b_[~np.isnan(b_)])
+    with pytest.raises(RuntimeError, match='cd_sgp_smoother'):
+        fs.eks(c.disc, f[0], f[1], c.dt, time_split=(2, 640))
+    with pytest.raises(RuntimeError, match='cd_sgp_smoother'):
+        fs.cd_sgp_smoother(c.drift, b, c.sgps, f[0], f[1], c.dt, time_split=(2, 640), flags=0x80)      # the LDS-reduced kernel knows no segments
