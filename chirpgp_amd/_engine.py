@@ -636,7 +636,7 @@ def run_smoother(method, spec, sgps, gamma, dt, mfs, Pfs, flags=0, want=(True, T
         lib, st = load_library(), _stream()
         sig_ref = C.byref(sig) if sig is not None else None
         if time_split is not None:
-            # cgp_smoother_time_split (cd_sgp_smoother): several wavefronts per trial, each starting `burn_in` steps later than its piece from the
+            # cgp_smoother_time_split (cd_sgp_smoother, cd_eks): several wavefronts per trial, each starting `burn_in` steps later than its piece from the
             # filtering row there; the launch reports the mismatch at its junctions (with split_tol: fall back to the sequential smoother)
             if select is not None:
                 raise ValueError('time_split writes full rows only')

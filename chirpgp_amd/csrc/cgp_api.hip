@@ -591,9 +591,11 @@ static int smoother_impl(cgp_ctx* ctx, int method, const cgp_model* model, const
         if (burn_in < 0) return fail(ctx, CGP_E_ARG, "burn_in must be >= 0");
         if (!junction_err) return fail(ctx, CGP_E_ARG, "junction_err must be set: a time-split smoother is only as good as its junctions");
         if (want_sel) return fail(ctx, CGP_E_UNSUPPORTED, "cgp_smoother_time_split writes full rows only");
-        if (route != kCoop4CdSgp || (flags & CGP_DPP_KERNEL) || !sigma_mfma_taken(flags, T, ma))
-            return fail(ctx, CGP_E_UNSUPPORTED, "time-split smoothers with burn-in are built for cd_sgp_smoother on the d = 4 chirp / La Scala SDE (matrix-core kernel, "
-                                                "standard sigma set); the discrete smoothers split exactly (CGP_TIME_SPLIT)");
+        const bool split_sgp = route == kCoop4CdSgp && !(flags & CGP_DPP_KERNEL) && sigma_mfma_taken(flags, T, ma);
+        const bool split_eks = route == kCoop4CdEks && !(flags & CGP_DPP_KERNEL) && T * 128 <= 0x7FFFFF00LL;        // cgp_inst_coop4.hip: the matrix-core kernel
+        if (!split_sgp && !split_eks)
+            return fail(ctx, CGP_E_UNSUPPORTED, "time-split smoothers with burn-in are built for cd_eks and cd_sgp_smoother on the d = 4 chirp / La Scala SDE (matrix-core "
+                                                "kernels; standard sigma set); the discrete smoothers split exactly (CGP_TIME_SPLIT)");
         const int64_t chunks = (T - 1 + 63) / 64;
         if (chunks >= 2) {
             const int64_t cps = (chunks + segments - 1) / segments;

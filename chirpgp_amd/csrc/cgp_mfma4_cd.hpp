@@ -217,6 +217,30 @@ __global__ void __launch_bounds__(64) cdsgp4_mfma_kernel(FilterIO io, ModelArgs 
 // Backward RK4 with  dm = _m + G^T (m - mf),  dP = _P + G^T P + P G - 2 gamma,  G = Pf^{-1} gamma  (filters_smoothers.py:615-621).
 // G is constant over the four stages and computed a chunk of 64 steps at a time, lane-parallel (cgp_coop4_sigma.hpp:
 // coop4_chunk_gains); the walk reads it back from LDS one entry per lane, and mf in column form.
+// The chunks of workgroup (trial, seg) of a time-split smoother launch (SmootherIO::bsegs): [j_first, j_last] walked, [j_own, j_last] stored;
+// chunk j covers the rows T - 2 - 64 j - 63 .. T - 2 - 64 j, and the carry starts from the filtering row t_start.
+struct SmootherSpan { int64_t j_own, j_first, j_last, t_start; bool empty; };
+template <bool SPLIT> CGP_DEV SmootherSpan smoother_span(const SmootherIO& io, int seg) {
+    const int64_t n_chunks = (io.T - 1 + 63) / 64;
+    SmootherSpan sp{0, 0, n_chunks - 1, io.T - 1, false};
+    if constexpr (SPLIT) {
+        sp.j_own = (int64_t)seg * io.chunks_per_bseg;
+        sp.j_last = sp.j_own + io.chunks_per_bseg - 1 < n_chunks - 1 ? sp.j_own + io.chunks_per_bseg - 1 : n_chunks - 1;
+        sp.j_first = sp.j_own - io.burn_chunks > 0 ? sp.j_own - io.burn_chunks : 0;
+        sp.empty = sp.j_own >= n_chunks;                                 // (more segments than chunks: nothing to do)
+        sp.t_start = io.T - 1 - 64 * sp.j_first;
+    }
+    return sp;
+}
+// the state a segment's burn-in arrived at (the carry in front of its first own chunk): m in column form, P one entry per lane
+CGP_DEV void smoother_junction_store(const SmootherIO& io, int64_t trial, int seg, int r, int b, int q, double ms, double Ps) {
+    if (seg > 0 && io.junction) {
+        double* __restrict__ jn = io.junction + (trial * io.bsegs + seg) * 20;
+        if (r == 0 && b == 0) jn[q] = ms;
+        if (b == 0) jn[4 + 4 * r + q] = Ps;
+    }
+}
+
 // SPLIT (round 6; cgp_smoother_time_split): one wavefront per (trial, segment) -- see SmootherIO::bsegs.  Chunk j covers the rows
 // T - 2 - 64 j - 63 .. T - 2 - 64 j; segment s owns the chunks [s cps, (s + 1) cps) and starts burn_chunks chunks earlier in its walk
 // (later in time) from the FILTERING row there; the burn-in chunks store through a zero-byte window.
@@ -257,33 +281,19 @@ __global__ void __launch_bounds__(64) cdsgps4_mfma_kernel(SmootherIO io, ModelAr
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
     const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
 
-    // this wavefront's chunks: [j_first, j_last], of which [j_own, j_last] are its own (stored)
-    const int64_t n_chunks = (T - 1 + 63) / 64;
-    int64_t j_own = 0, j_first = 0, j_last = n_chunks - 1;
-    if constexpr (SPLIT) {
-        j_own = (int64_t)seg * io.chunks_per_bseg;
-        j_last = j_own + io.chunks_per_bseg - 1 < n_chunks - 1 ? j_own + io.chunks_per_bseg - 1 : n_chunks - 1;
-        j_first = j_own - io.burn_chunks > 0 ? j_own - io.burn_chunks : 0;
-        if (j_own >= n_chunks) return;                                   // (more segments than chunks: nothing to do)
-    }
-    const int64_t t_start = T - 1 - 64 * j_first;                        // the row the carry starts from: the last filtering row, or a later segment's territory
-    double ms = mfs[t_start * 4 + q];                                    // the mean in column form
-    double Ps = coop4_load_sym_entry(Pfs + t_start * 16, r, q);
-    if (j_first == 0 && j_own == 0) {
+    const SmootherSpan sp = smoother_span<SPLIT>(io, seg);
+    if (sp.empty) return;
+    double ms = mfs[sp.t_start * 4 + q];                                 // the mean in column form
+    double Ps = coop4_load_sym_entry(Pfs + sp.t_start * 16, r, q);
+    if (sp.j_first == 0 && sp.j_own == 0) {
         if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
         if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
     }
 
-    for (int64_t j = j_first; j <= j_last; j++) {
+    for (int64_t j = sp.j_first; j <= sp.j_last; j++) {
         const int64_t t_hi = T - 2 - 64 * j;
-        const bool own = j >= j_own;
-        if constexpr (SPLIT) {
-            if (j == j_own && seg > 0 && io.junction) {                  // the state this segment's burn-in arrived at, at row t_hi + 1
-                double* __restrict__ jn = io.junction + (trial * io.bsegs + seg) * 20;
-                if (r == 0 && b == 0) jn[q] = ms;
-                if (b == 0) jn[4 + 4 * r + q] = Ps;
-            }
-        }
+        const bool own = j >= sp.j_own;
+        if constexpr (SPLIT) { if (j == sp.j_own) smoother_junction_store(io, trial, seg, r, b, q, ms, Ps); }
         const OobWindow& oP = own ? wP : wPnull;
         const OobWindow& om = own ? wm : wmnull;
         const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
@@ -444,11 +454,13 @@ __global__ void __launch_bounds__(64) cdekf4_mfma_kernel(FilterIO io, ModelArgs 
     if (lane == 0 && io.nll && nll_final) io.nll[trial] = cum;
 }
 
+template <bool SPLIT = false>      // SPLIT: cgp_smoother_time_split, as cdsgps4_mfma_kernel
 __global__ void __launch_bounds__(64) cdeks4_mfma_kernel(SmootherIO io, ModelArgs ma) {
     __shared__ __attribute__((aligned(16))) double gbuf[64 * kGainPitch];
     const int lane = threadIdx.x;
     const int r = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const int64_t trial = blockIdx.x;
+    const int64_t trial = SPLIT ? (int64_t)(blockIdx.x / (unsigned)io.bsegs) : (int64_t)blockIdx.x;
+    const int seg = SPLIT ? (int)(blockIdx.x % (unsigned)io.bsegs) : 0;
     if (trial >= io.B) return;
 
     HarmonicSDE<1> model;
@@ -469,18 +481,28 @@ __global__ void __launch_bounds__(64) cdeks4_mfma_kernel(SmootherIO io, ModelArg
     const double* __restrict__ Pfs = io.Pfs + trial * T * 16;
     double* __restrict__ mss = io.mss + trial * T * 4;
     double* __restrict__ Pss = io.Pss + trial * T * 16;
-    OobWindow wP, wm;
+    OobWindow wP, wm, wPnull, wmnull;
     wP.init(Pss, T * 128);
     wm.init(mss, T * 32);
+    wPnull.init(nullptr, 0); wmnull.init(nullptr, 0);                    // the burn-in chunks of a segment store through these
     const unsigned offP = (b == 0) ? (unsigned)(4 * r + q) * 8u : kOobOffset;
     const unsigned offm = (lane < 4) ? (unsigned)lane * 8u : kOobOffset;
 
-    double ms = mfs[(T - 1) * 4 + q];
-    double Ps = coop4_load_sym_entry(Pfs + (T - 1) * 16, r, q);
-    if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
-    if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    const SmootherSpan sp = smoother_span<SPLIT>(io, seg);
+    if (sp.empty) return;
+    double ms = mfs[sp.t_start * 4 + q];
+    double Ps = coop4_load_sym_entry(Pfs + sp.t_start * 16, r, q);
+    if (sp.j_first == 0 && sp.j_own == 0) {
+        if (lane < 16) Pss[(T - 1) * 16 + lane] = Pfs[(T - 1) * 16 + lane];      // filters_smoothers.py:140-142, verbatim copy
+        if (lane < 4) mss[(T - 1) * 4 + lane] = mfs[(T - 1) * 4 + lane];
+    }
 
-    for (int64_t t_hi = T - 2; t_hi >= 0; t_hi -= 64) {
+    for (int64_t j = sp.j_first; j <= sp.j_last; j++) {
+        const int64_t t_hi = T - 2 - 64 * j;
+        const bool own = j >= sp.j_own;
+        if constexpr (SPLIT) { if (j == sp.j_own) smoother_junction_store(io, trial, seg, r, b, q, ms, Ps); }
+        const OobWindow& oP = own ? wP : wPnull;
+        const OobWindow& om = own ? wm : wmnull;
         const int nsteps = t_hi + 1 < 64 ? (int)(t_hi + 1) : 64;
         coop4_chunk_gains(gbuf, lane, nsteps, t_hi, mfs, Pfs, gamma);  // Pf^{-1} gamma of the chunk's steps, one step per lane
         for (int slot = 0; slot < nsteps; slot++) {
@@ -505,8 +527,8 @@ __global__ void __launch_bounds__(64) cdeks4_mfma_kernel(SmootherIO io, ModelArg
             }
             ms = ms + (dt * am) * kSixth;
             Ps = Ps + (dt * aP) * kSixth;
-            wP.store(Ps, t * 128u + offP);
-            wm.store(ms, t * 32u + offm);
+            oP.store(Ps, t * 128u + offP);
+            om.store(ms, t * 32u + offm);
         }
         wave_lds_fence();
     }
@@ -521,7 +543,12 @@ inline int launch_cdekf4_mfma(const FilterIO& io, const ModelArgs& ma, hipStream
 inline int launch_cdeks4_mfma(const SmootherIO& io, const ModelArgs& ma, hipStream_t stream) {
     if (io.B <= 0 || io.T <= 0) return CGP_OK;
     if (io.T * 128 > kOobMaxBytes) return CGP_E_UNSUPPORTED;
-    hipLaunchKernelGGL(cdeks4_mfma_kernel, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    if (io.bsegs > 1) {
+        if (io.B * io.bsegs > 0x7fffffffLL) return CGP_E_UNSUPPORTED;
+        hipLaunchKernelGGL(cdeks4_mfma_kernel<true>, dim3((unsigned)(io.B * io.bsegs)), dim3(64), 0, stream, io, ma);
+    } else {
+        hipLaunchKernelGGL(cdeks4_mfma_kernel<false>, dim3((unsigned)io.B), dim3(64), 0, stream, io, ma);
+    }
     return hip_rc(hipGetLastError());
 }
 #endif  // CGP_NO_CD_EKF_KERNELS

@@ -293,8 +293,8 @@ int cgp_smoother(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sig
  * nothing until its piece begins, and carries on like the sequential smoother.  junction_err[b] (DEVICE, [B], required): the largest relative
  * mismatch, over trial b's junctions, between the state a burn-in arrived at and the row the piece later in time wrote there (max |difference| /
  * max |reference|, mean and covariance separately; inf for a NaN) -- a heuristic like the filters' (see there), checked by the caller against
- * its own tolerance.  Built for CGP_S_CD_SGP on the d = 4 chirp / La Scala SDE (matrix-core kernel, standard sigma set); CGP_E_UNSUPPORTED
- * otherwise.  segments = 1: cgp_smoother (junction_err = 0).  Scratch: 8 * 20 * B * segments bytes of the stream's workspace. */
+ * its own tolerance.  Built for CGP_S_CD_SGP (standard sigma set) and CGP_S_CD_EKS on the d = 4 chirp / La Scala SDE (matrix-core kernels);
+ * CGP_E_UNSUPPORTED otherwise.  segments = 1: cgp_smoother (junction_err = 0).  Scratch: 8 * 20 * B * segments bytes of the stream's workspace. */
 int cgp_smoother_time_split(cgp_ctx* ctx, int method, const cgp_model* model, const cgp_sigma* sigma,
                             double dt, const double* mfs, const double* Pfs, int64_t B, int64_t T,
                             double* mss, double* Pss, uint32_t flags, int64_t segments, int64_t burn_in,

@@ -250,3 +250,37 @@ def test_cd_sgp_smoother_time_split_against_the_oracle_and_refusals():
         fs.eks(c.disc, f[0], f[1], c.dt, time_split=(2, 640))
     with pytest.raises(RuntimeError, match='cd_sgp_smoother'):
         fs.cd_sgp_smoother(c.drift, b, c.sgps, f[0], f[1], c.dt, time_split=(2, 640), flags=0x80)      # the LDS-reduced kernel knows no segments
+
+
+@pytest.mark.parametrize('T,segments,burn_in', [(3000, 3, 640), (1000, 4, 0), (65, 5, 64)])
+def test_cd_eks_time_split_against_its_sequential_launch_and_the_oracle(T, segments, burn_in):
+    """The same cut for cd_eks (cdeks4_mfma_kernel<SPLIT>): within 5 x the reported junction mismatch of the sequential launch, the segment
+    last in time bit-identical, and (through the sequential launch's own parity) of the C port on identical filtering rows."""
+    import copy
+    from chirpgp_amd import filters_smoothers as fs
+    from oracle import port
+    c = cs.chirp_case(T=T, seed=93)
+    dg = copy.copy(c.drift)
+    dg.gamma = c.disp.outer()
+    ys = c.ys[None, :T] + 0.05 * np.random.default_rng(3).standard_normal((3, T))
+    f = port.filter(port.F_CD_EKF, dg, None, c.H, c.Xi, c.m0, c.P0, c.dt, ys)
+    seq = fs.cd_eks(c.drift, c.disp, f[0], f[1], c.dt)
+    got = fs.cd_eks(c.drift, c.disp, f[0], f[1], c.dt, time_split=(segments, burn_in), return_junction_error=True)
+    err = np.asarray(got[2].cpu()) if hasattr(got[2], 'cpu') else np.asarray(got[2])
+    assert err.shape == (3,) and np.isfinite(err).all()
+    chunks = (T - 1 + 63) // 64
+    cps = -(-chunks // segments)
+    own = min(64 * cps, T - 1)
+    want = port.smoother(port.S_CD_EKS, dg, None, c.dt, f[0], f[1])
+    for g, s_, w, n in zip(got[:2], seq, want, ('mss', 'Pss')):
+        np.testing.assert_array_equal(g[:, T - 1 - own:], s_[:, T - 1 - own:])
+        worst = np.abs(g - s_).reshape(3, -1).max(axis=1) / np.abs(s_).max()
+        assert (worst <= np.maximum(1e-12, 5 * err)).all(), (n, worst, err)
+        if burn_in:
+            worst = np.abs(g - w).reshape(3, -1).max(axis=1) / np.abs(w).max()
+            assert (worst <= np.maximum(1e-8, 5 * err)).all(), (n, worst, err)
+    if burn_in == 0 and chunks > cps:
+        assert err.max() > 1e-3
+    print(f'cd_eks T {T} segments {segments} burn-in {burn_in}: junction mismatch {err.max():.1e}')
+    with pytest.raises(RuntimeError, match='cd_eks'):
+        fs.cd_eks(c.drift, c.disp, f[0], f[1], c.dt, time_split=(2, 640), flags=0x80)          # the LDS-reduced kernel knows no segments
