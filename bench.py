@@ -749,6 +749,7 @@ def main():
         drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
         B, T, dt = 1000, 10000, 1e-3
         chunks = B * ((T + 63) // 64)
+        steps = max(steps, 10)              # (timed like the headline: the one synchronisation amortised over ten passes or more, not three)
         rows = []
         for seed in (0, 1000, 2000, 3000, 4000):
             for Xi in (0.01, 0.1, 1.0):
@@ -783,6 +784,7 @@ def main():
                 "combinations": len(rows), "steps": steps, "chunks_per_launch": chunks,
                 "value_min": float(vals.min()), "value_median": med, "value_max": float(vals.max()),
                 "slowest_over_median_time": med / float(vals.min()), "slowest": slow,
+                "value_at_headline_set": float(np.median([r['value'] for r in rows if (r['seed'], r['Xi'], r['offset_hz']) == (0, 0.1, 8.0)])),
                 "note": "median and slowest are to be read against the line's own value (the reference's records, seed 0, steps passes)",
                 "redone_plus_checked_share_max": max((r['redone'] + r['checked']) / chunks for r in rows),
                 "redone_plus_checked_share_at_reference_inputs": max((r['redone'] + r['checked']) / chunks for r in rows if (r['Xi'], r['offset_hz']) == (0.1, 8.0)),

@@ -86,7 +86,10 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
     const std::string D = std::to_string(d);
     std::string src = "#include \"cgp_custom.hpp\"\nnamespace cgp_user {\nusing namespace cgp::ad;\n#line 1 \"model\"\n";
     src += body;
-    src += "\n}\nstruct CgpUserModel {\n";
+    // (the kernels take FilterIO / SmootherIO / ModelArgs BY VALUE: the headers under include_dir must be the ones this library was built from --
+    // their sizes travel with the code object and are compared after loading)
+    src += "\n}\nextern \"C\" __device__ const unsigned cgp_rtc_abi[3] = {(unsigned)sizeof(cgp::FilterIO), (unsigned)sizeof(cgp::SmootherIO), (unsigned)sizeof(cgp::ModelArgs)};\n"
+           "struct CgpUserModel {\n";
     std::string f_name, s_name, sf_name, ss_name;
     if (kind == CGP_CUSTOM_DISCRETE) {
         src += "    template <class T> __device__ static void mean(const T* u, const double* p, double dt, T* m) { cgp_user::cond_mean(u, p, dt, m); }\n"
@@ -136,6 +139,19 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
         if (m->module) (void)hipModuleUnload(m->module);
         delete m;
         return done(CGP_E_HIP, "loading the compiled model failed: " + why);
+    }
+    {
+        hipDeviceptr_t abi_ptr = nullptr;
+        size_t abi_bytes = 0;
+        unsigned abi[3] = {0, 0, 0};
+        const bool read = hipModuleGetGlobal(&abi_ptr, &abi_bytes, m->module, "cgp_rtc_abi") == hipSuccess && abi_bytes == sizeof(abi) &&
+                          hipMemcpy(abi, abi_ptr, sizeof(abi), hipMemcpyDeviceToHost) == hipSuccess;
+        if (!read || abi[0] != sizeof(FilterIO) || abi[1] != sizeof(SmootherIO) || abi[2] != sizeof(ModelArgs)) {
+            (void)hipModuleUnload(m->module);
+            delete m;
+            return done(CGP_E_ARG, "the headers under include_dir are not the ones this library was built from (argument structs differ in size): "
+                                   "point include_dir at the csrc/ of this build");
+        }
     }
     R.DestroyProgram(&prog);
     *out = m;
