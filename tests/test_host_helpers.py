@@ -99,3 +99,65 @@ def test_remaining_reference_model_names():
     assert pm.disc_chirp_euler_maruyama() is NotImplemented
     with pytest.raises(NotImplementedError):
         pm.disc_chirp_tme(0.1, 0.1, 1., 1.)
+
+
+# ------------------------------------------------------------------------------------------------ round 6: host side of the exact gradient, refusals
+def test_tangent_directions_are_the_derivatives_of_the_model_constants():
+    """mle.tangent_directions (complex step, what cgp_ekf_nll_grad propagates) against fourth-order central differences of the same constants
+    along theta = g_inv(params): both builders with an exact gradient, lam > 0 and the lam = 0 branch's own derivative away from 0."""
+    from chirpgp_amd import mle
+    rng = np.random.default_rng(5)
+    for build, P in ((pm.build_chirp_model, 6), (pm.build_lascala_model, 4)):
+        consts = mle._constants_of(build)
+        assert consts is not None
+        n = P or 6
+        thetas = rng.uniform(-1.0, 1.5, (3, n))
+        dt, Xi = 1e-3, 0.1
+        got = mle.tangent_directions(build, thetas, dt, Xi)
+        assert got.shape == (3, n, 24) and np.isfinite(got).all()
+        for k in range(n):
+            def at(e):
+                th = thetas.copy(); th[:, k] += e
+                return np.real(consts(pm.g(th).T.astype(np.complex128), dt, Xi)).T            # (G, 24)
+            h = 1e-4
+            fd = (-at(2 * h) + 8 * at(h) - 8 * at(-h) + at(-2 * h)) / (12 * h)
+            # (the quotient carries eps |c| / h of rounding on constants that do not depend on theta_k at all)
+            # ... and eps / h absolutely where the constant is a difference of O(1) terms (the Matern covariance's dt^3 entry, as in the reference)
+            tol = 1e-7 * np.abs(fd).max(axis=0) + 1e-9 * np.abs(at(0.0)).max(axis=0) + 1e-11
+            assert (np.abs(got[:, k, :] - fd) <= tol).all(), (build.__name__, k, np.abs(got[:, k, :] - fd).max(axis=0), tol)
+    assert mle.has_exact_gradient('ekf', pm.build_chirp_model, 0.1)
+    assert not mle.has_exact_gradient('sgp', pm.build_chirp_model, 0.1)
+    assert not mle.has_exact_gradient('ekf', pm.build_harmonic_chirp_model, 0.1)
+    assert not mle.has_exact_gradient('ekf', pm.build_chirp_model, np.array([0.1, 0.2]))       # a per-trial Xi: the difference form
+    assert mle._exact_by_default('ekf', pm.build_chirp_model, 0.1, mle.EXACT_FROM_RECORDS, {})
+    assert not mle._exact_by_default('ekf', pm.build_chirp_model, 0.1, mle.EXACT_FROM_RECORDS - 1, {})
+
+
+def test_plain_callables_and_unknown_keywords_are_refused_by_name():
+    """No CPU fallback: a Python closure is a TypeError before anything touches the GPU, and so is a keyword a runtime-compiled model does not take."""
+    import pytest
+    from chirpgp_amd import filters_smoothers as fs
+    H, m0, P0, ys = np.eye(4)[0], np.zeros(4), np.eye(4), np.zeros(10)
+    with pytest.raises(TypeError, match='descriptor'):
+        fs.ekf(lambda u, dt: (u, np.eye(4)), H, 0.1, m0, P0, 1e-3, ys)
+    with pytest.raises(TypeError, match='drift'):
+        fs.cd_ekf(lambda u: u, lambda u: np.eye(4), H, 0.1, m0, P0, 1e-3, ys)
+    with pytest.raises(TypeError, match='SigmaPoints'):
+        fs.sgp_filter(pm.disc_chirp_lcd(0.1, 0.1, 1.0, 1.0), 'gh3', H, 0.1, m0, P0, 1e-3, ys)
+    with pytest.raises(ValueError, match='d = 3'):
+        fs.sgp_filter(pm.disc_chirp_lcd(0.1, 0.1, 1.0, 1.0), SigmaPoints.gauss_hermite(3, 3), H, 0.1, m0, P0, 1e-3, ys)
+    with pytest.raises(TypeError, match='time_split'):
+        fs._custom_kw(dict(time_split=(2, 64)))
+    assert fs._custom_kw(dict(flags=0), ('flags',)) == dict(flags=0)
+
+
+def test_gauss_hermite_rule_of_the_fused_expectation():
+    """_engine._gh_rule(order) is the reference's 1-D rule (quadratures.py:156-196): sqrt(2) x the physicists' roots, weights / sqrt(pi)."""
+    from chirpgp_amd import _engine
+    for order in (3, 10, 32):
+        xi, w = _engine._gh_rule(order)
+        x, ww = np.polynomial.hermite.hermgauss(order)
+        # (the reference finds the roots with np.roots: 3e-15 at order 10, 7e-10 at 32 -- restated, not improved)
+        npt.assert_allclose(np.sort(xi), np.sqrt(2) * x, rtol=0, atol=1e-14 if order <= 10 else 5e-9)
+        npt.assert_allclose(w[np.argsort(xi)], ww / np.sqrt(np.pi), rtol=0, atol=1e-14 if order <= 10 else 1e-11)
+        assert abs(w.sum() - 1) < 1e-12
