@@ -145,6 +145,22 @@ template <class DM> struct SgpsStepCustom {
     }
 };
 
+// ekf_for_kpt's measurement function h(u) supplied as U::measure<T> (filters_smoothers.py:298-311: H = jacfwd(h)(mp), pred = h(mp)): the
+// interface of KptUpdate (cgp_kernels.hpp).  The vector the linear filters read as H arrives as the body's q.
+template <int D_, class U> struct CustomMeasurement {
+    static constexpr int D = D_;
+    static constexpr bool LINEAR = false;
+    CGP_DEV static void update(const Vec<D>& mp, const Sym<D>& Pp, const Vec<D>& q, double Xi, double y, Vec<D>& mf, Sym<D>& Pf,
+                               double& S, double& innov) {
+        ad::Dual<D> x[D];
+        CGP_UNROLL for (int i = 0; i < D; i++) { x[i] = ad::Dual<D>(mp.v[i]); x[i].d[i] = 1.0; }
+        const ad::Dual<D> h = U::template measure<ad::Dual<D>>(x, q.v);
+        Vec<D> H;
+        CGP_UNROLL for (int i = 0; i < D; i++) H.v[i] = h.d[i];
+        scalar_update<D>(mp, Pp, H, Xi, y, true, h.v, mf, Pf, S, innov);
+    }
+};
+
 // SDE drift a(u) supplied as U::drift<T>: the interface of LinearSDE (cgp_models.hpp)
 template <int D_, class U> struct CustomSDE {
     static constexpr int D = D_;

@@ -73,7 +73,8 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
     if (!ctx) return CGP_E_ARG;
     if (!out) return fail(ctx, CGP_E_ARG, "out is NULL");
     *out = nullptr;
-    if (kind != CGP_CUSTOM_DISCRETE && kind != CGP_CUSTOM_SDE) return fail(ctx, CGP_E_ARG, "kind must be CGP_CUSTOM_DISCRETE or CGP_CUSTOM_SDE");
+    if (kind != CGP_CUSTOM_DISCRETE && kind != CGP_CUSTOM_SDE && kind != CGP_CUSTOM_MEASUREMENT)
+        return fail(ctx, CGP_E_ARG, "kind must be CGP_CUSTOM_DISCRETE, CGP_CUSTOM_SDE or CGP_CUSTOM_MEASUREMENT");
     if (d < 1 || d > 8) return fail(ctx, CGP_E_UNSUPPORTED, "custom models: state dimension 1..8");
     if (!body || !include_dir) return fail(ctx, CGP_E_ARG, "body / include_dir is NULL");
     Rtc& R = rtc();
@@ -99,6 +100,10 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
         s_name = "cgp::smoother_kernel<cgp::EksStep<CgpUserM, false>>";
         sf_name = "cgp::filter_kernel<cgp::SgpPredictCustom<CgpUserM>, cgp::LinearMeasurement<" + D + ">>";
         ss_name = "cgp::smoother_kernel<cgp::SgpsStepCustom<CgpUserM>>";
+    } else if (kind == CGP_CUSTOM_MEASUREMENT) {
+        // ekf_for_kpt: linear dynamics (F, Sigma as the parameter vector), the caller's h -- a filter, nothing else
+        src += "    template <class T> __device__ static T measure(const T* u, const double* q) { return cgp_user::measure(u, q); }\n};\n";
+        f_name = "cgp::filter_kernel<cgp::EkfPredict<cgp::LinearDisc<" + D + ">, false>, cgp::CustomMeasurement<" + D + ", CgpUserModel>>";
     } else {
         src += "    template <class T> __device__ static void drift(const T* u, const double* p, T* a) { cgp_user::drift(u, p, a); }\n};\n"
                "using CgpUserM = cgp::CustomSDE<" + D + ", CgpUserModel>;\n";
@@ -110,8 +115,9 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
     void* prog = nullptr;
     if (R.CreateProgram(&prog, src.c_str(), "cgp_custom_model.hip", 0, nullptr, nullptr) != 0) return fail(ctx, CGP_E_HIP, "hiprtcCreateProgram failed");
     auto done = [&](int code, const std::string& msg) { R.DestroyProgram(&prog); return fail(ctx, code, msg); };
-    if (R.AddNameExpression(prog, f_name.c_str()) != 0 || R.AddNameExpression(prog, s_name.c_str()) != 0 ||
-        R.AddNameExpression(prog, sf_name.c_str()) != 0 || R.AddNameExpression(prog, ss_name.c_str()) != 0) return done(CGP_E_HIP, "hiprtcAddNameExpression failed");
+    const std::string* names[4] = {&f_name, &s_name, &sf_name, &ss_name};
+    for (const std::string* n : names)
+        if (!n->empty() && R.AddNameExpression(prog, n->c_str()) != 0) return done(CGP_E_HIP, "hiprtcAddNameExpression failed");
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
     const std::string inc1 = std::string("-I") + include_dir, inc2 = std::string("-I") + include_dir + "/../../include";
     const char* opts[] = {arch.c_str(), "-std=c++17", "-O3", "-fno-fast-math", inc1.c_str(), inc2.c_str()};
@@ -123,18 +129,20 @@ int cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, c
         if (log.size() > 6000) log.resize(6000);
         return done(CGP_E_ARG, "the model source does not compile:\n" + log);
     }
-    const char *f_low = nullptr, *s_low = nullptr, *sf_low = nullptr, *ss_low = nullptr;
+    const char* low[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t size = 0;
-    if (R.GetLoweredName(prog, f_name.c_str(), &f_low) != 0 || R.GetLoweredName(prog, s_name.c_str(), &s_low) != 0 ||
-        R.GetLoweredName(prog, sf_name.c_str(), &sf_low) != 0 || R.GetLoweredName(prog, ss_name.c_str(), &ss_low) != 0 || R.GetCodeSize(prog, &size) != 0)
-        return done(CGP_E_HIP, "hiprtc: no lowered names / code");
+    for (int i = 0; i < 4; i++)
+        if (!names[i]->empty() && R.GetLoweredName(prog, names[i]->c_str(), &low[i]) != 0) return done(CGP_E_HIP, "hiprtc: no lowered name");
+    if (R.GetCodeSize(prog, &size) != 0) return done(CGP_E_HIP, "hiprtc: no code");
     std::vector<char> code(size);
     if (R.GetCode(prog, code.data()) != 0) return done(CGP_E_HIP, "hiprtcGetCode failed");
     cgp_custom_model* m = new cgp_custom_model;
     m->kind = kind; m->d = d; m->device = ctx->device;
-    if (hipModuleLoadData(&m->module, code.data()) != hipSuccess || hipModuleGetFunction(&m->filter, m->module, f_low) != hipSuccess ||
-        hipModuleGetFunction(&m->smoother, m->module, s_low) != hipSuccess || hipModuleGetFunction(&m->sgp_filter, m->module, sf_low) != hipSuccess ||
-        hipModuleGetFunction(&m->sgp_smoother, m->module, ss_low) != hipSuccess) {
+    hipFunction_t* fns[4] = {&m->filter, &m->smoother, &m->sgp_filter, &m->sgp_smoother};
+    bool loaded = hipModuleLoadData(&m->module, code.data()) == hipSuccess;
+    for (int i = 0; loaded && i < 4; i++)
+        if (low[i]) loaded = hipModuleGetFunction(fns[i], m->module, low[i]) == hipSuccess;
+    if (!loaded) {
         const std::string why = hipGetErrorString(hipGetLastError());
         if (m->module) (void)hipModuleUnload(m->module);
         delete m;
@@ -179,6 +187,7 @@ int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* m, const cgp_sigma* 
     if (ys_stride < 0 || ys_repeat < 1) return fail(ctx, CGP_E_ARG, "ys_stride must be >= 0 and ys_repeat >= 1");
     if (!init || !init->H || !init->Xi || !init->m0 || !init->P0) return fail(ctx, CGP_E_ARG, "init.H / Xi / m0 / P0 must be set");
     if (m->kind == CGP_CUSTOM_SDE && !gamma) return fail(ctx, CGP_E_ARG, "SDE models need gamma = b b^T");
+    if (!(sigma ? m->sgp_filter : m->filter)) return fail(ctx, CGP_E_UNSUPPORTED, "a measurement function (ekf_for_kpt) has no sigma-point form");
     DeviceScope on_device(ctx->device);
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);
@@ -204,6 +213,8 @@ int cgp_smoother_custom(cgp_ctx* ctx, const cgp_custom_model* m, const cgp_sigma
     if (m->device != ctx->device) return fail(ctx, CGP_E_ARG, "the model was compiled for another device's context");
     if (!mfs || !Pfs || !mss || !Pss || !params) return fail(ctx, CGP_E_ARG, "mfs / Pfs / mss / Pss / params must be set");
     if (m->kind == CGP_CUSTOM_SDE && !gamma) return fail(ctx, CGP_E_ARG, "SDE models need gamma = b b^T");
+    if (!(sigma ? m->sgp_smoother : m->smoother))
+        return fail(ctx, CGP_E_UNSUPPORTED, "a measurement function (ekf_for_kpt) has no smoother of its own: its dynamics are linear -- cgp_smoother with CGP_S_EKS on (F, Sigma)");
     DeviceScope on_device(ctx->device);
     if (!on_device.ok) return fail(ctx, CGP_E_HIP, "hipSetDevice failed");
     std::lock_guard<std::recursive_mutex> launches(ctx->launch_mutex);

@@ -75,8 +75,11 @@ def ekf(cond_m_cov, H, Xi, m0, P0, dt, ys, **kw):
 
 def ekf_for_kpt(F, Sigma, h, Xi, m0, P0, dt, ys, **kw):
     """Ad-hoc EKF of the KPT model: linear dynamics, harmonic measurement h (filters_smoothers.py:267-314)."""
+    if isinstance(h, M.CustomMeasurement):            # a measurement function compiled at run time over the linear dynamics
+        spec = h.with_dynamics(_np(F), _np(Sigma))
+        return E.run_filter_custom(spec, None, spec.q, Xi, m0, P0, dt, ys, **_custom_kw(kw))
     if not isinstance(h, M.MeasurementKPT):
-        raise TypeError('h must be the MeasurementKPT returned by chirpgp_amd.models.build_kpt_chirp_model')
+        raise TypeError('h must be the MeasurementKPT returned by chirpgp_amd.models.build_kpt_chirp_model, or a custom_measurement(source, d)')
     spec = M.linear_cond_m_cov(_np(F), _np(Sigma))
     if spec.d != h.n_harm + 2:
         raise ValueError('F must be (n_harm + 2) x (n_harm + 2)')

@@ -12,8 +12,8 @@ batch axis (one parameter vector per trial: parameter sweeps / MLE grids).
 import math
 import numpy as np
 
-__all__ = ['g', 'g_inv', 'DiscreteModel', 'DriftModel', 'Dispersion', 'MeasurementKPT', 'CustomDiscrete', 'CustomDrift',
-           'custom_cond_m_cov', 'custom_sde',
+__all__ = ['g', 'g_inv', 'DiscreteModel', 'DriftModel', 'Dispersion', 'MeasurementKPT', 'CustomDiscrete', 'CustomDrift', 'CustomMeasurement',
+           'custom_cond_m_cov', 'custom_sde', 'custom_measurement',
            'linear_cond_m_cov', 'linear_sde',
            'model_chirp', 'model_harmonic_chirp', 'model_lascala',
            'disc_chirp_lcd', 'disc_harmonic_chirp_lcd', 'disc_model_lascala_lcd', 'disc_m32',
@@ -157,7 +157,7 @@ class MeasurementKPT:
 
 # --------------------------------------------------------------------------- models compiled at run time
 M_CUSTOM = -1
-CUSTOM_DISCRETE, CUSTOM_SDE = 0, 1          # include/chirpgp_hip.h
+CUSTOM_DISCRETE, CUSTOM_SDE, CUSTOM_MEASUREMENT = 0, 1, 2          # include/chirpgp_hip.h
 
 
 class _CustomSpec(_Spec):
@@ -193,6 +193,46 @@ class CustomDrift(_CustomSpec):
         if self.host is None:
             raise TypeError('this custom drift has no host callable (pass host= to custom_sde to evaluate it with NumPy)')
         return self.host(u)
+
+
+class CustomMeasurement(_CustomSpec):
+    """ekf_for_kpt's measurement function h(u) as source: `measure<T>` (see custom_measurement).  `params` here is the vector q the source
+    reads (d doubles at most; one row per trial if batched); the linear dynamics (F, Sigma) arrive with the call."""
+    kind = CUSTOM_MEASUREMENT
+
+    def __init__(self, source, d, q=None, host=None):
+        q = np.zeros(d) if q is None else _f64(q)
+        if q.shape[-1] > d:
+            raise ValueError(f'the measurement function takes at most d = {d} parameters (they travel in the slot of H)')
+        pad = np.zeros(q.shape[:-1] + (d,))
+        pad[..., :q.shape[-1]] = q
+        super().__init__(source, d, pad, host)
+
+    def __call__(self, u):
+        if self.host is None:
+            raise TypeError('this custom measurement has no host callable (pass host= to custom_measurement to evaluate it with NumPy)')
+        return self.host(u)
+
+    def with_dynamics(self, F, Sigma):
+        """The spec the engine launches: this measurement over lambda u, dt: (F @ u, Sigma) -- params [F | Sigma], q in the slot of H."""
+        lin = linear_cond_m_cov(F, Sigma)
+        if lin.d != self.d:
+            raise ValueError(f'F must be {self.d} x {self.d}')
+        spec = CustomMeasurement.__new__(CustomMeasurement)
+        _CustomSpec.__init__(spec, self.source, self.d, lin.params, self.host)
+        spec.q = self.params
+        return spec
+
+
+def custom_measurement(source, d, q=None, host=None):
+    """Descriptor of a measurement function the library does not enumerate -- what the reference's ``ekf_for_kpt`` takes as any traceable
+    scalar ``h(u)`` (filters_smoothers.py:267-314: ``H = jacfwd(h)(mp)``, ``pred = h(mp)``).  ``source`` is HIP device code defining
+
+        template <class T> __device__ T measure(const T* u, const double* q);
+
+    for a generic scalar type T (double or the kernel's dual numbers, as for custom_cond_m_cov); ``q`` (at most d doubles, (n,) or (B, n))
+    is handed to it per trial; ``host`` an optional NumPy callable ``u -> h(u)``.  d <= 8."""
+    return CustomMeasurement(source, d, q, host)
 
 
 def custom_cond_m_cov(source, d, params, host=None):

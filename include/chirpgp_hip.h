@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define CGP_VERSION 150          /* 0.1.5: cgp_smoother_select, cgp_ekf_nll_grad, cgp_model_from_source / cgp_filter_custom / cgp_smoother_custom; 0.1.4: cgp_release_workspace, cgp_source_hash, pinned reserved workspaces, per-call launch lock; 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
+#define CGP_VERSION 160          /* 0.1.6: CGP_CUSTOM_MEASUREMENT (ekf_for_kpt's h as source), cgp_smoother_time_split for cd_eks, run-time models check their argument structs; 0.1.5: cgp_smoother_select, cgp_ekf_nll_grad, cgp_model_from_source / cgp_filter_custom / cgp_smoother_custom; 0.1.4: cgp_release_workspace, cgp_source_hash, pinned reserved workspaces, per-call launch lock; 0.1.3: per-stream workspace kept by the context (cgp_reserve_workspace); 0.1.2: cgp_debug_set / cgp_debug_counters, cgp_gaussian_expectation_fn, cgp_filter_time_split */
 #define CGP_MAX_D   12           /* largest state dimension compiled in (9 .. 12: the harmonic LCD model with 4 or 5 harmonics only) */
 
 typedef struct cgp_ctx cgp_ctx;
@@ -240,15 +240,20 @@ int cgp_ekf_nll_grad(cgp_ctx* ctx, const cgp_model* model, const cgp_init* init,
  *     CGP_CUSTOM_DISCRETE:   template <class T> __device__ void cond_mean(const T* u, const double* p, double dt, T* mean);
  *                            __device__ void cond_cov(const double* u, const double* p, double dt, double* cov);      cov [d][d] row-major
  *     CGP_CUSTOM_SDE:        template <class T> __device__ void drift(const T* u, const double* p, T* a);              (b b^T is `gamma`)
+ *     CGP_CUSTOM_MEASUREMENT: template <class T> __device__ T measure(const T* u, const double* q);                     (0.1.6)
+ *         the scalar measurement function h of ekf_for_kpt (filters_smoothers.py:267-314: H = jacfwd(h)(mp), pred = h(mp)) over LINEAR dynamics:
+ *         cgp_filter_custom then reads `params` as [F (d x d) | Sigma (d x d)] per trial, like a CGP_M_LINEAR model, and hands init->H -- d doubles,
+ *         per trial with H_stride -- to the body as q (whatever the measurement function wants to be told; zeros if nothing).  Filter only.
  * p = the trial's parameter vector (`params` + trial * param_stride at launch; any length the body agrees on with its caller).
  * include_dir = the directory of this library's kernel headers (chirpgp_amd/csrc in the source tree; include/ is found beside it).
  * A body that does not compile gives CGP_E_ARG with the compiler's messages in cgp_last_error.  d <= 8. */
 typedef struct cgp_custom_model cgp_custom_model;
 #define CGP_CUSTOM_DISCRETE 0
 #define CGP_CUSTOM_SDE      1
+#define CGP_CUSTOM_MEASUREMENT 2
 int  cgp_model_from_source(cgp_ctx* ctx, int kind, int32_t d, const char* body, const char* include_dir, cgp_custom_model** out);
 void cgp_custom_model_destroy(cgp_custom_model* model);
-/* ekf (filters_smoothers.py:222-264) / cd_ekf (:352-397) on a compiled model -- or, with a sigma-point set (a plain point list: xi, w, s, d;
+/* ekf (filters_smoothers.py:222-264) / cd_ekf (:352-397) / ekf_for_kpt (:267-314, CGP_CUSTOM_MEASUREMENT) on a compiled model -- or, with a sigma-point set (a plain point list: xi, w, s, d;
  * groups and flags are not read), sgp_filter (:446-490) / cd_sgp_filter (:534-582); the other arguments as cgp_filter.  The discrete
  * model's covariance is evaluated at every sigma point (filters_smoothers.py:118-120 as written). */
 int cgp_filter_custom(cgp_ctx* ctx, const cgp_custom_model* model, const cgp_sigma* sigma, const double* params, int64_t param_stride,

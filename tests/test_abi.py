@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     assert set(names) == set(eng.EXPORTS), (names, eng.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in chirpgp_hip.h but not exported'
-    assert lib.cgp_version() == 150
+    assert lib.cgp_version() == 160
 
 
 def test_struct_layouts_match_header():

@@ -208,3 +208,59 @@ def test_errors_are_named():
         fs.ekf(pm.custom_cond_m_cov(CHIRP, 9, np.ones(4)), np.ones(9), 0.1, np.zeros(9), np.eye(9), 1e-3, np.zeros(10))
     with pytest.raises(TypeError, match='no host callable'):
         ok(np.zeros(4), 1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- ekf_for_kpt with a measurement function of one's own
+KPT_H2 = r'''
+// models.py:539-580 for two harmonics: h(u) = sum_k u[k] sin(k g(u[0] + u[d-1])), d = 4
+template <class T> __device__ T measure(const T* u, const double* q) {
+    const T phase = softplus(u[0] + u[3]);
+    return u[1] * sin(phase) + u[2] * sin(phase * 2.0);
+}
+'''
+OTHER_H = r'''
+// nothing the library enumerates: per-trial coefficients q, a product and a tanh
+template <class T> __device__ T measure(const T* u, const double* q) {
+    return q[0] * u[0] * sin(u[1]) + q[1] * tanh(u[2]) + exp(u[0] * q[2]);
+}
+'''
+
+
+def test_ekf_for_kpt_with_a_measurement_function_as_source():
+    """filters_smoothers.py:267-314 takes ANY traceable h (H = jacfwd(h)(mp), :304): the reference's own harmonic measurement handed over as
+    source reproduces the compiled-in one (1e-11; the generic kernel's naive softplus against the tile-layout kernel's), and a measurement
+    function of another kind, with per-trial coefficients, agrees with the NumPy oracle (complex-step Jacobian) at 1e-9."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from oracle import np_filters as onf
+    c = cs.kpt_case(T=300, seed=31, nh=2)
+    ys = c.ys[None, :300] + 0.05 * np.random.default_rng(3).standard_normal((5, 300))
+    want = fs.ekf_for_kpt(c.F, c.Sigma, c.h, c.Xi, c.m0, c.P0, c.dt, ys)
+    h = pm.custom_measurement(KPT_H2, 4)
+    got = fs.ekf_for_kpt(c.F, c.Sigma, h, c.Xi, c.m0, c.P0, c.dt, ys)
+    for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+        cs.assert_close(g, w, 1e-11, f'custom kpt measurement {n}')
+    last = fs.ekf_for_kpt(c.F, c.Sigma, h, c.Xi, c.m0, c.P0, c.dt, ys, nll_final_only=True, want=(False, False, True))[2]
+    cs.assert_close(last, want[2][:, -1], 1e-11, 'final NLL')
+    # another h, d = 3, dense F, per-trial q
+    rng = np.random.default_rng(8)
+    d, T, B = 3, 200, 4
+    F = np.eye(d) + 0.05 * rng.standard_normal((d, d))
+    A = 0.1 * rng.standard_normal((d, d))
+    Sigma = A @ A.T + 0.01 * np.eye(d)
+    q = np.stack([np.array([1.0, 0.5, 0.1]) + 0.1 * rng.standard_normal(3) for _ in range(B)])
+    m0, P0, Xi = np.array([0.3, 0.2, -0.1]), 0.5 * np.eye(d), 0.05
+    ys2 = rng.standard_normal((B, T))
+    h2 = pm.custom_measurement(OTHER_H, d, q)
+    got2 = fs.ekf_for_kpt(F, Sigma, h2, Xi, m0, P0, 1e-2, ys2)
+    for b in range(B):
+        def host(u, qb=q[b]):
+            return qb[0] * u[0] * np.sin(u[1]) + qb[1] * np.tanh(u[2]) + np.exp(u[0] * qb[2])
+        want2 = onf.ekf_for_kpt(F, Sigma, host, Xi, m0, P0, 1e-2, ys2[b])
+        for g, w, n in zip(got2, want2, ('mfs', 'Pfs', 'nll')):
+            cs.assert_close(g[b], w, 1e-9, f'custom measurement trial {b} {n}')
+    with pytest.raises(ValueError, match='F must be 3 x 3'):
+        fs.ekf_for_kpt(np.eye(4), np.eye(4), h2, Xi, np.zeros(4), np.eye(4), 1e-2, ys2)
+    with pytest.raises(ValueError, match='at most d'):
+        pm.custom_measurement(OTHER_H, 3, np.ones(5))
+    with pytest.raises(TypeError, match='no host callable'):
+        h2(np.zeros(3))
