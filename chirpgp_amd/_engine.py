@@ -476,6 +476,20 @@ def custom_model(spec, device_index=None):
     return h
 
 
+def release_custom_models():
+    """Unload every runtime-compiled model of this process (cgp_custom_model_destroy: the code objects stay loaded for the life of the process
+    otherwise -- a sweep over many sources would accumulate them).  The streams that used them must have drained: synchronises first."""
+    if not _custom_cache:
+        return 0
+    _torch().cuda.synchronize()
+    lib = load_library()
+    n = len(_custom_cache)
+    for h in _custom_cache.values():
+        lib.cgp_custom_model_destroy(h)
+    _custom_cache.clear()
+    return n
+
+
 def _custom_params(spec, gamma, B, keep):
     params = dev_const(spec.params)
     if params.ndim == 2 and params.shape[0] != B:

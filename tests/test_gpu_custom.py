@@ -264,3 +264,9 @@ def test_ekf_for_kpt_with_a_measurement_function_as_source():
         pm.custom_measurement(OTHER_H, 3, np.ones(5))
     with pytest.raises(TypeError, match='no host callable'):
         h2(np.zeros(3))
+    # the compiled programs can be unloaded and come back on the next call
+    from chirpgp_amd import _engine
+    assert _engine.release_custom_models() >= 2 and _engine.release_custom_models() == 0
+    again = fs.ekf_for_kpt(c.F, c.Sigma, h, c.Xi, c.m0, c.P0, c.dt, ys)
+    for g, w in zip(again, got):
+        assert np.array_equal(g, w)
