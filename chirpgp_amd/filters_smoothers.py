@@ -13,7 +13,7 @@ import numpy as np
 
 from chirpgp_amd import _engine as E
 from chirpgp_amd import models as M
-from chirpgp_amd.quadratures import SigmaPoints
+from chirpgp_amd.quadratures import SigmaPoints      # noqa: F401 (re-exported, as filters_smoothers.py:22 imports it)
 
 __all__ = ['kf', 'rts', 'ekf', 'ekf_for_kpt', 'eks', 'cd_ekf', 'cd_eks',
            'sgp_filter', 'sgp_smoother', 'cd_sgp_filter', 'cd_sgp_smoother']
