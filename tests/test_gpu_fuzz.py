@@ -141,3 +141,64 @@ def test_random_records_through_the_regime_state_machine():
     # the fuzz reached every tier of the state machine
     for k in ('high', 'common', 'low', 'mid', 'wide', 'redone'):
         assert totals[k] > 0, (k, totals)
+
+
+# ------------------------------------------------------------------------------------------------ the sigma-point filters' tiers
+def _dist_any(g, w, n, d):
+    bad = ~(np.isfinite(w) & np.isfinite(g))
+    gf, wf = np.where(bad, 0.0, g), np.where(bad, 0.0, w)
+    if n == 'mfs':
+        return max(cs.max_rel_err(gf[..., c], wf[..., c]) for c in range(d))
+    if n == 'Pfs':
+        sd = np.sqrt(np.maximum(np.abs(wf[..., np.arange(d), np.arange(d)]).reshape(-1, d).max(axis=0), 1e-300))
+        return max(float(np.abs(gf[..., i, j] - wf[..., i, j]).max() / (sd[i] * sd[j])) for i in range(d) for j in range(d))
+    return cs.max_rel_err(gf, wf)
+
+
+@pytest.mark.parametrize('config', ['gh3_d4', 'cubature_d8'])
+def test_random_records_through_the_sigma_point_filters(config):
+    """The sigma-point filters speculate too (cgp_mfma4_sigma.hpp, cgp_coop8.hpp, cgp_lane4.hpp: a lean fan where every point's frequency state
+    sits in the common regime, a branch-free full-accuracy fan behind it, the checked fan beyond 700): the same random record sets -- tracks
+    that cross the bands anywhere, per-trial parameters and noise levels, NaN / inf measurements -- through sgp_filter with Gauss-Hermite order 3
+    on the d = 4 chirp model (one wavefront per trial AND one lane per trial) and with the cubature rule on the three-harmonic model (d = 8, tile
+    layout), against the C port under the conditioning-based gate of the EKF fuzz."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    d = 4 if config == 'gh3_d4' else 8
+    sgps = SigmaPoints.gauss_hermite(4, 3) if config == 'gh3_d4' else SigmaPoints.cubature(8)
+    shapes = ((0x2, 'wave'), (0x4, 'lane')) if config == 'gh3_d4' else ((0x2, 'wave'),)
+    failures, worst, ill, below, arrays = [], dict.fromkeys([s for _, s in shapes], 0.0), 0, 0, 0
+    n_sets = 60
+    for seed in range(n_sets):
+        B, T, dt, Xi, params, ys, _ = make_set(1000 + seed)
+        T = min(T, 1200)
+        ys = np.ascontiguousarray(ys[:, :T])
+        if config == 'gh3_d4':
+            _, _, disc, m0, P0, H = pm.build_chirp_model(params)
+        else:
+            _, _, disc, m0, P0, H = pm.build_harmonic_chirp_model(params, num_harmonics=3)
+        want = port.filter(port.F_SGP, disc, sgps, H, Xi, m0, P0, dt, ys)
+        moved = port.filter(port.F_SGP, disc, sgps, H, Xi, m0, P0, dt, ys * (1 + 1e-15 * np.random.default_rng(seed).choice([-1., 1.], size=ys.shape)))
+        delta = {n: _dist_any(np.asarray(b_), np.asarray(a), n, d) for a, b_, n in zip(want, moved, ('mfs', 'Pfs', 'nll'))}
+        tols = {n: max(1e-9, 300.0 * v) for n, v in delta.items()}
+        tols_lean = {n: max(tols[n], min(1e-7, 2e4 * v)) for n, v in delta.items()}
+        ill += max(tols.values()) > 1e-9
+        for flags, shape in shapes:
+            got = fs.sgp_filter(disc, sgps, H, Xi, m0, P0, dt, ys, flags=flags)
+            for g, w, n in zip(got, want, ('mfs', 'Pfs', 'nll')):
+                g, w = np.asarray(g), np.asarray(w)
+                bad = ~np.isfinite(w)
+                if not (np.array_equal(bad, ~np.isfinite(g)) and np.array_equal(np.isnan(w), np.isnan(g))):
+                    failures.append((seed, shape, n, 'non-finite entries differ', dict(B=B, T=T, dt=dt)))
+                    continue
+                e, tol = _dist_any(g, w, n, d), tols_lean[n]
+                if not e <= tol:
+                    failures.append((seed, shape, n, f'{e:.3e} > {tol:.1e}', dict(B=B, T=T, dt=dt, delta=delta[n])))
+                worst[shape] = max(worst[shape], e)
+                below += e < 1e-10
+                arrays += 1
+                if e > 1e-9:
+                    print(f'  seed {seed} {shape} {n}: {e:.2e}  (B {B} T {T} dt {dt}; the port under a 1e-15 perturbation: {delta[n]:.2e})')
+    print(f'{config}: {n_sets} sets ({ill} ill-conditioned); {below} of {arrays} output arrays below 1e-10; worst ' + ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
+    assert not failures, failures[:6]
