@@ -202,3 +202,98 @@ def test_random_records_through_the_sigma_point_filters(config):
                     print(f'  seed {seed} {shape} {n}: {e:.2e}  (B {B} T {T} dt {dt}; the port under a 1e-15 perturbation: {delta[n]:.2e})')
     print(f'{config}: {n_sets} sets ({ill} ill-conditioned); {below} of {arrays} output arrays below 1e-10; worst ' + ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
     assert not failures, failures[:6]
+
+
+def test_random_records_through_the_smoothers_and_the_continuous_discrete_filters():
+    """The rest of the d = 4 chirp kernels on the random record sets: eks and cd_eks in both launch shapes (the walk / the matrix-core kernel, and one
+    lane per trial), sgp_smoother and cd_sgp_smoother (Gauss-Hermite order 3) on the port's filtering rows, cd_ekf and cd_sgp_filter on the
+    records -- each against the C port under the conditioning-based gate (the smoothers are run on IDENTICAL filtering rows, so their gate is the
+    plain 1e-9 unless the port's smoother itself moves under a 1e-15 perturbation of those rows)."""
+    import copy
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    gh3 = SigmaPoints.gauss_hermite(4, 3)
+    failures, worst, arrays, below, broken, overflowed = [], {}, 0, 0, 0, 0
+
+    def broken_from(want):
+        """Per trial, the first step at which the port's filter has broken down -- a negative variance or a NaN likelihood (RK4 at dt = 1e-2 on a 20 Hz
+        chirp loses the covariance's definiteness; the reference returns NaN from there on).  What any float64 implementation computes behind that
+        point is the rounding noise of differences of 1e80-sized numbers: the port's own sample of it is reproduced only by a kernel with the port's
+        operation order (the DPP kernels do, to 1e-10; the matrix-core ones do not), and nothing is compared there."""
+        Pd = np.asarray(want[1])[..., np.arange(4), np.arange(4)]
+        ok = np.isfinite(np.asarray(want[2])) & (Pd > 0).all(axis=-1) & np.isfinite(np.asarray(want[0])).all(axis=-1)
+        return np.where(ok.all(axis=1), ok.shape[1], np.argmin(ok, axis=1))
+
+    def check(tag, seed, got, want, moved, info, until=None, valid=None):
+        nonlocal arrays, below
+        for i, (g, w, mv) in enumerate(zip(got, want, moved)):
+            g, w, mv = np.array(g), np.array(w), np.array(mv)
+            if until is not None:
+                for b, t in enumerate(until):
+                    g[b, t:], w[b, t:], mv[b, t:] = 0.0, 0.0, 0.0
+            if valid is not None:
+                g[~valid], w[~valid], mv[~valid] = 0.0, 0.0, 0.0
+            n = ('mfs', 'Pfs', 'nll')[i]
+            bad = ~np.isfinite(w)
+            if not (np.array_equal(bad, ~np.isfinite(g)) and np.array_equal(np.isnan(w), np.isnan(g))):
+                failures.append((seed, tag, n, 'non-finite entries differ', info))
+                continue
+            delta = _dist_any(mv, w, n, 4)
+            tol = max(1e-9, 300.0 * delta, min(1e-7, 2e4 * delta))
+            e = _dist_any(g, w, n, 4)
+            if not e <= tol:
+                failures.append((seed, tag, n, f'{e:.3e} > {tol:.1e}', dict(info, delta=delta)))
+            worst[tag] = max(worst.get(tag, 0.0), e)
+            arrays += 1
+            below += e < 1e-10
+
+    for seed in range(40):
+        B, T, dt, Xi, params, ys, _ = make_set(2000 + seed)
+        T = min(T, 800)
+        ys = np.ascontiguousarray(ys[:, :T])
+        info = dict(B=B, T=T, dt=dt)
+        drift, disp, disc, m0, P0, H = pm.build_chirp_model(params)
+        dg = copy.copy(drift)
+        dg.gamma = disp.outer()
+        sign = np.random.default_rng(seed).choice([-1., 1.], size=ys.shape)
+        ys_moved = ys * (1 + 1e-15 * sign)
+        # ---- continuous-discrete filters on the records
+        for tag, method, sg, run in (('cd_ekf', port.F_CD_EKF, None, lambda: fs.cd_ekf(drift, disp, H, Xi, m0, P0, dt, ys)),
+                                     ('cd_sgp_filter', port.F_CD_SGP, gh3, lambda: fs.cd_sgp_filter(drift, disp(None), gh3, H, Xi, m0, P0, dt, ys))):
+            want = port.filter(method, dg, sg, H, Xi, m0, P0, dt, ys)
+            moved = port.filter(method, dg, sg, H, Xi, m0, P0, dt, ys_moved)
+            until = broken_from(want)
+            broken += int((until < T).sum())
+            check(tag, seed, run(), want, moved, info, until)
+        # ---- smoothers on the port's filtering rows (finite records only: a NaN row makes every earlier smoothed row NaN, nothing to compare)
+        fd = port.filter(port.F_EKF, disc, None, H, Xi, m0, P0, dt, ys)
+        fc = port.filter(port.F_CD_EKF, dg, None, H, Xi, m0, P0, dt, ys)
+        # (filtering rows a smoother can be asked to smooth: finite and positive definite throughout, from either filter)
+        finite = np.isfinite(ys).all(axis=1) & (broken_from(fd) == T) & (broken_from(fc) == T)
+        if not finite.any():
+            continue
+        sel = np.flatnonzero(finite)
+        prm = params[sel]
+        drift_s, disp_s, disc_s, _, _, _ = pm.build_chirp_model(prm)
+        dg_s = copy.copy(drift_s)
+        dg_s.gamma = disp_s.outer()
+        for tag, method, model, sg, f, runs in (
+                ('eks', port.S_EKS, disc_s, None, fd, {'wave': lambda m, P: fs.eks(disc_s, m, P, dt, flags=0x2), 'lane': lambda m, P: fs.eks(disc_s, m, P, dt, flags=0x4)}),
+                ('sgp_smoother', port.S_SGP, disc_s, gh3, fd, {'wave': lambda m, P: fs.sgp_smoother(disc_s, gh3, m, P, dt, flags=0x2)}),
+                ('cd_eks', port.S_CD_EKS, dg_s, None, fc, {'wave': lambda m, P: fs.cd_eks(drift_s, disp_s, m, P, dt, flags=0x2), 'lane': lambda m, P: fs.cd_eks(drift_s, disp_s, m, P, dt, flags=0x4)}),
+                ('cd_sgp_smoother', port.S_CD_SGP, dg_s, gh3, fc, {'wave': lambda m, P: fs.cd_sgp_smoother(drift_s, disp_s(None), gh3, m, P, dt, flags=0x2)})):
+            m, P = np.ascontiguousarray(f[0][sel]), np.ascontiguousarray(f[1][sel])
+            if not (np.isfinite(m).all() and np.isfinite(P).all()):
+                continue
+            want = port.smoother(method, model, sg, dt, m, P)
+            moved = port.smoother(method, model, sg, dt, m * (1 + 1e-15), P)
+            # the backward RK4 can overflow as well (dt = 1e-2): rows are compared from the end of the record down to the port's first non-finite
+            # one; behind it the implementations differ in where inf turns into NaN, which is nobody's result
+            ok = np.isfinite(want[0]).all(axis=-1) & np.isfinite(want[1]).all(axis=(-1, -2))
+            valid = np.flip(np.logical_and.accumulate(np.flip(ok, axis=1), axis=1), axis=1)
+            overflowed += int((~valid.all(axis=1)).sum())
+            for shape, run in runs.items():
+                check(f'{tag} {shape}', seed, run(m, P), want, moved, info, valid=valid)
+    print(f'{broken} (trial, filter) pairs broke down and {overflowed} (trial, smoother) pairs overflowed (compared up to there); {below} of {arrays} output arrays below 1e-10; worst by kernel: ' + ', '.join(f'{k} {v:.1e}' for k, v in sorted(worst.items())))
+    assert not failures, failures[:6]
