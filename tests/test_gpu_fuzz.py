@@ -297,3 +297,114 @@ def test_random_records_through_the_smoothers_and_the_continuous_discrete_filter
                 check(f'{tag} {shape}', seed, run(m, P), want, moved, info, valid=valid)
     print(f'{broken} (trial, filter) pairs broke down and {overflowed} (trial, smoother) pairs overflowed (compared up to there); {below} of {arrays} output arrays below 1e-10; worst by kernel: ' + ', '.join(f'{k} {v:.1e}' for k, v in sorted(worst.items())))
     assert not failures, failures[:6]
+
+
+def _gate(g, w, mv, n, d):
+    """(error, tolerance) of one output array under the fuzz's conditioning-based gate; None if the non-finite patterns differ."""
+    g, w, mv = np.asarray(g), np.asarray(w), np.asarray(mv)
+    bad = ~np.isfinite(w)
+    if not (np.array_equal(bad, ~np.isfinite(g)) and np.array_equal(np.isnan(w), np.isnan(g))):
+        return None
+    delta = _dist_any(mv, w, n, d)
+    return _dist_any(g, w, n, d), max(1e-9, 300.0 * delta, min(1e-7, 2e4 * delta))
+
+
+def test_random_models_through_the_other_kernels():
+    """What the chirp fuzz does not reach: the linear kernels at every dimension 1 .. 8 (kf + rts on random stable F, Sigma: generic, d = 4 matrix-core /
+    walk and d >= 5 tile-layout kernels, whole-record and time-split smoothers), the La Scala model (ekf, eks, sgp_filter: the chirp kernels on
+    its parameter layout), the harmonic models at d = 6 and 8 (ekf + eks in the tile layout and per lane), and ekf_for_kpt at d = 3, 4, 5 -- random
+    parameters, noise levels, record lengths and NaN measurements, against the C port under the conditioning-based gate."""
+    from chirpgp_amd import filters_smoothers as fs, models as pm
+    from chirpgp_amd.quadratures import SigmaPoints
+    from oracle import port
+    failures, worst, arrays, below = [], {}, 0, 0
+
+    def compare(tag, seed, got, want, moved, d, names=('mfs', 'Pfs', 'nll')):
+        nonlocal arrays, below
+        for g, w, mv, n in zip(got, want, moved, names):
+            r = _gate(g, w, mv, n, d)
+            if r is None:
+                failures.append((seed, tag, n, 'non-finite entries differ'))
+                continue
+            e, tol = r
+            if not e <= tol:
+                failures.append((seed, tag, n, f'{e:.3e} > {tol:.1e}'))
+            worst[tag] = max(worst.get(tag, 0.0), e)
+            arrays += 1
+            below += e < 1e-10
+
+    for seed in range(48):
+        rng = np.random.default_rng(70000 + seed)
+        B, T = int(rng.integers(2, 7)), int(rng.integers(30, 700))
+        sign = rng.choice([-1., 1.], size=(B, T))
+        # ---- linear: kf + rts, d = 1 .. 8
+        d = 1 + seed % 8
+        A = rng.standard_normal((d, d))
+        F = 0.97 * A / max(np.abs(np.linalg.eigvals(A)).max(), 1e-3) if d > 1 else np.array([[0.9]])
+        L = 0.3 * rng.standard_normal((d, d))
+        Sigma = L @ L.T + 0.01 * np.eye(d)
+        H = rng.standard_normal(d)
+        Xi = 10 ** rng.uniform(-2, 0)
+        m0, P0 = rng.standard_normal(d), np.eye(d) * rng.uniform(0.2, 2.0)
+        ys = rng.standard_normal((B, T))
+        if rng.random() < 0.3:
+            ys[rng.integers(0, B), rng.integers(0, T)] = np.nan
+        lin = pm.linear_cond_m_cov(F, Sigma)
+        want = port.filter(port.F_EKF, lin, None, H, Xi, m0, P0, 0.0, ys)
+        moved = port.filter(port.F_EKF, lin, None, H, Xi, m0, P0, 0.0, ys * (1 + 1e-15 * sign))
+        for name, fl in (('wave', 0x2), ('lane', 0x4), ('generic', 0x12)):
+            compare(f'kf d{d} {name}', seed, fs.kf(F, Sigma, H, Xi, m0, P0, ys, flags=fl), want, moved, d)
+        ok = np.isfinite(ys).all(axis=1)
+        if ok.any():
+            m, P = np.ascontiguousarray(want[0][ok]), np.ascontiguousarray(want[1][ok])
+            ws = port.smoother(port.S_EKS, lin, None, 0.0, m, P)
+            ms = port.smoother(port.S_EKS, lin, None, 0.0, m * (1 + 1e-15), P)
+            for name, fl in (('wave', 0x2), ('lane', 0x4), ('generic', 0x12), ('time-split', 0x2 | 0x800)):
+                compare(f'rts d{d} {name}', seed, fs.rts(F, Sigma, m, P, flags=fl), ws, ms, d, ('mfs', 'Pfs'))
+        # ---- La Scala (d = 4), harmonic (d = 6, 8), KPT (d = 3, 4, 5): a toy chirp per trial
+        dt = 1e-3
+        ts = dt * np.arange(1, T + 1)
+        f0 = rng.uniform(2.0, 12.0, size=(B, 1))
+        ysc = np.sin(2 * np.pi * (f0 * ts + 0.5 * rng.uniform(-3, 3, size=(B, 1)) * ts ** 2)) + np.sqrt(0.1) * rng.standard_normal((B, T))
+        kind = seed % 3
+        if kind == 0:
+            prm = np.array([0.1, 1.0, 1.0, 7.0]) * rng.uniform(0.6, 1.5, size=(B, 4))
+            _, _, disc, m0c, P0c, Hc = pm.build_lascala_model(prm)
+            gh3 = SigmaPoints.gauss_hermite(4, 3)
+            for tag, method, sg, run in (('lascala ekf', port.F_EKF, None, lambda fl: fs.ekf(disc, Hc, 0.1, m0c, P0c, dt, ysc, flags=fl)),
+                                         ('lascala sgp_filter', port.F_SGP, gh3, lambda fl: fs.sgp_filter(disc, gh3, Hc, 0.1, m0c, P0c, dt, ysc, flags=fl))):
+                want = port.filter(method, disc, sg, Hc, 0.1, m0c, P0c, dt, ysc)
+                moved = port.filter(method, disc, sg, Hc, 0.1, m0c, P0c, dt, ysc * (1 + 1e-15 * sign))
+                for name, fl in (('wave', 0x2), ('lane', 0x4)):
+                    compare(f'{tag} {name}', seed, run(fl), want, moved, 4)
+                if sg is None:
+                    ws = port.smoother(port.S_EKS, disc, None, dt, want[0], want[1])
+                    ms = port.smoother(port.S_EKS, disc, None, dt, want[0] * (1 + 1e-15), want[1])
+                    for name, fl in (('wave', 0x2), ('lane', 0x4), ('time-split', 0x2 | 0x800)):
+                        compare(f'lascala eks {name}', seed, fs.eks(disc, want[0], want[1], dt, flags=fl), ws, ms, 4, ('mfs', 'Pfs'))
+        elif kind == 1:
+            nh = 2 + (seed // 3) % 2
+            dd = 2 * nh + 2
+            prm = np.array([0.1, 0.1, 0.1, 1.0, 1.0, 7.0]) * rng.uniform(0.6, 1.5, size=(B, 6))
+            _, _, disc, m0c, P0c, Hc = pm.build_harmonic_chirp_model(prm, num_harmonics=nh)
+            want = port.filter(port.F_EKF, disc, None, Hc, 0.1, m0c, P0c, dt, ysc)
+            moved = port.filter(port.F_EKF, disc, None, Hc, 0.1, m0c, P0c, dt, ysc * (1 + 1e-15 * sign))
+            for name, fl in (('wave', 0x2), ('lane', 0x4)):
+                compare(f'harmonic{nh} ekf {name}', seed, fs.ekf(disc, Hc, 0.1, m0c, P0c, dt, ysc, flags=fl), want, moved, dd)
+            ws = port.smoother(port.S_EKS, disc, None, dt, want[0], want[1])
+            ms = port.smoother(port.S_EKS, disc, None, dt, want[0] * (1 + 1e-15), want[1])
+            for name, fl in (('wave', 0x2), ('lane', 0x4), ('time-split', 0x2 | 0x800)):
+                compare(f'harmonic{nh} eks {name}', seed, fs.eks(disc, want[0], want[1], dt, flags=fl), ws, ms, dd, ('mfs', 'Pfs'))
+        else:
+            nh = 1 + (seed // 3) % 3
+            c = cs.kpt_case(T=max(T, 2), seed=seed, nh=nh, params=tuple(np.array([0.5, 1e-4, 0.1, 8., 1.]) * rng.uniform(0.7, 1.4, size=5)))
+            yk = c.ys[None, :T] + 0.05 * rng.standard_normal((B, T))
+            spec = pm.linear_cond_m_cov(c.F, c.Sigma)
+            spec.model_id, spec.n_harm = pm.M_KPT, nh
+            want = port.filter(port.F_EKF_KPT, spec, None, None, c.Xi, c.m0, c.P0, c.dt, yk)
+            moved = port.filter(port.F_EKF_KPT, spec, None, None, c.Xi, c.m0, c.P0, c.dt, yk * (1 + 1e-15 * sign))
+            for name, fl in (('wave', 0x2), ('lane', 0x4), ('generic', 0x12)):
+                compare(f'kpt{nh} {name}', seed, fs.ekf_for_kpt(c.F, c.Sigma, c.h, c.Xi, c.m0, c.P0, c.dt, yk, flags=fl), want, moved, nh + 2)
+    print(f'{below} of {arrays} output arrays below 1e-10; worst by kernel family: ' +
+          ', '.join(f'{k} {v:.1e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]))
+    assert not failures, failures[:8]
