@@ -19,6 +19,8 @@ headline kernel's speculative step; "exact_lost": the filter starts 1.5 Hz off a
 
     python -m tests.golden.make_exact          (about two minutes)
     python -m tests.golden.make_exact --grad   (exact_grad.npz: the MLE objective's exact gradient on the same records; about five minutes)
+    python -m tests.golden.make_exact --rest   (exact_rest.npz: kf, rts, cd_ekf, cd_eks, ekf_for_kpt on the first record -- with the three pairs above,
+                                                all eleven public functions of filters_smoothers.py; about a minute)
 """
 import math
 import os
@@ -300,6 +302,80 @@ def pipelines(params, Xi, dt, ys, cd_T):
     return res
 
 
+def pipelines_rest(params, Xi, dt, ys, cd_T):
+    """The five functions the first fixtures leave out -- kf + rts (:145-219), cd_ekf + cd_eks (:352-443), ekf_for_kpt (:267-314) -- so that every
+    public function of filters_smoothers.py has its exact values: --rest writes tests/golden/exact_rest.npz."""
+    drift, b, cond, m0, P0, H = build_chirp_model(params)
+    Xi, dt = mpf(float(Xi)), mpf(float(dt))
+    ys = [mpf(float(y)) for y in ys]
+    gamma = matmul(b, tr(b))
+    res, extra = {}, {}
+
+    # ---- kf + rts on the chirp model frozen at its initial frequency state (the linear test model of bench.py's C1): F = d mean / d u there
+    F = jacobian(lambda u: cond(u, dt)[0], m0)
+    Sig = cond(m0, dt)[1]
+
+    def kf_step(mf, Pf, y):                                             # :48-68, 145-184
+        return linear_update(matvec(F, mf), madd(matmul(matmul(F, Pf), tr(F)), Sig), H, Xi, y)
+
+    def rts_step(ms, Ps, mf, Pf):                                       # :187-219
+        return smoother_common(matmul(F, Pf), mf, Pf, matvec(F, mf), madd(matmul(matmul(F, Pf), tr(F)), Sig), ms, Ps)
+    f = run_filter(kf_step, m0, P0, ys)
+    res['kf'], res['rts'] = f, run_smoother(rts_step, f)
+    extra['kf.F'], extra['kf.Sigma'] = [[float(v) for v in r] for r in F], [[float(v) for v in r] for r in Sig]
+    print('  kf + rts done', flush=True)
+
+    # ---- cd_ekf + cd_eks
+    def cde_ode(m, P):                                                  # :384-385
+        J = jacobian(drift, m)
+        return drift(m), madd(madd(matmul(P, tr(J)), matmul(J, P)), gamma)
+
+    def cde_step(mf, Pf, y):
+        mp_, Pp = rk4(cde_ode, mf, Pf, dt)
+        return linear_update(mp_, Pp, H, Xi, y)
+
+    def cds_ode(m, P, mf, Pf):                                          # :427-432
+        A = madd(jacobian(drift, m), tr(cho_solve(Pf, tr(gamma))))
+        sol = cho_solve(Pf, [[v] for v in vadd(m, mf, -1)])
+        return vadd(drift(m), matvec(gamma, [r[0] for r in sol])), madd(madd(matmul(A, P), matmul(P, tr(A))), gamma, -1)
+
+    def cds_step(ms, Ps, mf, Pf):
+        return rk4(cds_ode, ms, Ps, -dt, mf, Pf)
+    f = run_filter(cde_step, m0, P0, ys[:cd_T])
+    res['cd_ekf'], res['cd_eks'] = f, run_smoother(cds_step, f)
+    print('  cd_ekf + cd_eks done', flush=True)
+
+    # ---- ekf_for_kpt on build_kpt_chirp_model((0.5, 1e-4, 0.1, 8, 1), fs = 1 / dt, two harmonics) (models.py:522-580)
+    q1, q2, p0, f0, a0 = (mpf(v) for v in ('0.5', '0.0001', '0.1', '8', '1'))
+    fs_, nh, d = 1 / dt, 2, 4
+    Fk = [[mpf(1 if i == j else 0) for j in range(d)] for i in range(d)]
+    Fk[d - 1][0] = mpf(1)
+    Sk = zeros(d, d)
+    Sk[0][0] = (2 * mp.pi * q1 / fs_) ** 2
+    for k in range(1, nh + 1):
+        Sk[k][k] = q2
+    m0k = [2 * mp.pi * f0 / fs_] + [a0] * nh + [mpf(0)]
+    P0k = [[p0 if i == j else mpf(0) for j in range(d)] for i in range(d)]
+
+    def h(x):
+        ph = g(x[0] + x[d - 1])
+        return sum(x[k] * mp.sin(ph * k) for k in range(1, nh + 1))
+
+    def kpt_step(mf, Pf, y):                                            # :298-311
+        mp_, Pp = matvec(Fk, mf), madd(matmul(matmul(Fk, Pf), tr(Fk)), Sk)
+        Hk = jacobian(lambda x: [h(x)], mp_)[0]
+        PH = matvec(Pp, Hk)
+        S = sum(a * v for a, v in zip(Hk, PH)) + Xi
+        K = [v / S for v in PH]
+        pred = h(mp_)
+        scale2 = mp.sqrt(S) ** 2
+        nll = (mp.log(2 * mp.pi * scale2) + (y - pred) ** 2 / scale2) / 2
+        return vadd(mp_, [k * (y - pred) for k in K]), madd(Pp, mscale(outer(K, K), S), -1), nll
+    res['ekf_for_kpt'] = run_filter(kpt_step, m0k, P0k, ys)
+    print('  ekf_for_kpt done', flush=True)
+    return res, extra
+
+
 def ekf_final_nll(params, Xi, dt, ys):
     """ekf(...)[2][-1] (filters_smoothers.py:222-264) for mpf parameters: the MLE objective of demos/ekfs_mle.py:42-47"""
     drift, b, cond, m0, P0, H = build_chirp_model(params)
@@ -359,9 +435,19 @@ def main_gradient():
     np.savez_compressed(os.path.join(OUT, 'exact_grad.npz'), digits=mp.dps, **out)
 
 
+def main_rest():
+    """tests/golden/exact_rest.npz: kf, rts, cd_ekf, cd_eks, ekf_for_kpt on the tracking record"""
+    name, p, Xi, dt, ys = records()[0]
+    print(name, 'rest', flush=True)
+    res, extra = pipelines_rest(p, Xi, dt, ys, cd_T=300)
+    np.savez_compressed(os.path.join(OUT, 'exact_rest.npz'), ys=ys, params=p, Xi=Xi, dt=dt, digits=mp.dps, **{k.replace('.', '_'): np.array(v) for k, v in extra.items()}, **to_f64(res))
+
+
 def main():
     if '--grad' in sys.argv:
         return main_gradient()
+    if '--rest' in sys.argv:
+        return main_rest()
     for name, p, Xi, dt, ys in records():
         print(name, flush=True)
         res = pipelines(p, Xi, dt, ys, cd_T=300)

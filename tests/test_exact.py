@@ -88,3 +88,71 @@ def test_hip_kernels_sit_within_the_same_distance(name, shape):
             # the lean polynomials of the speculative tiers (softplus to 1e-11) are an engine design decision, not rounding: 1e-8 there
             limit = max(GATE[fn], 1e-8 / EPS) if fn in ('ekf', 'eks') else GATE[fn] * 10
             assert a < limit, (name, fn, a)
+
+
+# ------------------------------------------------------------------------------------------------ the other five functions (exact_rest.npz)
+# measured (pytest -s), units of 2^-53, NumPy oracle / C port: kf 164 / 154, rts 381 / 430, cd_ekf 23 / 32, cd_eks 97 / 101, ekf_for_kpt 73 / 73;
+# gates about a decade above
+GATE_REST = {'kf': 2e3, 'rts': 5e3, 'cd_ekf': 500., 'cd_eks': 2e3, 'ekf_for_kpt': 1e3}
+
+
+def _rest(backend, z, exact, hip_kw=None):
+    """kf, rts, cd_ekf, cd_eks, ekf_for_kpt of one implementation on the fixture's record"""
+    from chirpgp_amd import models as pm
+    from oracle import np_filters as onf, np_models as om, port
+    c = _case(z)
+    F, Sigma = z['kf_F'], z['kf_Sigma']
+    cd_T = exact['cd_ekf'][0].shape[0]
+    k = cs.kpt_case(T=8, nh=2, fs=1.0 / float(z['dt']), Xi=float(z['Xi']))
+    out = {}
+    if backend == 'hip':
+        from chirpgp_amd import filters_smoothers as fs
+        kw = hip_kw or {}
+        out['kf'] = fs.kf(F, Sigma, c.H, c.Xi, c.m0, c.P0, c.ys, **kw)
+        out['rts'] = fs.rts(F, Sigma, out['kf'][0], out['kf'][1], **kw)
+        out['cd_ekf'] = fs.cd_ekf(c.drift, c.disp, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys[:cd_T], **kw)
+        out['cd_eks'] = fs.cd_eks(c.drift, c.disp, out['cd_ekf'][0], out['cd_ekf'][1], c.dt, **kw)
+        out['ekf_for_kpt'] = fs.ekf_for_kpt(k.F, k.Sigma, k.h, k.Xi, k.m0, k.P0, k.dt, c.ys, **kw)
+    elif backend == 'port':
+        import copy
+        lin = pm.linear_cond_m_cov(F, Sigma)
+        dg = copy.copy(c.drift)
+        dg.gamma = c.disp.outer()
+        out['kf'] = port.filter(port.F_EKF, lin, None, c.H, c.Xi, c.m0, c.P0, 0.0, c.ys)
+        out['rts'] = port.smoother(port.S_EKS, lin, None, 0.0, out['kf'][0], out['kf'][1])
+        out['cd_ekf'] = port.filter(port.F_CD_EKF, dg, None, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys[:cd_T])
+        out['cd_eks'] = port.smoother(port.S_CD_EKS, dg, None, c.dt, out['cd_ekf'][0], out['cd_ekf'][1])
+        spec = pm.linear_cond_m_cov(k.F, k.Sigma)
+        spec.model_id, spec.n_harm = pm.M_KPT, 2
+        out['ekf_for_kpt'] = port.filter(port.F_EKF_KPT, spec, None, None, k.Xi, k.m0, k.P0, k.dt, c.ys)
+    else:
+        out['kf'] = onf.kf(F, Sigma, c.H, c.Xi, c.m0, c.P0, c.ys)
+        out['rts'] = onf.rts(F, Sigma, out['kf'][0], out['kf'][1])
+        out['cd_ekf'] = onf.cd_ekf(c.o_drift, c.o_disp, c.H, c.Xi, c.m0, c.P0, c.dt, c.ys[:cd_T])
+        out['cd_eks'] = onf.cd_eks(c.o_drift, c.o_disp, out['cd_ekf'][0], out['cd_ekf'][1], c.dt)
+        out['ekf_for_kpt'] = onf.ekf_for_kpt(k.F, k.Sigma, k.o_h, k.Xi, k.m0, k.P0, k.dt, c.ys)
+    return out
+
+
+@pytest.mark.parametrize('backend', ['numpy', 'port'])
+def test_cpu_oracles_against_the_exact_values_of_the_other_five_functions(backend):
+    """kf, rts, cd_ekf, cd_eks, ekf_for_kpt (filters_smoothers.py:145-219, 352-443, 267-314): with the three pairs above every public function of
+    the reference's module has been evaluated in 100-digit arithmetic, and both oracles sit within the recursion's amplification of it."""
+    z, exact = _load('exact_rest')
+    assert int(z['digits']) >= 40
+    got = _rest(backend, z, exact)
+    for fn in GATE_REST:
+        a = _amplification(got[fn], exact[fn])
+        print(f'exact_rest {backend:5s} {fn:12s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+        assert a < GATE_REST[fn], (backend, fn, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', ['wave', 'lane'])
+def test_hip_kernels_against_the_exact_values_of_the_other_five_functions(shape):
+    z, exact = _load('exact_rest')
+    got = _rest('hip', z, exact, hip_kw=dict(flags=0x2 if shape == 'wave' else 0x4))
+    for fn in GATE_REST:
+        a = _amplification(got[fn], exact[fn])
+        print(f'exact_rest hip/{shape} {fn:12s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+        assert a < GATE_REST[fn] * 10, (shape, fn, a)
