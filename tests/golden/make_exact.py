@@ -21,6 +21,8 @@ headline kernel's speculative step; "exact_lost": the filter starts 1.5 Hz off a
     python -m tests.golden.make_exact --grad   (exact_grad.npz: the MLE objective's exact gradient on the same records; about five minutes)
     python -m tests.golden.make_exact --rest   (exact_rest.npz: kf, rts, cd_ekf, cd_eks, ekf_for_kpt on the first record -- with the three pairs above,
                                                 all eleven public functions of filters_smoothers.py; about a minute)
+    python -m tests.golden.make_exact --harmonic  (exact_harmonic.npz: BASELINE C5's model -- three harmonics, d = 8 -- with ekf + eks and the cubature
+                                                sgp_filter + sgp_smoother)
 """
 import math
 import os
@@ -208,7 +210,7 @@ def sgp_prediction(sg, cond_m_cov, dt, mf, Pf):                         # :88-12
     ev = [cond_m_cov(c, dt) for c in chi]
     fm = [e[0] for e in ev]
     mp_ = sg.expect_vec(fm)
-    Ecov = zeros(4, 4)
+    Ecov = zeros(len(mf), len(mf))
     for w, e in zip(sg.w, ev):
         Ecov = madd(Ecov, mscale(e[1], w))
     Pp = madd(madd(sg.expect_outer(fm, fm), Ecov), outer(mp_, mp_), -1)
@@ -376,6 +378,72 @@ def pipelines_rest(params, Xi, dt, ys, cd_T):
     return res, extra
 
 
+class Cubature(GH3):
+    """SigmaPoints.cubature(d), quadratures.py:138-150: +- sqrt(d) e_k, weights 1 / (2 d)"""
+    def __init__(self, d):
+        r = mp.sqrt(d)
+        self.xi = [[(r if j == k else mpf(0)) for j in range(d)] for k in range(d)] + [[(-r if j == k else mpf(0)) for j in range(d)] for k in range(d)]
+        self.w = [mpf(1) / (2 * d)] * (2 * d)
+
+
+def build_harmonic_chirp_model(params, nh):
+    """models.py:462-494 with 122-178 and 332-386 (freq_scale = 1): (cond_m_cov, m0, P0, H), d = 2 nh + 2"""
+    lam, b, delta, ell, sigma, m0_v = (mpf(float(p)) for p in params)
+
+    def cond_m_cov(u, dt):
+        w = 2 * mp.pi * g(u[-2])
+        e = mp.exp(-lam * dt)
+        Fm, Sm = m32_solution(ell, sigma, dt)
+        mean = []
+        for k in range(1, nh + 1):
+            c, s_ = mp.cos(dt * k * w), mp.sin(dt * k * w)
+            a, bb = u[2 * k - 2], u[2 * k - 1]
+            mean += [e * (c * a - s_ * bb), e * (s_ * a + c * bb)]
+        mean += [Fm[0][0] * u[-2] + Fm[0][1] * u[-1], Fm[1][0] * u[-2] + Fm[1][1] * u[-1]]
+        q = b ** 2 * dt if lam == 0 else b ** 2 / (2 * lam) * (1 - mp.exp(-2 * lam * dt))
+        return mean, blkdiag(*([q] * (2 * nh)), Sm)
+    m0 = [mpf(0), mpf(1)] * nh + [m0_v, mpf(0)]
+    P0 = blkdiag(*([delta] * (2 * nh)), [[sigma ** 2, mpf(0)], [mpf(0), (mp.sqrt(3) / ell) ** 2 * sigma ** 2]])
+    H = [mpf(0), mpf(1)] * nh + [mpf(0), mpf(0)]
+    return cond_m_cov, m0, P0, H
+
+
+def pipelines_harmonic(params, Xi, dt, ys, nh=3):
+    """BASELINE C5's methods -- sgp_filter + sgp_smoother with the cubature rule on the three-harmonic model, d = 8 (demos/ghfs_harmonics_mle.py:25-27)
+    -- and ekf + eks on the same model: --harmonic writes tests/golden/exact_harmonic.npz."""
+    cond, m0, P0, H = build_harmonic_chirp_model(params, nh)
+    Xi, dt = mpf(float(Xi)), mpf(float(dt))
+    ys = [mpf(float(y)) for y in ys]
+    sg = Cubature(2 * nh + 2)
+    res = {}
+
+    def ekf_step(mf, Pf, y):
+        J = jacobian(lambda u: cond(u, dt)[0], mf)
+        mp_, Sig = cond(mf, dt)
+        return linear_update(mp_, madd(matmul(matmul(J, Pf), tr(J)), Sig), H, Xi, y)
+
+    def eks_step(ms, Ps, mf, Pf):
+        J = jacobian(lambda u: cond(u, dt)[0], mf)
+        mp_, Sig = cond(mf, dt)
+        return smoother_common(matmul(J, Pf), mf, Pf, mp_, madd(matmul(matmul(J, Pf), tr(J)), Sig), ms, Ps)
+    f = run_filter(ekf_step, m0, P0, ys)
+    res['ekf'], res['eks'] = f, run_smoother(eks_step, f)
+    print('  ekf + eks (d = 8) done', flush=True)
+
+    def sgpf_step(mf, Pf, y):
+        mp_, Pp, _, _ = sgp_prediction(sg, cond, dt, mf, Pf)
+        return linear_update(mp_, Pp, H, Xi, y)
+
+    def sgps_step(ms, Ps, mf, Pf):
+        mp_, Pp, chi, fm = sgp_prediction(sg, cond, dt, mf, Pf)
+        D = madd(sg.expect_outer(chi, fm), outer(mf, mp_), -1)
+        return smoother_common(tr(D), mf, Pf, mp_, Pp, ms, Ps)
+    f = run_filter(sgpf_step, m0, P0, ys)
+    res['sgp_filter'], res['sgp_smoother'] = f, run_smoother(sgps_step, f)
+    print('  sgp_filter + sgp_smoother (cubature, d = 8) done', flush=True)
+    return res
+
+
 def ekf_final_nll(params, Xi, dt, ys):
     """ekf(...)[2][-1] (filters_smoothers.py:222-264) for mpf parameters: the MLE objective of demos/ekfs_mle.py:42-47"""
     drift, b, cond, m0, P0, H = build_chirp_model(params)
@@ -443,9 +511,22 @@ def main_rest():
     np.savez_compressed(os.path.join(OUT, 'exact_rest.npz'), ys=ys, params=p, Xi=Xi, dt=dt, digits=mp.dps, **{k.replace('.', '_'): np.array(v) for k, v in extra.items()}, **to_f64(res))
 
 
+def main_harmonic():
+    """tests/golden/exact_harmonic.npz: the three-harmonic model (d = 8) on tests/cases.py:harmonic_case's record (T = 300)"""
+    sys.path.insert(0, ROOT)
+    from tests import cases
+    c = cases.harmonic_case(T=300, seed=12, nh=3)
+    p = np.array([0.1, 0.1, 0.1, 1., 1., 7.])
+    print('exact_harmonic', flush=True)
+    res = pipelines_harmonic(p, c.Xi, c.dt, c.ys)
+    np.savez_compressed(os.path.join(OUT, 'exact_harmonic.npz'), ys=c.ys, params=p, Xi=c.Xi, dt=c.dt, nh=3, digits=mp.dps, **to_f64(res))
+
+
 def main():
     if '--grad' in sys.argv:
         return main_gradient()
+    if '--harmonic' in sys.argv:
+        return main_harmonic()
     if '--rest' in sys.argv:
         return main_rest()
     for name, p, Xi, dt, ys in records():

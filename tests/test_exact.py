@@ -156,3 +156,38 @@ def test_hip_kernels_against_the_exact_values_of_the_other_five_functions(shape)
         a = _amplification(got[fn], exact[fn])
         print(f'exact_rest hip/{shape} {fn:12s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
         assert a < GATE_REST[fn] * 10, (shape, fn, a)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE C5's model (exact_harmonic.npz)
+# measured, units of 2^-53, NumPy oracle / C port: ekf 1.2e3 / 1.2e3, eks 2.9e3 / 2.8e3, sgp_filter 2.7e4 / 9.9e3, sgp_smoother 1.6e5 / 8.8e4
+GATE_HARM = {'ekf': 2e4, 'eks': 5e4, 'sgp_filter': 5e5, 'sgp_smoother': 2e6}
+
+
+def _harmonic(backend, z, hip_kw=None):
+    from tests import backends as bk
+    c = cs.harmonic_case(T=8, nh=int(z['nh']), params=tuple(z['params']), Xi=float(z['Xi']), dt=float(z['dt']))
+    c.ys = z['ys']
+    return bk.run_pairs(backend, c, only=('ekf', 'sgp_filter'), **({'hip_kw': hip_kw} if hip_kw else {}))
+
+
+@pytest.mark.parametrize('backend', ['numpy', 'port'])
+def test_cpu_oracles_against_the_exact_values_on_the_three_harmonic_model(backend):
+    """ekf + eks and the cubature sgp_filter + sgp_smoother at d = 8 (BASELINE C5: demos/ghfs_harmonics_mle.py:25-27) -- with this every BASELINE
+    configuration's method has been evaluated in 100-digit arithmetic (C1 kf / rts, C2, C3, C4 above)."""
+    z, exact = _load('exact_harmonic')
+    got = _harmonic(backend, z)
+    for fn in GATE_HARM:
+        a = _amplification(got[fn], exact[fn])
+        print(f'exact_harmonic {backend:5s} {fn:14s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+        assert a < GATE_HARM[fn], (backend, fn, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', ['wave', 'lane'])
+def test_hip_kernels_against_the_exact_values_on_the_three_harmonic_model(shape):
+    z, exact = _load('exact_harmonic')
+    got = _harmonic('hip', z, hip_kw=dict(flags=0x2 if shape == 'wave' else 0x4))
+    for fn in GATE_HARM:
+        a = _amplification(got[fn], exact[fn])
+        print(f'exact_harmonic hip/{shape} {fn:14s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+        assert a < max(GATE_HARM[fn] * 10, 1e-8 / EPS), (shape, fn, a)
