@@ -76,3 +76,25 @@ def test_a_stale_library_is_refused(monkeypatch):
         eng.load_library()
     monkeypatch.setattr(eng, 'source_hash', lambda: None)            # binary-only install: nothing to compare with
     assert eng.load_library() is not None
+
+
+def test_the_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The drop-in boundary is a C-ABI: include/chirpgp_hip.h compiles as pedantic C99 (and as C++11), its struct sizes are what the ctypes mirror
+    assumes, and a C program that links against libchirpgp_hip.so sees the version and source hash -- no Python, no torch type in any signature."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    _lib()
+    src = tmp_path / 'abi.c'
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "chirpgp_hip.h"\n'
+                   'int main(void) {\n'
+                   '    printf("%d %zu %zu %zu %zu %zu\\n", cgp_version(), sizeof(cgp_model), sizeof(cgp_sigma), sizeof(cgp_init), sizeof(cgp_smooth_out), strlen(cgp_source_hash()));\n'
+                   '    return cgp_version() == CGP_VERSION && cgp_filter(NULL, 0, NULL, NULL, NULL, 0.0, NULL, 1, 1, NULL, 1, 1, NULL, NULL, NULL, 0u, NULL) == CGP_E_ARG ? 0 : 1;\n}\n')
+    inc, libdir = os.path.join(ROOT, 'include'), os.path.join(ROOT, 'chirpgp_amd')
+    exe = tmp_path / 'abi'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', f'-I{inc}', str(src), '-o', str(exe), f'-L{libdir}', '-lchirpgp_hip',
+                    f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib'], check=True, capture_output=True)
+    subprocess.run(['g++', '-std=c++11', '-Wall', '-Wextra', '-Werror', f'-I{inc}', '-x', 'c++', '-fsyntax-only', str(src)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == [160, 48, 40, 64, 72, 64], out
