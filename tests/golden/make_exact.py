@@ -21,6 +21,7 @@ headline kernel's speculative step; "exact_lost": the filter starts 1.5 Hz off a
     python -m tests.golden.make_exact --grad   (exact_grad.npz: the MLE objective's exact gradient on the same records; about five minutes)
     python -m tests.golden.make_exact --rest   (exact_rest.npz: kf, rts, cd_ekf, cd_eks, ekf_for_kpt on the first record -- with the three pairs above,
                                                 all eleven public functions of filters_smoothers.py; about a minute)
+    python -m tests.golden.make_exact --lascala   (exact_lascala.npz: the La Scala model through the six pipelines of the first fixtures)
     python -m tests.golden.make_exact --harmonic  (exact_harmonic.npz: BASELINE C5's model -- three harmonics, d = 8 -- with ekf + eks and the cubature
                                                 sgp_filter + sgp_smoother)
 """
@@ -522,9 +523,22 @@ def main_harmonic():
     np.savez_compressed(os.path.join(OUT, 'exact_harmonic.npz'), ys=c.ys, params=p, Xi=c.Xi, dt=c.dt, nh=3, digits=mp.dps, **to_f64(res))
 
 
+def main_lascala():
+    """tests/golden/exact_lascala.npz: the La Scala model (models.py:181-261, 419-434, 497-519) -- the chirp model without damping and without chirp
+    noise: its drift, dispersion and discretisation are build_chirp_model's at lam = b = 0 (the lam == 0 branch of :302-308 gives q = 0) -- through
+    the same six pipelines on the first record (tetralith/jobs/lascala_ekfs_mle.py, lascala_ghfs_mle.py)"""
+    name, _, Xi, dt, ys = records()[0]
+    p = np.array([0.1, 1., 1., 7.])                                          # delta, ell, sigma, m0_v
+    print('exact_lascala', flush=True)
+    res = pipelines([0., 0., p[0], p[1], p[2], p[3]], Xi, dt, ys, cd_T=300)
+    np.savez_compressed(os.path.join(OUT, 'exact_lascala.npz'), ys=ys, params=p, Xi=Xi, dt=dt, digits=mp.dps, **to_f64(res))
+
+
 def main():
     if '--grad' in sys.argv:
         return main_gradient()
+    if '--lascala' in sys.argv:
+        return main_lascala()
     if '--harmonic' in sys.argv:
         return main_harmonic()
     if '--rest' in sys.argv:

@@ -191,3 +191,37 @@ def test_hip_kernels_against_the_exact_values_on_the_three_harmonic_model(shape)
         a = _amplification(got[fn], exact[fn])
         print(f'exact_harmonic hip/{shape} {fn:14s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
         assert a < max(GATE_HARM[fn] * 10, 1e-8 / EPS), (shape, fn, a)
+
+
+# ------------------------------------------------------------------------------------------------ the La Scala model (exact_lascala.npz)
+def _lascala(backend, z, cd_T, hip_kw=None):
+    from tests import backends as bk
+    c = cs.lascala_case(T=8, params=tuple(z['params']), Xi=float(z['Xi']), dt=float(z['dt']))
+    c.ys = z['ys']
+    c.sgps = cs.chirp_case(T=8).sgps                          # Gauss-Hermite order 3, d = 4
+    return bk.run_pairs(backend, c, cd_T=cd_T, only=('ekf', 'sgp_filter', 'cd_sgp_filter'), **({'hip_kw': hip_kw} if hip_kw else {}))
+
+
+@pytest.mark.parametrize('backend', ['numpy', 'port'])
+def test_cpu_oracles_against_the_exact_values_on_the_lascala_model(backend):
+    """models.py:181-261, 419-434, 497-519 (tetralith/jobs/lascala_*_mle.py): the six pipelines of the first fixtures on the model without damping and
+    chirp noise -- a singular process covariance, which the chirp records never exercise."""
+    z, exact = _load('exact_lascala')
+    got = _lascala(backend, z, exact['cd_sgp_filter'][0].shape[0])
+    for f, s in PAIRS:
+        for fn in (f, s):
+            a = _amplification(got[fn], exact[fn])
+            print(f'exact_lascala {backend:5s} {fn:16s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+            assert a < GATE[fn], (backend, fn, a)                # (the chirp model's gates hold as they are: 472 .. 4.3e5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', ['wave', 'lane'])
+def test_hip_kernels_against_the_exact_values_on_the_lascala_model(shape):
+    z, exact = _load('exact_lascala')
+    got = _lascala('hip', z, exact['cd_sgp_filter'][0].shape[0], hip_kw=dict(flags=0x2 if shape == 'wave' else 0x4))
+    for f, s in PAIRS:
+        for fn in (f, s):
+            a = _amplification(got[fn], exact[fn])
+            print(f'exact_lascala hip/{shape} {fn:16s} {a:10.3g} x 2^-53  = {a * EPS:.2e}')
+            assert a < max(GATE[fn] * 10, 1e-8 / EPS), (shape, fn, a)
